@@ -1,0 +1,686 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Run ONLY in the build container (where /root/reference is mounted, CPU only):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference is pure PyTorch eager code with no tests and no golden vectors of
+its own, so parity is pinned by what this script captures:
+inputs and the reference's outputs, as plain numpy arrays.  Nothing from the
+reference's source text is stored; only data.  The GPU box never runs this
+script (it has no /root/reference) - it only reads the .npz files.
+
+Shims (applied after `import transformers`, this script only):
+  * stub modules timm / timm.models.layers{Swish} / ...activations_me{SwishMe}
+    (quantization/hijacker.py:5-6 imports them, nothing on the path uses them)
+  * transformers.modeling_utils.apply_chunking_to_forward alias
+    (quantized_bert.py:28 - moved to pytorch_utils in transformers 5.x)
+  * dummy modeling_opt._expand_mask/_make_causal_mask (quantized_opt.py:12-13,
+    only used by the decoder shell, not by the attention class)
+"""
+import importlib.machinery
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore")
+
+
+def _shim():
+    import transformers  # noqa: F401
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+    import transformers.models.opt.modeling_opt as mo
+
+    if not hasattr(mu, "apply_chunking_to_forward"):
+        mu.apply_chunking_to_forward = pu.apply_chunking_to_forward
+    for name in ("_expand_mask", "_make_causal_mask"):
+        if not hasattr(mo, name):
+            setattr(mo, name, lambda *a, **k: None)
+
+    def mk(name):
+        m = types.ModuleType(name)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        m.__path__ = []
+        sys.modules[name] = m
+        return m
+
+    class Swish(torch.nn.Module):
+        pass
+
+    class SwishMe(torch.nn.Module):
+        pass
+
+    mk("timm")
+    mk("timm.models")
+    layers = mk("timm.models.layers")
+    layers.Swish = Swish
+    acts = mk("timm.models.layers.activations_me")
+    acts.SwishMe = SwishMe
+
+
+def _f32(t):
+    return t.detach().cpu().to(torch.float32).numpy().copy()
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays")
+
+
+# --------------------------------------------------------------------------------------
+def gen_softmax_rows():
+    sys.path.insert(0, os.path.join(REF, "OutEffHop"))
+    from transformers_language.models.softmax import SOFTMAX_MAPPING
+
+    g = torch.Generator().manual_seed(1001)
+    R, S = 24, 96
+    x = torch.randn(R, S, generator=g)
+    x[8:16] *= 4.0
+    x[16:24] *= 10.0
+    fmin = torch.finfo(torch.float32).min
+    # rows with masked tails (additive finfo.min as HF does), one fully masked row
+    xm = x.clone()
+    xm[0, 60:] = fmin
+    xm[9, 1:] = fmin
+    xm[17, :] = fmin
+    edge = {
+        "known123": torch.tensor([[1.0, 2.0, 3.0]]),
+        "known00": torch.tensor([[0.0, 0.0]]),
+        "allmasked": torch.full((1, 4), fmin),
+        "neg": torch.tensor([[-20.0, -21.0, -30.0]]),
+        "big": torch.tensor([[80.0, 85.0, 88.0, 30.0]]),
+        "below_exp_range": torch.tensor([[-90.0, -95.0, -100.0]]),
+        "near_exp_range": torch.tensor([[-87.0, -88.0, -88.5]]),
+        "single": torch.tensor([[0.3]]),
+    }
+    arrays = {"x": _np(x), "xm": _np(xm)}
+    keys, base, gam, eta = [], [], [], []
+    for k, fn in SOFTMAX_MAPPING.items():
+        if k == "entmax":
+            continue
+        keys.append(k)
+        if k == "vanilla":
+            base.append(0), gam.append(0.0), eta.append(1.0)
+        elif k == "softmax1":
+            base.append(1), gam.append(0.0), eta.append(1.0)
+        else:
+            base.append(1 if fn.func.__name__ == "clipped_softmax1" else 0)
+            gam.append(float(fn.keywords["gamma"]))
+            eta.append(float(fn.keywords["eta"]))
+        arrays[f"y[{k}]"] = _np(fn(x, dim=-1))
+    for k in ("vanilla", "softmax1", "clipped(-.025:1)", "clippedsoftmax1(-.025:1)", "clipped(0:1.03)"):
+        fn = SOFTMAX_MAPPING[k]
+        arrays[f"ym[{k}]"] = _np(fn(xm, dim=-1))
+        for en, ev in edge.items():
+            arrays[f"edge_y[{en}][{k}]"] = _np(fn(ev, dim=-1))
+    for en, ev in edge.items():
+        arrays[f"edge_x[{en}]"] = _np(ev)
+    # pure-fp16 eager behaviour of the reference (documented deviation, SURVEY 7 hard part 3)
+    x16 = torch.tensor([[-12.0, -13.0], [1.0, 2.0], [-5.0, -6.0]], dtype=torch.float16)
+    arrays["fp16_x"] = _np(x16)
+    arrays["fp16_y_softmax1"] = _np(SOFTMAX_MAPPING["softmax1"](x16, dim=-1))
+    arrays["keys"] = np.array(keys)
+    arrays["key_base"] = np.array(base, dtype=np.int32)
+    arrays["key_gamma"] = np.array(gam, dtype=np.float64)
+    arrays["key_eta"] = np.array(eta, dtype=np.float64)
+    arrays["all_keys_in_order"] = np.array(list(SOFTMAX_MAPPING.keys()))
+    save("softmax_rows.npz", **arrays)
+
+
+# --------------------------------------------------------------------------------------
+def gen_fakequant():
+    from quantization.quantizers.uniform_quantizers import (
+        AsymmetricUniformQuantizer,
+        SymmetricUniformQuantizer,
+    )
+
+    g = torch.Generator().manual_seed(1002)
+    x = torch.cat(
+        [
+            torch.randn(2048, generator=g) * 3.0,
+            torch.rand(1024, generator=g),
+            torch.randn(512, generator=g) * 30.0,
+            torch.tensor([0.0, -0.0, 1.0, -1.0, 0.5, 1e-9, -1e-9, 255.0, -255.0, 1e6, -1e6]),
+        ]
+    )
+    arrays = {"x": _np(x)}
+    ranges = [(-3.0, 5.0), (0.0, 1.0), (-0.37, 0.011), (0.2, 7.0), (-80.0, 60.0), (-1e-12, 1e-12)]
+    meta = []
+    for i, (lo, hi) in enumerate(ranges):
+        for nb in (8, 4):
+            q = AsymmetricUniformQuantizer(n_bits=nb)
+            q.set_quant_range(lo, hi)
+            tag = f"asym{i}_b{nb}"
+            arrays[f"{tag}_delta"] = _np(q.delta).astype(np.float64)
+            arrays[f"{tag}_zero_float"] = _np(q.zero_float).astype(np.float64)
+            arrays[f"{tag}_scale"] = _np(q.scale)
+            arrays[f"{tag}_zero_point"] = _np(q.zero_point)
+            arrays[f"{tag}_idx"] = _np(q.to_integer_forward(x))
+            arrays[f"{tag}_xq"] = _np(q(x))
+            meta.append(dict(tag=tag, lo=lo, hi=hi, n_bits=nb, kind="asym"))
+    # float64 range scalars as produced by np.percentile
+    data = (torch.rand(4, 8, 16, 16, generator=g) ** 3).numpy()
+    lo64, hi64 = np.percentile(data, (100 - 99.999, 99.999))
+    q = AsymmetricUniformQuantizer(n_bits=8)
+    q.set_quant_range(torch.tensor(lo64), torch.tensor(hi64))
+    xs = torch.from_numpy(data).reshape(-1)
+    arrays["pct_x"] = data.reshape(-1)
+    arrays["pct_lo"] = np.float64(lo64)
+    arrays["pct_hi"] = np.float64(hi64)
+    arrays["pct_delta"] = _np(q.delta)
+    arrays["pct_zero_float"] = _np(q.zero_float)
+    arrays["pct_idx"] = _np(q.to_integer_forward(xs))
+    arrays["pct_xq"] = _np(q(xs))
+    assert q.delta.dtype == torch.float64
+    # symmetric (weights) - for the QuantLinear shell around the path
+    w = torch.randn(64, 48, generator=g) * 0.05
+    q = SymmetricUniformQuantizer(n_bits=8)
+    q.set_quant_range(w.min(), w.max())
+    arrays["sym_w"] = _np(w)
+    arrays["sym_delta"] = _np(q.delta)
+    arrays["sym_signed"] = np.array(bool(q.signed))
+    arrays["sym_wq"] = _np(q(w))
+    arrays["meta_json"] = np.array(json.dumps(meta))
+    save("fakequant.npz", **arrays)
+
+
+# --------------------------------------------------------------------------------------
+def gen_range_estimators():
+    from quantization.range_estimators import CurrentMinMaxEstimator, RunningMinMaxEstimator
+    from quantization.quantizers.uniform_quantizers import AsymmetricUniformQuantizer
+
+    g = torch.Generator().manual_seed(1003)
+    batches = [torch.randn(2, 4, 16, 16, generator=g) * (1.0 + 0.5 * i) for i in range(4)]
+    arrays = {f"batch{i}": _np(b) for i, b in enumerate(batches)}
+    for tag, kw in (("pct", dict(percentile=99.999)), ("minmax", dict()), ("pct99", dict(percentile=99.0))):
+        est = RunningMinMaxEstimator(**kw)
+        q = AsymmetricUniformQuantizer(n_bits=8)
+        traj = []
+        for b in batches:
+            lo, hi = est(b)
+            q.set_quant_range(lo, hi)
+            traj.append([float(lo), float(hi), float(q.delta), float(q.zero_float)])
+        arrays[f"running_{tag}_traj"] = np.array(traj, dtype=np.float64)
+    est = CurrentMinMaxEstimator()
+    lo, hi = est(batches[0])
+    arrays["current_minmax"] = np.array([float(lo), float(hi)])
+    save("range_estimators.npz", **arrays)
+
+
+# --------------------------------------------------------------------------------------
+class _Cfg:
+    hidden_size = 128
+    num_attention_heads = 2
+    attention_probs_dropout_prob = 0.1
+    position_embedding_type = "absolute"
+    is_decoder = False
+    max_position_embeddings = 64
+
+
+GATE_CASES = {
+    # name: ctor kwargs (gate type given by name)
+    "nogate": dict(),
+    "uncond_head": dict(attn_gate_type="unconditional_per_head"),
+    "tok_linear": dict(attn_gate_type="conditional_per_token", attn_gate_init=0.25),
+    "tok_mlp": dict(attn_gate_type="conditional_per_token", attn_gate_mlp=True),
+    "tok_mlp2": dict(attn_gate_type="conditional_per_token", attn_gate_mlp2=True),
+    "head_linear": dict(attn_gate_type="conditional_per_head", attn_gate_init=0.5),
+    "head_mlp": dict(attn_gate_type="conditional_per_head", attn_gate_mlp=True),
+    "tok_allfeat": dict(attn_gate_type="conditional_per_token", attn_gate_linear_all_features=True),
+    "tok_linear_ft": dict(attn_gate_type="conditional_per_token", attn_gate_init=0.25, fine_tuning=True),
+}
+
+
+def _randomise_gate(mod, g):
+    """Default init leaves some gate params trivial (zeros); perturb all of them, seeded."""
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            if n.startswith("alpha"):
+                p.add_(torch.randn(p.shape, generator=g) * 0.3)
+
+
+def _bert_mask(B, S, lengths, dtype=torch.float32):
+    m = torch.zeros(B, 1, 1, S, dtype=dtype)
+    for b, L in enumerate(lengths):
+        m[b, :, :, L:] = torch.finfo(dtype).min
+    return m
+
+
+def _opt_mask(B, T, lengths, dtype=torch.float32):
+    """HF 4.31 OPTDecoder._prepare_decoder_attention_mask semantics: causal(finfo.min) + padding(finfo.min)."""
+    fmin = torch.finfo(dtype).min
+    causal = torch.full((T, T), fmin, dtype=dtype).triu(1)[None, None].expand(B, 1, T, T).clone()
+    pad = torch.zeros(B, 1, T, T, dtype=dtype)
+    for b, L in enumerate(lengths):  # left-aligned tokens, right padding
+        pad[b, :, :, L:] = fmin
+    return causal + pad  # may hit -inf: the module clamps with torch.max(., finfo.min)
+
+
+def gen_bert_fp():
+    from transformers_language.models.bert_attention import AttentionGateType, BertSelfAttentionWithExtras
+    from transformers_language.models.softmax import SOFTMAX_MAPPING
+
+    B, S = 2, 32
+    g = torch.Generator().manual_seed(1004)
+    hidden = torch.randn(B, S, _Cfg.hidden_size, generator=g)
+    mask = _bert_mask(B, S, [32, 20])
+    arrays = {"hidden": _np(hidden), "mask": _np(mask)}
+    torch.manual_seed(2004)
+    base = BertSelfAttentionWithExtras(_Cfg())
+    base_sd = {k: v.clone() for k, v in base.state_dict().items()}
+    for k, v in base_sd.items():
+        arrays[f"w.{k}"] = _np(v)
+    cases = []
+    for sm in ("vanilla", "softmax1", "clipped(-.025:1)", "clippedsoftmax1(-.025:1)", "clippedsoftmax1(-.0001:1)"):
+        cases.append((f"sm[{sm}]", sm, "nogate"))
+    for gc in GATE_CASES:
+        if gc != "nogate":
+            cases.append((f"gate[{gc}]", "softmax1", gc))
+    names = []
+    for name, sm, gc in cases:
+        kw = dict(GATE_CASES[gc])
+        if "attn_gate_type" in kw:
+            kw["attn_gate_type"] = AttentionGateType[kw["attn_gate_type"]]
+        torch.manual_seed(3000 + len(names))
+        mod = BertSelfAttentionWithExtras(_Cfg(), softmax_fn=SOFTMAX_MAPPING[sm], **kw)
+        mod.load_state_dict(base_sd, strict=False)
+        _randomise_gate(mod, g)
+        mod.eval()
+        for k, v in mod.state_dict().items():
+            if k.startswith("alpha"):
+                arrays[f"{name}.w.{k}"] = _np(v)
+        with torch.no_grad():
+            ctx, probs = mod(hidden, attention_mask=mask, output_attentions=True)
+            ctx_nomask = mod(hidden)[0]
+        arrays[f"{name}.ctx"] = _np(ctx)
+        arrays[f"{name}.probs"] = _np(probs)
+        arrays[f"{name}.ctx_nomask"] = _np(ctx_nomask)
+        if mod.last_gate_avg_prob is not None:
+            arrays[f"{name}.last_gate_avg_prob"] = _np(mod.last_gate_avg_prob)
+        arrays[f"{name}.gate_scaling_factor"] = np.float64(mod.gate_scaling_factor)
+        names.append(json.dumps(dict(name=name, softmax=sm, gate=gc)))
+    # alpha (ctor arg) -> clipped softmax with gamma=-alpha/max_seq_length (bert_attention.py:89-92)
+    mod = BertSelfAttentionWithExtras(_Cfg(), alpha=4.0, max_seq_length=S)
+    mod.load_state_dict(base_sd, strict=False)
+    mod.eval()
+    with torch.no_grad():
+        arrays["alpha4.ctx"] = _np(mod(hidden, attention_mask=mask)[0])
+    # skip_attn
+    mod = BertSelfAttentionWithExtras(_Cfg(), skip_attn=True)
+    arrays["skip.ctx"] = _np(mod(hidden)[0])
+    # fp16 module (pure fp16 eager math in the reference) - documented deviation case
+    mod = BertSelfAttentionWithExtras(_Cfg(), softmax_fn=SOFTMAX_MAPPING["softmax1"])
+    mod.load_state_dict(base_sd, strict=False)
+    mod = mod.half().eval()
+    with torch.no_grad():
+        arrays["half.ctx"] = _np(mod(hidden.half(), attention_mask=_bert_mask(B, S, [32, 20], torch.float16))[0])
+    arrays["cases_json"] = np.array(names)
+    save("bert_attn_fp.npz", **arrays)
+
+
+def gen_opt_fp():
+    from transformers_language.models.bert_attention import AttentionGateType
+    from transformers_language.models.opt_attention import OPTAttentionWithExtras
+    from transformers_language.models.softmax import SOFTMAX_MAPPING
+
+    B, T, E, H = 2, 32, 128, 2
+    g = torch.Generator().manual_seed(1005)
+    hidden = torch.randn(B, T, E, generator=g)
+    mask = _opt_mask(B, T, [32, 23])
+    arrays = {"hidden": _np(hidden), "mask": _np(mask)}
+    torch.manual_seed(2005)
+    base = OPTAttentionWithExtras(E, H, is_decoder=True)
+    base_sd = {k: v.clone() for k, v in base.state_dict().items()}
+    for k, v in base_sd.items():
+        arrays[f"w.{k}"] = _np(v)
+    cases = []
+    for sm in ("vanilla", "softmax1", "clippedsoftmax1(-.025:1)", "clipped(-.003:1.003)"):
+        cases.append((f"sm[{sm}]", sm, "nogate"))
+    for gc in ("uncond_head", "tok_linear", "tok_mlp", "head_linear", "tok_allfeat", "tok_linear_ft"):
+        cases.append((f"gate[{gc}]", "softmax1", gc))
+    names = []
+    for name, sm, gc in cases:
+        kw = dict(GATE_CASES[gc])
+        if "attn_gate_type" in kw:
+            kw["attn_gate_type"] = AttentionGateType[kw["attn_gate_type"]]
+        torch.manual_seed(3100 + len(names))
+        mod = OPTAttentionWithExtras(E, H, is_decoder=True, softmax_fn=SOFTMAX_MAPPING[sm], **kw)
+        mod.load_state_dict(base_sd, strict=False)
+        _randomise_gate(mod, g)
+        mod.eval()
+        for k, v in mod.state_dict().items():
+            if k.startswith("alpha"):
+                arrays[f"{name}.w.{k}"] = _np(v)
+        with torch.no_grad():
+            out, w, past = mod(hidden, attention_mask=mask, output_attentions=True)
+            out_nomask = mod(hidden)[0]
+        arrays[f"{name}.out"] = _np(out)
+        arrays[f"{name}.probs"] = _np(w)
+        arrays[f"{name}.out_nomask"] = _np(out_nomask)
+        arrays[f"{name}.gate_scaling_factor"] = np.float64(mod.gate_scaling_factor)
+        names.append(json.dumps(dict(name=name, softmax=sm, gate=gc)))
+    arrays["past_k"] = _np(past[0])
+    arrays["past_v"] = _np(past[1])
+    # ctor alpha path (opt_attention.py:70-77): `attn_softmax is "softmax1"` is an identity test on a
+    # literal; record what the reference actually does for alpha=12, attn_softmax="softmax1".
+    mod = OPTAttentionWithExtras(E, H, is_decoder=True, alpha=12.0, max_seq_length=T, attn_softmax="softmax1")
+    mod.load_state_dict(base_sd, strict=False)
+    mod.eval()
+    arrays["alpha12.softmax_fn_name"] = np.array(mod.softmax_fn.func.__name__)
+    with torch.no_grad():
+        arrays["alpha12.out"] = _np(mod(hidden, attention_mask=mask)[0])
+    # the fp16 + softmax1 TypeError - record the exception type name
+    mod = OPTAttentionWithExtras(E, H, softmax_fn=SOFTMAX_MAPPING["softmax1"]).half().eval()
+    try:
+        mod(hidden.half(), attention_mask=_opt_mask(B, T, [32, 23], torch.float16))
+        err = "none"
+    except Exception as e:  # noqa: BLE001
+        err = type(e).__name__
+    arrays["half_softmax1_error"] = np.array(err)
+    arrays["cases_json"] = np.array(names)
+    save("opt_attn_fp.npz", **arrays)
+
+
+# --------------------------------------------------------------------------------------
+def _qparams(percentile=99.999):
+    from quantization.range_estimators import RangeEstimators  # noqa: F401
+    from transformers_language.quant_configs import get_quant_config
+    from transformers_language.utils import val_qparams
+
+    cfg = get_quant_config()
+    # validate_clm.py:444-454: asymmetric acts, running_minmax, percentile option
+    cfg.act_quant.options = dict(percentile=percentile) if percentile else {}
+    qp = val_qparams(cfg)
+    qp["quant_dict"] = {}
+    return qp
+
+
+def _capture_quant_io(qmod):
+    """Hook the three activation quantizers: record pre-quant input, output, integer indices."""
+    rec = {}
+
+    def mk(tag, m):
+        def hook(mod, inp, out):
+            x = inp[0].detach()
+            rec[f"{tag}.in"] = _np(x)
+            rec[f"{tag}.out"] = _np(out.detach())
+            rec[f"{tag}.idx"] = _np(mod.activation_quantizer.quantizer.to_integer_forward(x)).astype(np.uint8)
+
+        return m.register_forward_hook(hook)
+
+    hs = [
+        mk("scores", qmod.attn_scores_act_quantizer),
+        mk("probs", qmod.attn_probs_act_quantizer),
+        mk("ctx", qmod.context_act_quantizer),
+    ]
+    return rec, hs
+
+
+def _dump_quantizers(prefix, qmod, arrays):
+    for n, m in qmod.named_modules():
+        q = getattr(m, "quantizer", None)
+        if n.endswith("range_estimator"):
+            continue  # holds a reference to the same quantizer object
+        if q is not None and getattr(q, "_delta", None) is not None:
+            arrays[f"{prefix}.q.{n}.delta"] = np.float64(float(q._delta))
+            zf = getattr(q, "_zero_float", None)
+            if zf is not None:
+                arrays[f"{prefix}.q.{n}.zero_float"] = np.float64(float(zf))
+            sg = getattr(q, "_signed", None)
+            if sg is not None:
+                arrays[f"{prefix}.q.{n}.signed"] = np.array(bool(sg))
+
+
+def gen_int8():
+    from transformers_language.models.bert_attention import AttentionGateType, BertSelfAttentionWithExtras
+    from transformers_language.models.opt_attention import OPTAttentionWithExtras
+    from transformers_language.models.quantized_bert import QuantizedBertSelfAttentionWithExtras
+    from transformers_language.models.quantized_opt import QuantizedOPTAttentionWithExtras
+    from transformers_language.models.softmax import SOFTMAX_MAPPING
+
+    B, S, E, H = 2, 32, 128, 2
+    arrays = {}
+    meta = []
+    g = torch.Generator().manual_seed(1006)
+    calib = [torch.randn(B, S, E, generator=g) * (1.0 + 0.1 * i) for i in range(4)]
+    evalx = torch.randn(B, S, E, generator=g)
+    for i, c in enumerate(calib):
+        arrays[f"calib{i}"] = _np(c)
+    arrays["eval"] = _np(evalx)
+    bmask = _bert_mask(B, S, [32, 20])
+    omask = _opt_mask(B, S, [32, 23])
+    arrays["bert_mask"] = _np(bmask)
+    arrays["opt_mask"] = _np(omask)
+
+    def run(prefix, qmod, fwd):
+        qmod.set_quant_state(weight_quant=True, act_quant=True)
+        qmod.eval()
+        with torch.no_grad():
+            for c in calib:
+                fwd(qmod, c)
+            qmod.fix_ranges()
+            _dump_quantizers(prefix, qmod, arrays)
+            rec, hs = _capture_quant_io(qmod)
+            out = fwd(qmod, evalx)
+            for h in hs:
+                h.remove()
+        for k, v in rec.items():
+            arrays[f"{prefix}.{k}"] = v
+        arrays[f"{prefix}.out"] = _np(out[0])
+        # Q/K/V as the attention core sees them (outputs of the QuantLinear shells)
+        with torch.no_grad():
+            if hasattr(qmod, "q_proj"):
+                arrays[f"{prefix}.q_lin"] = _np(qmod.q_proj(evalx))
+                arrays[f"{prefix}.k_lin"] = _np(qmod.k_proj(evalx))
+                arrays[f"{prefix}.v_lin"] = _np(qmod.v_proj(evalx))
+            else:
+                arrays[f"{prefix}.q_lin"] = _np(qmod.query(evalx))
+                arrays[f"{prefix}.k_lin"] = _np(qmod.key(evalx))
+                arrays[f"{prefix}.v_lin"] = _np(qmod.value(evalx))
+
+    for sm, gc in (("softmax1", "nogate"), ("softmax1", "tok_linear"), ("clippedsoftmax1(-.025:1)", "nogate"), ("vanilla", "nogate")):
+        kw = dict(GATE_CASES[gc])
+        if "attn_gate_type" in kw:
+            kw["attn_gate_type"] = AttentionGateType[kw["attn_gate_type"]]
+        tag = f"[{sm}|{gc}]"
+        torch.manual_seed(2006)
+        org = BertSelfAttentionWithExtras(_Cfg(), softmax_fn=SOFTMAX_MAPPING[sm], **kw)
+        _randomise_gate(org, torch.Generator().manual_seed(7))
+        for k, v in org.state_dict().items():
+            arrays[f"bert{tag}.w.{k}"] = _np(v)
+        qmod = QuantizedBertSelfAttentionWithExtras(org, **_qparams())
+        run(f"bert{tag}", qmod, lambda m, x: m(x, attention_mask=bmask))
+        torch.manual_seed(2007)
+        org = OPTAttentionWithExtras(E, H, is_decoder=True, softmax_fn=SOFTMAX_MAPPING[sm], **kw)
+        _randomise_gate(org, torch.Generator().manual_seed(8))
+        for k, v in org.state_dict().items():
+            arrays[f"opt{tag}.w.{k}"] = _np(v)
+        qmod = QuantizedOPTAttentionWithExtras(org, **_qparams())
+        run(f"opt{tag}", qmod, lambda m, x: m(x, attention_mask=omask))
+        meta.append(dict(tag=tag, softmax=sm, gate=gc))
+    arrays["meta_json"] = np.array(json.dumps(meta))
+    save("int8_attn.npz", **arrays)
+
+
+# --------------------------------------------------------------------------------------
+def gen_stanhop():
+    sys.path.insert(0, os.path.join(REF, "STanHop_time_seeries"))
+    # cross_models/ and OutEffHop both have a package-less `cross_models`; import fresh
+    from cross_models.hopfield import Association, Hopfield, HopfieldPooling
+
+    g = torch.Generator().manual_seed(1007)
+    B, L, S, H, E = 3, 7, 5, 4, 16
+    q = torch.randn(B, L, H, E, generator=g)
+    k = torch.randn(B, S, H, E, generator=g)
+    v = torch.randn(B, S, H, E, generator=g)
+    arrays = {"q": _np(q), "k": _np(k), "v": _np(v)}
+    for mode in ("softmax1", "softmax", "clip"):
+        m = Association(mode=mode).eval()
+        with torch.no_grad():
+            arrays[f"assoc[{mode}]"] = _np(m(q, k, v))
+    m = Association(mode="softmax1", scale=0.37).eval()
+    with torch.no_grad():
+        arrays["assoc[softmax1,scale=0.37]"] = _np(m(q, k, v))
+    try:
+        Association(mode="clip_softmax1")
+        err = "none"
+    except Exception as e:  # noqa: BLE001
+        err = type(e).__name__
+    arrays["clip_softmax1_ctor_error"] = np.array(err)
+    # Hopfield / HopfieldPooling modules (V is computed from the projected K: hopfield.py:78)
+    torch.manual_seed(2008)
+    hop = Hopfield(64, 4, mode="softmax1").eval()
+    x = torch.randn(6, 28, 64, generator=g)
+    y = torch.randn(6, 11, 64, generator=g)
+    for kk, vv in hop.state_dict().items():
+        arrays[f"hop.w.{kk}"] = _np(vv)
+    with torch.no_grad():
+        arrays["hop.x"] = _np(x)
+        arrays["hop.y"] = _np(y)
+        arrays["hop.self"] = _np(hop(x, x, x))
+        arrays["hop.cross"] = _np(hop(x, y, y))
+    torch.manual_seed(2009)
+    pool = HopfieldPooling(64, 4, num_pattern=3, mode="softmax1").eval()
+    with torch.no_grad():
+        torch.nn.init.normal_(pool.key, generator=g)
+        for kk, vv in pool.state_dict().items():
+            arrays[f"pool.w.{kk}"] = _np(vv)
+        arrays["pool.out"] = _np(pool(x))
+    save("stanhop_assoc.npz", **arrays)
+    sys.path.remove(os.path.join(REF, "STanHop_time_seeries"))
+    for mname in [m for m in sys.modules if m.startswith("cross_models")]:
+        del sys.modules[mname]
+
+
+def gen_theory_cfg1():
+    """BASELINE config 1: theory_verification single Hopfield layer, B=4 S=64 d=32, CPU eager."""
+    tv = os.path.join(REF, "theory_verification")
+    sys.path.insert(0, tv)
+    saved = {m: sys.modules.pop(m) for m in list(sys.modules) if m == "utils" or m.startswith("utils.") or m == "layers"}
+    import layers as tv_layers
+    from functions import softmax_1 as tv_softmax_1
+
+    torch.manual_seed(0)
+    hop = tv_layers.Hopfield(d_model=32, n_heads=1, dropout=0.0).eval()
+    R = torch.randn(4, 64, 32)
+    arrays = {"R": _np(R)}
+    for kk, vv in hop.state_dict().items():
+        arrays[f"w.{kk}"] = _np(vv)
+    with torch.no_grad():
+        arrays["out_softmax"] = _np(hop(R, R))  # reference as-is: Association hard-codes torch.softmax (layers.py:120)
+        # config 1 proper: same structure with the reference's softmax_1 substituted for torch.softmax
+        q = hop.query_projection(R).view(4, 64, 1, -1)
+        kproj = hop.key_projection(R)
+        v = hop.value_projection(kproj).view(4, 64, 1, -1)
+        k = kproj.view(4, 64, 1, -1)
+        scores = torch.einsum("blhe,bshe->bhls", q, k)
+        A = tv_softmax_1((1.0 / np.sqrt(32)) * scores, dim=-1)
+        V = torch.einsum("bhls,bshd->blhd", A, v).contiguous()
+        arrays["out_softmax1"] = _np(hop.out_projection(V.view(4, 64, -1)))
+        arrays["assoc_q"] = _np(q)
+        arrays["assoc_k"] = _np(k)
+        arrays["assoc_v"] = _np(v)
+        arrays["assoc_out_softmax1"] = _np(V)
+    save("theory_hopfield_cfg1.npz", **arrays)
+    sys.path.remove(tv)
+    for m in ("layers", "functions"):
+        sys.modules.pop(m, None)
+    sys.modules.update(saved)
+
+
+def gen_vit():
+    from transformers_language.models.bert_attention import AttentionGateType
+    from transformers_language.models.softmax import SOFTMAX_MAPPING
+    from transformers_language.models.vit_attention import ViTSelfAttentionWithExtras
+
+    g = torch.Generator().manual_seed(1010)
+    B, N, C, H = 2, 19, 128, 2
+    x = torch.randn(B, N, C, generator=g)
+    arrays = {"x": _np(x)}
+    names = []
+    for name, sm, gc in (("sm[softmax1]", "softmax1", "nogate"), ("sm[vanilla]", "vanilla", "nogate"),
+                         ("sm[clippedsoftmax1(-.025:1)]", "clippedsoftmax1(-.025:1)", "nogate"),
+                         ("gate[tok_linear]", "softmax1", "tok_linear"), ("gate[uncond_head]", "softmax1", "uncond_head")):
+        kw = dict(GATE_CASES[gc])
+        if "attn_gate_type" in kw:
+            kw["attn_gate_type"] = AttentionGateType[kw["attn_gate_type"]]
+        torch.manual_seed(2010)
+        mod = ViTSelfAttentionWithExtras(C, num_heads=H, qkv_bias=True, softmax_fn=SOFTMAX_MAPPING[sm], **kw)
+        _randomise_gate(mod, torch.Generator().manual_seed(9))
+        mod.eval()
+        for kk, vv in mod.state_dict().items():
+            arrays[f"{name}.w.{kk}"] = _np(vv)
+        with torch.no_grad():
+            arrays[f"{name}.out"] = _np(mod(x))
+        arrays[f"{name}.fused_attn_flag"] = np.array(bool(mod.fused_attn))
+        names.append(json.dumps(dict(name=name, softmax=sm, gate=gc)))
+    arrays["cases_json"] = np.array(names)
+    save("vit_attn_fp.npz", **arrays)
+
+
+def gen_core_cases():
+    """Core (B,H,S,d) attention at small sizes straight from reference primitives, fp32 math on
+    fp16-rounded inputs - the definition of the fp16 oracle - BERT and OPT op orders."""
+    from transformers_language.models.softmax import SOFTMAX_MAPPING
+
+    g = torch.Generator().manual_seed(1011)
+    arrays = {}
+    B, H, S, d = 2, 3, 80, 64
+    q = torch.randn(B, H, S, d, generator=g).half().float()
+    k = torch.randn(B, H, S, d, generator=g).half().float()
+    v = torch.randn(B, H, S, d, generator=g).half().float()
+    arrays.update(q=_np(q), k=_np(k), v=_np(v))
+    pad = _bert_mask(B, S, [80, 51])
+    arrays["pad_mask"] = _np(pad)
+    for sm in ("softmax1", "vanilla", "clippedsoftmax1(-.025:1)"):
+        fn = SOFTMAX_MAPPING[sm]
+        # BERT order (bert_attention.py:222,265,272,276,292)
+        sc = torch.matmul(q, k.transpose(-1, -2)) / np.sqrt(d)
+        p = fn(sc + pad, dim=-1)
+        arrays[f"bert[{sm}].probs"] = _np(p)
+        arrays[f"bert[{sm}].ctx"] = _np(torch.matmul(p, v))
+        # OPT order (opt_attention.py:167,204,220-224,232,263): q pre-scaled and (fp16 storage) re-rounded
+        qs = (q * d ** -0.5).half().float()
+        sc = torch.bmm(qs.view(B * H, S, d), k.view(B * H, S, d).transpose(1, 2)).view(B, H, S, S)
+        m = _opt_mask(B, S, [80, 51])
+        sc = torch.max(sc + m, torch.tensor(torch.finfo(torch.float32).min))
+        p = fn(sc.view(B * H, S, S), dim=-1)
+        arrays[f"opt[{sm}].probs"] = _np(p.view(B, H, S, S))
+        arrays[f"opt[{sm}].ctx"] = _np(torch.bmm(p, v.view(B * H, S, d)).view(B, H, S, d))
+    arrays["opt_mask"] = _np(_opt_mask(B, S, [80, 51]))
+    save("core_attn.npz", **arrays)
+
+
+def main():
+    assert os.path.isdir(REF), "reference not mounted: golden fixtures can only be generated in the build container"
+    torch.set_num_threads(1)  # deterministic reduction order for the captured outputs
+    _shim()
+    gen_softmax_rows()
+    gen_fakequant()
+    gen_range_estimators()
+    gen_bert_fp()
+    gen_opt_fp()
+    gen_int8()
+    gen_vit()
+    gen_core_cases()
+    gen_stanhop()
+    gen_theory_cfg1()
+
+
+if __name__ == "__main__":
+    main()

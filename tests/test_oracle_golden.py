@@ -1,0 +1,219 @@
+"""Pin the CPU oracle (oracle/oeh_oracle.py) against fixtures captured from the reference itself
+(tests/golden/make_golden.py).  CPU only; no reference import, no HIP."""
+import json
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oeh_oracle as O
+from tests.conftest import load_golden
+
+ELEM = dict(rtol=2e-6, atol=1e-7)   # elementwise chains: exp() implementations differ by <= 1-2 ulp
+MM = dict(rtol=1e-5, atol=2e-6)     # chains containing fp32 matmuls (BLAS accumulation order)
+
+
+def test_softmax_table_matches_reference_registry():
+    g = load_golden("softmax_rows.npz")
+    tbl = O.softmax_table()
+    ref_keys = [k for k in g["all_keys_in_order"] if k != "entmax"]
+    assert list(tbl.keys()) == ref_keys and len(tbl) == 39
+    for k, b, ga, et in zip(g["keys"], g["key_base"], g["key_gamma"], g["key_eta"]):
+        assert tbl[str(k)] == (int(b), float(ga), float(et)), k
+    assert tbl["clippedsoftmax1(-.025:1)"] == (1, -0.025, 1.1)      # eta quirk, softmax.py:61
+    assert tbl["clipped(-.005:1.005)"] == (0, -0.003, 1.005)        # gamma quirk, softmax.py:57
+
+
+def test_softmax_rows_all_keys():
+    g = load_golden("softmax_rows.npz")
+    tbl = O.softmax_table()
+    for k, (b, ga, et) in tbl.items():
+        np.testing.assert_allclose(O.apply_softmax(g["x"], b, ga, et), g[f"y[{k}]"], err_msg=k, **ELEM)
+
+
+def test_softmax_masked_and_edge_rows():
+    g = load_golden("softmax_rows.npz")
+    tbl = O.softmax_table()
+    edges = ["known123", "known00", "allmasked", "neg", "big", "below_exp_range", "near_exp_range", "single"]
+    for k in ("vanilla", "softmax1", "clipped(-.025:1)", "clippedsoftmax1(-.025:1)", "clipped(0:1.03)"):
+        b, ga, et = tbl[k]
+        np.testing.assert_allclose(O.apply_softmax(g["xm"], b, ga, et), g[f"ym[{k}]"], err_msg=k, **ELEM)
+        for e in edges:
+            got = O.apply_softmax(g[f"edge_x[{e}]"], b, ga, et)
+            np.testing.assert_allclose(got, g[f"edge_y[{e}][{k}]"], err_msg=f"{k}/{e}", **ELEM)
+    # known answers quoted in SURVEY 8c
+    np.testing.assert_allclose(O.softmax_1(np.array([0.0, 0.0])), [1 / 3, 1 / 3], rtol=1e-6)
+    np.testing.assert_allclose(O.softmax_1(np.array([1.0, 2.0, 3.0])), [0.0871443227, 0.2368828356, 0.6439142823], rtol=1e-6)
+    # fully masked row -> exactly zero under softmax1 (vanilla gives uniform)
+    assert np.all(O.softmax_1(g["edge_x[allmasked]"]) == 0.0)
+    assert np.all(g["edge_y[allmasked][softmax1]"] == 0.0)
+    assert np.all(O.softmax_1(g["edge_x[below_exp_range]"]) == 0.0)
+
+
+def test_fp16_eager_deviation_is_documented():
+    """Reference in pure-fp16 eager math zeroes rows with max < -11.09 (exp(-m) overflows in fp16);
+    the oracle / kernel contract is fp32 math on the fp16-rounded inputs."""
+    g = load_golden("softmax_rows.npz")
+    ref16 = g["fp16_y_softmax1"].astype(np.float32)
+    mine = O.softmax_1(g["fp16_x"].astype(np.float32))
+    assert np.all(ref16[0] == 0.0) and np.all(mine[0] > 0) and np.all(mine[0] < 1e-4)
+    np.testing.assert_allclose(mine[1:], ref16[1:], atol=1e-3)
+
+
+def test_fake_quant_bit_exact():
+    g = load_golden("fakequant.npz")
+    for m in json.loads(str(g["meta_json"])):
+        t = m["tag"]
+        scale, zp, qmax = O.fq_grid(g[f"{t}_delta"], g[f"{t}_zero_float"], m["n_bits"])
+        assert scale == g[f"{t}_scale"] and zp == g[f"{t}_zero_point"], t
+        idx = O.fq_index(g["x"], scale, zp, qmax)
+        assert np.array_equal(idx, g[f"{t}_idx"]), t
+        assert np.array_equal(O.fq_dequant(idx, scale, zp), g[f"{t}_xq"]), t
+        d, z = O.quant_range_to_params(m["lo"], m["hi"], m["n_bits"])
+        assert np.float32(d) == np.float32(g[f"{t}_delta"]) and np.float32(z) == np.float32(g[f"{t}_zero_float"]), t
+    # float64 calibration scalars (np.percentile) -> same grid after fp32 rounding
+    d, z = O.quant_range_to_params(np.float64(g["pct_lo"]), np.float64(g["pct_hi"]))
+    assert d == g["pct_delta"] and z == g["pct_zero_float"] and d.dtype == np.float64
+    xq, idx = O.fake_quant(g["pct_x"], g["pct_delta"], g["pct_zero_float"])
+    assert np.array_equal(idx, g["pct_idx"]) and np.array_equal(xq, g["pct_xq"])
+    assert np.array_equal(O.sym_weight_quant(g["sym_w"]), g["sym_wq"])
+
+
+def test_running_minmax_estimator():
+    g = load_golden("range_estimators.npz")
+    for tag, kw in (("pct", dict(percentile=99.999)), ("minmax", dict()), ("pct99", dict(percentile=99.0))):
+        est = O.RunningMinMax(**kw)
+        for i in range(4):
+            lo, hi = est.update(g[f"batch{i}"])
+            d, z = O.quant_range_to_params(lo, hi)
+            np.testing.assert_allclose([lo, hi, d, z], g[f"running_{tag}_traj"][i], rtol=1e-6, atol=1e-9, err_msg=f"{tag}/{i}")
+
+
+def _state(g, prefix, case=None):
+    sd = {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+    if case is not None:
+        sd.update({k[len(case) + 3:]: g[k] for k in g.files if k.startswith(case + ".w.")})
+    return sd
+
+
+def _case_kwargs(c, tbl):
+    b, ga, et = tbl[c["softmax"]]
+    return dict(base=b, gamma=ga, eta=et, clip=not (ga == 0.0 and et == 1.0), per_head_pool=c["gate"].startswith("head_"))
+
+
+def test_bert_module_fp():
+    g = load_golden("bert_attn_fp.npz")
+    tbl = O.softmax_table()
+    for cj in g["cases_json"]:
+        c = json.loads(str(cj))
+        sd = _state(g, "w.", c["name"])
+        kw = _case_kwargs(c, tbl)
+        gs = float(g[f"{c['name']}.gate_scaling_factor"])
+        ctx, ex = O.bert_self_attention(sd, g["hidden"], 2, mask=g["mask"], gate_scaling=gs, want=("probs",), **kw)
+        np.testing.assert_allclose(ex["probs"], g[f"{c['name']}.probs"], err_msg=c["name"], **MM)
+        np.testing.assert_allclose(ctx, g[f"{c['name']}.ctx"], err_msg=c["name"], **MM)
+        ctx = O.bert_self_attention(sd, g["hidden"], 2, gate_scaling=gs, **kw)
+        np.testing.assert_allclose(ctx, g[f"{c['name']}.ctx_nomask"], err_msg=c["name"], **MM)
+    # ctor alpha=4, max_seq_length=32 -> clipped softmax gamma=-4/32, eta=1 (bert_attention.py:89-92)
+    ctx = O.bert_self_attention(_state(g, "w."), g["hidden"], 2, mask=g["mask"], base=0, gamma=-4.0 / 32, eta=1.0, clip=True)
+    np.testing.assert_allclose(ctx, g["alpha4.ctx"], **MM)
+    assert not g["skip.ctx"].any()
+    # the reference's pure-fp16 module agrees with fp32-math-on-fp16-inputs to ~1e-3 (documented contract)
+    sd16 = {k: v.astype(np.float16).astype(np.float32) for k, v in _state(g, "w.").items()}
+    ctx = O.bert_self_attention(sd16, g["hidden"].astype(np.float16).astype(np.float32), 2, mask=g["mask"])
+    np.testing.assert_allclose(ctx, g["half.ctx"].astype(np.float32), atol=4e-3)
+
+
+def test_opt_module_fp():
+    g = load_golden("opt_attn_fp.npz")
+    tbl = O.softmax_table()
+    for cj in g["cases_json"]:
+        c = json.loads(str(cj))
+        sd = _state(g, "w.", c["name"])
+        kw = _case_kwargs(c, tbl)
+        gs = float(g[f"{c['name']}.gate_scaling_factor"])
+        out, ex = O.opt_attention(sd, g["hidden"], 2, mask=g["mask"], gate_scaling=gs, want=("probs",), **kw)
+        np.testing.assert_allclose(ex["probs"], g[f"{c['name']}.probs"], err_msg=c["name"], **MM)
+        np.testing.assert_allclose(out, g[f"{c['name']}.out"], err_msg=c["name"], **MM)
+        out = O.opt_attention(sd, g["hidden"], 2, gate_scaling=gs, **kw)
+        np.testing.assert_allclose(out, g[f"{c['name']}.out_nomask"], err_msg=c["name"], **MM)
+    # alpha=12, max_seq_length=32, attn_softmax="softmax1": the `is "softmax1"` test (opt_attention.py:73)
+    name = str(g["alpha12.softmax_fn_name"])
+    base = 1 if name == "clipped_softmax1" else 0
+    out = O.opt_attention(_state(g, "w."), g["hidden"], 2, mask=g["mask"], base=base, gamma=-12.0 / 32, eta=1.0, clip=True)
+    np.testing.assert_allclose(out, g["alpha12.out"], **MM)
+    assert str(g["half_softmax1_error"]) == "TypeError"  # fp16 OPT + softmax1 cannot run in the reference
+
+
+def test_core_cases_fp16_inputs():
+    g = load_golden("core_attn.npz")
+    tbl = O.softmax_table()
+    q, k, v = g["q"], g["k"], g["v"]
+    d = q.shape[-1]
+    for sm in ("softmax1", "vanilla", "clippedsoftmax1(-.025:1)"):
+        b, ga, et = tbl[sm]
+        clip = not (ga == 0.0 and et == 1.0)
+        ctx, ex = O.attn_core(q, k, v, scale=math.sqrt(d), scale_is_divisor=True, base=b, gamma=ga, eta=et, clip=clip,
+                              pad_mask=g["pad_mask"].reshape(q.shape[0], -1), want=("probs",))
+        np.testing.assert_allclose(ex["probs"], g[f"bert[{sm}].probs"], **MM)
+        np.testing.assert_allclose(ctx, g[f"bert[{sm}].ctx"], **MM)
+        qs = (q * np.float32(d ** -0.5)).astype(np.float16).astype(np.float32)
+        ctx, ex = O.attn_core(qs, k, v, base=b, gamma=ga, eta=et, clip=clip, full_mask=g["opt_mask"], clamp_min=True, want=("probs",))
+        np.testing.assert_allclose(ex["probs"], g[f"opt[{sm}].probs"], **MM)
+        np.testing.assert_allclose(ctx, g[f"opt[{sm}].ctx"], **MM)
+        # causal flag + key-padding vector == the materialised (B,1,T,S) HF mask
+        padvec = g["opt_mask"][:, 0, -1, :]
+        ctx2 = O.attn_core(qs, k, v, base=b, gamma=ga, eta=et, clip=clip, pad_mask=padvec, causal=True, clamp_min=True)
+        np.testing.assert_allclose(ctx2, g[f"opt[{sm}].ctx"], **MM)
+
+
+def _fq_from_golden(g, prefix):
+    def one(n):
+        return (np.float64(g[f"{prefix}.q.{n}.activation_quantizer.delta"]),
+                np.float64(g[f"{prefix}.q.{n}.activation_quantizer.zero_float"]))
+    return dict(scores=one("attn_scores_act_quantizer"), probs=one("attn_probs_act_quantizer"), ctx=one("context_act_quantizer"))
+
+
+@pytest.mark.parametrize("fam", ["bert", "opt"])
+def test_int8_core_from_captured_qkv(fam):
+    """Given the reference's own (already fake-quantised) Q/K/V, the oracle core reproduces the three
+    quantiser index tensors and the module output.  Index flips can only come from fp32 matmul
+    accumulation order, so they are rare and +-1; everything else must match."""
+    g = load_golden("int8_attn.npz")
+    tbl = O.softmax_table()
+    for m in json.loads(str(g["meta_json"])):
+        pre = f"{fam}{m['tag']}"
+        b, ga, et = tbl[m["softmax"]]
+        clip = not (ga == 0.0 and et == 1.0)
+        fq = _fq_from_golden(g, pre)
+        sd = _state(g, pre + ".w.")
+        H = 2
+        ql, kl, vl = g[f"{pre}.q_lin"], g[f"{pre}.k_lin"], g[f"{pre}.v_lin"]
+        # quantiser boundary: same pre-quant input => identical indices (bit-exact)
+        for name in ("scores", "probs", "ctx"):
+            _, idx = O.fake_quant(g[f"{pre}.{name}.in"], *fq[name])
+            assert np.array_equal(idx.astype(np.uint8), g[f"{pre}.{name}.idx"]), (pre, name)
+        kind, gp = O.gate_params_from_state(sd, H)
+        gate = None if kind is None else O.gate_values(g["eval"], H, kind, gp, False)
+        q, k, v = O.split_heads(ql, H), O.split_heads(kl, H), O.split_heads(vl, H)
+        if fam == "bert":
+            ctx, ex = O.attn_core(q, k, v, scale=8.0, scale_is_divisor=True, base=b, gamma=ga, eta=et, clip=clip,
+                                  pad_mask=g["bert_mask"].reshape(2, -1), gate=gate, fq_scores=fq["scores"], fq_probs=fq["probs"],
+                                  want=("scores_idx", "probs_idx"))
+            out = O.merge_heads(ctx)
+            out, cidx = O.fake_quant(out, *fq["ctx"])
+        else:
+            q = (q * np.float32(64 ** -0.5)).astype(np.float32)
+            ctx, ex = O.attn_core(q, k, v, base=b, gamma=ga, eta=et, clip=clip, full_mask=g["opt_mask"], clamp_min=True, gate=gate,
+                                  fq_scores=fq["scores"], fq_probs=fq["probs"], fq_ctx=fq["ctx"], ctx_quant_before_gate=True,
+                                  want=("scores_idx", "probs_idx", "ctx_idx"))
+            cidx = ex["ctx_idx"]
+        for name, got in (("scores", ex["scores_idx"]), ("probs", ex["probs_idx"]), ("ctx", cidx)):
+            ref = g[f"{pre}.{name}.idx"].reshape(got.shape)
+            diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+            assert diff.max() <= 1 and (diff != 0).mean() < 2e-3, (pre, name, diff.max(), (diff != 0).mean())
+        if fam == "bert":
+            ref = g[f"{pre}.out"]
+            step = np.float32(fq["ctx"][0])
+            bad = np.abs(out - ref) > 1e-5
+            assert bad.mean() < 2e-3 and np.abs(out - ref).max() <= 1.01 * step
