@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Headline benchmark: attention-layer tokens/s of the fused HIP kernel on the reference's OPT-125m
+configuration (opt-12L12H: 12 layers, 12 heads, d=64, S=512; B=16 per GPU), fp16 storage, softmax1, causal.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload opt_softmax1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+step       = one pass of the attention core over one synthetic batch through the model's 12 attention layers
+             (12 launches on 12 DISTINCT q/k/v/o buffer sets, 604 MB per GPU, so nothing stays resident in
+             the 256 MB Infinity Cache between uses: HBM-honest).
+value      = attention-layer tokens/s over all GPUs = N * B*S*layers*K / t   (B*S / t_layer)
+roofline   = algorithmic bytes of one launch (q,k,v in + o out = 4*B*H*S*d*2 B) / mean launch duration measured
+             with HIP events on the launch stream, against the 8 TB/s HBM3E peak.
+cpu_baseline = the eager-torch restatement of the reference op chain (oracle/eager_torch.py) timed on the host
+             cores of this box on a bounded sample (rank 0, N=1 only).
+Multi-GPU: batch-sharded, one process per GPU, NO collective in the timed region (RCCL only for the barriers
+and the max-over-ranks of the wall time).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (B, H, S, d, order, softmax(base, clip, gamma, eta), int8, gate)
+    "opt_softmax1": dict(B=16, H=12, S=512, d=64, order="opt", sm=(1, False, 0.0, 1.0), int8=False, gate=False,
+                         desc="OPT-125m attention core B=16 H=12 S=512 d=64 fp16 causal softmax1"),
+    "opt_clipped": dict(B=16, H=12, S=512, d=64, order="opt", sm=(1, True, -0.025, 1.1), int8=False, gate=False,
+                        desc="OPT-125m attention core B=16 H=12 S=512 d=64 fp16 causal clippedsoftmax1(-.025:1)"),
+    "opt_int8": dict(B=16, H=12, S=512, d=64, order="opt", sm=(1, False, 0.0, 1.0), int8=True, gate=False,
+                     desc="OPT-125m attention core B=16 H=12 S=512 d=64 fp16 causal softmax1 + 3 fused INT8 fake-quantisers"),
+    "bert_softmax1": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=False, gate=False,
+                          desc="BERT-base attention core B=32 H=12 S=128 d=64 fp16 key-padding mask softmax1"),
+    "bert_gated": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=False, gate=True,
+                       desc="BERT-base gated attention core (per-token gate) B=32/GPU H=12 S=128 d=64 fp16"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="opt_softmax1", choices=sorted(WORKLOADS))
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(w, seconds):
+    """Reference op chain (eager torch, fp32, all host threads) on a bounded sample of the same workload."""
+    import torch
+
+    from oracle import eager_torch as E
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Bs = max(1, w["B"] // 4)
+    H, S, d = w["H"], w["S"], w["d"]
+    g = torch.Generator().manual_seed(1235)
+    q = torch.randn(Bs, H, S, d, generator=g).half().float()
+    k = torch.randn(Bs, H, S, d, generator=g).half().float()
+    v = torch.randn(Bs, H, S, d, generator=g).half().float()
+    base, clip, gamma, eta = w["sm"]
+    if w["order"] == "opt":
+        q = (q * d ** -0.5).half().float()
+        mask = E.causal_mask(Bs, S)
+    else:
+        mask = torch.zeros(Bs, 1, 1, S)
+    fq = dict(scores=(0.08, 128.0, 255.0), probs=(1 / 255.0, 0.0, 255.0), ctx=(0.02, 128.0, 255.0)) if w["int8"] else None
+    gate = torch.rand(Bs, H, S, 1, generator=g) if w["gate"] else None
+    run = lambda: E.attn_core_eager(q, k, v, order=w["order"], base=base, clip=clip, gamma=gamma, eta=eta, mask=mask, fq=fq, gate=gate)  # noqa: E731
+    with torch.no_grad():
+        run()
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            run()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or n >= 200:
+                break
+    return dict(value=Bs * S * n / dt, unit="attention-layer tokens/s", cores=cores, kind="port",
+                sample=f"oracle/eager_torch.py (reference eager op chain, fp32, {cores} torch threads), B={Bs} of {w['B']} "
+                       f"H={H} S={S} d={d}, {n} layer passes in {dt:.1f} s")
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    from outeffhop_amd import _lib, ops
+
+    lib = _lib.load()
+    w = WORKLOADS[a.workload]
+    B, H, S, d, L = w["B"], w["H"], w["S"], w["d"], a.layers
+    base, clip, gamma, eta = w["sm"]
+    fmin = float(np.finfo(np.float32).min)
+
+    # ---- synthetic inputs, resident in HBM before the timed region; one buffer set per layer
+    g = torch.Generator(device="cpu").manual_seed(1235 + rank)
+    sets = []
+    for _ in range(L):
+        q = torch.randn(B, S, H * d, generator=g).half()
+        if w["order"] == "opt":
+            q = (q.float() * d ** -0.5).half()  # OPT scales q before QK^T (opt_attention.py:167)
+        k = torch.randn(B, S, H * d, generator=g).half()
+        v = torch.randn(B, S, H * d, generator=g).half()
+        view = lambda t: t.to(dev).view(B, S, H, d).permute(0, 2, 1, 3)  # noqa: E731  (B,H,S,d) view of (B,S,E)
+        o = torch.empty(B, S, H, d, dtype=torch.float16, device=dev).permute(0, 2, 1, 3)
+        sets.append((view(q), view(k), view(v), o))
+    pad = None
+    if w["order"] == "bert":
+        lens = torch.randint(S // 2, S + 1, (B,), generator=g)
+        pad = torch.zeros(B, S)
+        for b_, n_ in enumerate(lens.tolist()):
+            pad[b_, n_:] = fmin
+        pad = pad.to(dev)
+    gate = torch.rand(B, H, S, 1, generator=g).to(dev) if w["gate"] else None
+    fq = None
+    if w["int8"]:
+        FQ = ops.FakeQuantSpec
+        fq = ops.AttnFakeQuant(FQ(0.08, 128.0), FQ(1.0 / 255.0, 0.0), FQ(0.02, 128.0), ctx_before_gate=(w["order"] == "opt"))
+
+    # ---- prebuilt C-ABI descriptors: the timed loop is `oeh_attn_fwd` and nothing else
+    def make_call(q, k, v, o):
+        dsc = _lib.oeh_attn_desc()
+        dsc.B, dsc.H, dsc.Sq, dsc.Sk, dsc.D, dsc.dtype = B, H, S, S, d, _lib.OEH_F16
+        for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", o)):
+            getattr(dsc, name)[:] = [t.stride(0), t.stride(1), t.stride(2)]
+        if w["order"] == "opt":
+            dsc.scale, dsc.scale_div, dsc.causal, dsc.clamp_min = 1.0, 0.0, 1, 1
+        else:
+            dsc.scale, dsc.scale_div = 1.0, 8.0
+            dsc.key_pad_mask, dsc.key_pad_dtype, dsc.key_pad_stride = pad.data_ptr(), _lib.OEH_F32, pad.stride(0)
+        dsc.softmax_base, dsc.clip, dsc.gamma, dsc.eta, dsc.mask_min = base, int(clip), gamma, eta, fmin
+        if gate is not None:
+            dsc.gate = gate.data_ptr()
+            dsc.gate_stride[:] = [gate.stride(0), gate.stride(1), gate.stride(2)]
+        fqd = None
+        if fq is not None:
+            fqd = _lib.oeh_fq_desc()
+            ops._fill_fq(fqd.scores, fq.scores), ops._fill_fq(fqd.probs, fq.probs), ops._fill_fq(fqd.ctx, fq.ctx)
+            fqd.ctx_quant_before_gate = int(fq.ctx_before_gate)
+        args = (C.byref(dsc), C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()),
+                C.c_void_p(o.data_ptr()), None if fqd is None else C.byref(fqd))
+        return args, (dsc, fqd)
+
+    calls = [make_call(*s) for s in sets]
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fwd = lib.oeh_attn_fwd
+
+    def step():
+        for args, _ in calls:
+            rc = fwd(*args, stream)
+            if rc != 0:
+                raise RuntimeError(f"oeh_attn_fwd -> {rc}")
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fence()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(a.steps):
+        step()
+    ev1.record()
+    fence()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+
+    if rank == 0:
+        launches = a.steps * L
+        layer_tokens = world * B * S * L * a.steps
+        kern_s = dev_ms * 1e-3 / launches
+        elt = 2
+        alg_bytes = 4 * B * H * S * d * elt + (B * S * 4 if pad is not None else 0) + (B * H * S * 4 if gate is not None else 0)
+        achieved = alg_bytes / kern_s / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf):  # measured separately with rocprofv3 --pmc (see profiles/README.md); bytes per launch
+            try:
+                traffic = json.load(open(tf)).get(a.workload)
+            except Exception:
+                traffic = None
+        rec = {
+            "metric": "attention tokens/sec/GPU (OPT-125m S=512 softmax1); INT8 max-abs-err vs ref",
+            "value": layer_tokens / wall,
+            "unit": "attention-layer tokens/s (all GPUs)",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": wall * 1e3 / a.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16 storage, f32 accumulate" if not w["int8"] else "f16 storage, f32 accumulate, 8-bit fake-quant grids",
+            "data": "synthetic",
+            "config": {
+                "workload": w["desc"], "variant": ops.attn_variant(B, H, S, S, d, fq=w["int8"]),
+                "batch_per_gpu": B, "seq_len": S, "heads": H, "head_dim": d, "layers_per_step": L,
+                "launches_per_step": L, "model_tokens_per_s": world * B * S * a.steps / wall,
+                "parallelism": f"batch-shard x{world}, no collective in the timed region",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "kernel_us": kern_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
+                "flops_per_launch": 4 * B * H * S * S * d, "tflops": 4 * B * H * S * S * d / kern_s / 1e12,
+            },
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(w, a.cpu_seconds)
+            rec["config"]["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
+        print(json.dumps(rec), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

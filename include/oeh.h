@@ -1,0 +1,159 @@
+/*
+ * oeh.h - C ABI of liboeh_hip.so: the MI355X (gfx950) implementation of OutEffHop's
+ * modified-softmax attention hot path.
+ *
+ * The reference (MAGICS-LAB/OutEffHop) is pure PyTorch eager code and has NO native / FFI
+ * boundary of its own ("Native-code inventory"); its plugin surface is Python
+ * (SOFTMAX_MAPPING, AttentionGateType, the *WithExtras modules).  This header is therefore the
+ * boundary a maintainer would bind from that Python surface (ctypes stub in INTEGRATION.md);
+ * each entry point names the reference op chain it replaces.
+ *
+ * Conventions: plain pointers and sizes only (no torch / HIP types: `stream` is a hipStream_t
+ * passed as void*); every pointer is a DEVICE pointer unless said otherwise; calls enqueue on
+ * `stream` and return immediately; no allocation, no ownership transfer, no host synchronisation
+ * (graph-capture safe); return 0 on success or a negative OEH_E* code, never throw.
+ */
+#ifndef OEH_H_
+#define OEH_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OEH_ABI_VERSION 1
+
+/* error codes (negative errno style) */
+#define OEH_OK 0
+#define OEH_EINVAL (-22)     /* bad argument (null pointer, non-positive size, bad enum) */
+#define OEH_ENOTSUP (-95)    /* shape / dtype / option combination not implemented */
+#define OEH_EALIGN (-14)     /* pointer or stride not aligned as required (16 B rows) */
+#define OEH_ELAUNCH (-5)     /* HIP reported a launch error */
+#define OEH_ENODEV (-19)     /* no gfx950 device / code object not loadable */
+
+/* storage dtypes of q, k, v, o (arithmetic is always fp32 accumulate) */
+#define OEH_F16 0
+#define OEH_BF16 1
+#define OEH_F32 2
+
+/* softmax base: softmax_n with n = 0 (torch softmax) or n = 1 (softmax_1) */
+#define OEH_SOFTMAX_VANILLA 0
+#define OEH_SOFTMAX_ONE 1
+
+/* One per-tensor asymmetric uniform fake-quantiser in fixed-range mode
+ * (AsymmetricUniformQuantizer.forward, OutEffHop/quantization/quantizers/uniform_quantizers.py:119-148;
+ *  QuantizationManager in Qstates.fix_ranges, quantization_manager.py:94-102):
+ *    idx = clamp(rint(x / scale) + zero_point, 0, qmax);  x_q = scale * (idx - zero_point)
+ * scale = float32(max(delta, 1e-8)), zero_point = clamp(rint(zero_float), 0, qmax), qmax = 2^n_bits - 1,
+ * all computed on the host from the calibrated (_delta, _zero_float) buffers.  The division is a
+ * true IEEE fp32 division and rint is round-half-to-even (torch.round). */
+typedef struct oeh_fq {
+  int32_t enable;
+  float scale;
+  float zero_point;
+  float qmax;
+  uint8_t* dump_idx; /* optional (tests): receives idx as uint8, dense row-major in the tensor's logical shape */
+} oeh_fq;
+
+/* The three activation quantisers inside the attention class
+ * (quantized_opt.py:154,182,210; quantized_bert.py:363,374,434). */
+typedef struct oeh_fq_desc {
+  oeh_fq scores;                 /* on QK^T (after scaling), BEFORE the mask is added; dump shape (B,H,Sq,Sk) */
+  oeh_fq probs;                  /* on the softmax output (after clipping);              dump shape (B,H,Sq,Sk) */
+  oeh_fq ctx;                    /* on P@V;                                              dump shape (B,H,Sq,D)  */
+  int32_t ctx_quant_before_gate; /* 1: OPT order (quantized_opt.py:210 then gate :224-261);
+                                    0: BERT order (gate quantized_bert.py:389-426 then quant :434) */
+} oeh_fq_desc;
+
+/* Attention problem descriptor.  Tensors are (B,H,S,D) VIEWS given by element strides for
+ * (batch, head, sequence); the head dim is contiguous.  This covers the reference's layouts:
+ * BERT's permuted view of (B,S,H*D) (bert_attention.py:164-167), OPT's contiguous (B*H,S,D)
+ * (opt_attention.py:146-147,198-201), ViT's qkv unbind (vit_attention.py:205-206) and STanHop's
+ * (B,L,H,E) (hopfield.py:43-49).  The output is normally given (B,S,H,D) strides so the head merge
+ * (bert_attention.py:335-337, opt_attention.py:318-322) costs nothing. */
+typedef struct oeh_attn_desc {
+  int32_t B, H, Sq, Sk, D;
+  int32_t dtype;                 /* OEH_F16 | OEH_BF16 | OEH_F32 : q, k, v and o */
+  int64_t q_stride[3];           /* elements: batch, head, seq */
+  int64_t k_stride[3];
+  int64_t v_stride[3];
+  int64_t o_stride[3];
+
+  /* scores = (q.k) * scale          when scale_div == 0  (OPT: scale = 1, q pre-scaled, opt_attention.py:167;
+   *                                  ViT vit_attention.py:71; Association hopfield.py:48)
+   * scores = (q.k) / scale_div      when scale_div != 0  (BERT: / sqrt(d), bert_attention.py:265) */
+  float scale;
+  float scale_div;
+
+  int32_t softmax_base;          /* OEH_SOFTMAX_VANILLA | OEH_SOFTMAX_ONE (vutils/softmax_1.py:4-28) */
+  int32_t clip;                  /* 1: p = clip(p*(eta-gamma)+gamma, 0, 1) (models/softmax.py:10-19) */
+  float gamma, eta;
+
+  /* additive masks, applied in this order after the scores fake-quant:
+   *   key_pad_mask (B,Sk): BERT's (B,1,1,S) extended mask (bert_attention.py:270-272)
+   *   full_mask (B,1,Sq,Sk): OPT's causal+padding mask (opt_attention.py:215-220)
+   *   causal: analytic causal mask, adds mask_min where k > q + (Sk - Sq)
+   *   clamp_min: then max(x, mask_min) (opt_attention.py:221-223) */
+  const void* key_pad_mask;
+  int32_t key_pad_dtype;         /* OEH_F16 | OEH_F32 */
+  int64_t key_pad_stride;        /* elements between batches */
+  const void* full_mask;
+  int32_t full_mask_dtype;       /* OEH_F16 | OEH_F32 */
+  int64_t full_mask_stride[2];   /* elements: batch, query row; keys contiguous */
+  int32_t causal;
+  int32_t clamp_min;
+  float mask_min;                /* finfo.min of the dtype the reference would hold the scores in */
+
+  /* gate: fp32 values already multiplied by gate_scaling_factor, broadcast by zero strides
+   * (context *= gate * scaling, bert_attention.py:327; opt_attention.py:309).  NULL = no gate. */
+  const float* gate;
+  int64_t gate_stride[3];        /* elements: batch, head, query row */
+} oeh_attn_desc;
+
+/* QK^T -> scale -> [fq] -> mask -> softmax / softmax_1 -> [clip] -> [fq] -> PV -> [fq] -> gate -> [fq]
+ * in ONE kernel.  Replaces bert_attention.py:222-337, opt_attention.py:204-322,
+ * vit_attention.py:54-75/215-266, hopfield.py:47-49 and, with `fq`, quantized_bert.py:317-434 /
+ * quantized_opt.py:151-270.  `fq` may be NULL.  Dropout and head_mask are inference no-ops in the
+ * reference and are not part of this path (callers must not be training with p_drop > 0). */
+int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const void* v, void* o,
+                 const oeh_fq_desc* fq, void* stream);
+
+/* Row-wise softmax family on a dense (rows, cols) array: the SOFTMAX_MAPPING callables
+ * (models/softmax.py:22-64; vutils/softmax_1.py:24-28).  x and y may alias.  dtype of x and y. */
+int oeh_softmax_rows(const void* x, void* y, int64_t rows, int32_t cols, int32_t dtype, int32_t softmax_base,
+                     int32_t clip, float gamma, float eta, void* stream);
+
+/* Stand-alone per-tensor asymmetric fake-quant (QuantizedActivation in fixed-range mode,
+ * base_quantized_classes.py:182-199).  y (same dtype as x) and/or idx (uint8) may be NULL. */
+int oeh_fake_quant(const void* x, void* y, uint8_t* idx, int64_t n, int32_t dtype, float scale, float zero_point,
+                   float qmax, void* stream);
+
+/* Gate probabilities for the conditional gates (bert_attention.py:301-327):
+ *   hidden (B,T,E) [dtype], E = H*d; per-head predictor fc_h on hidden[:, :, h*d:(h+1)*d]:
+ *     hidden_units == 0 : Linear(d,1)            w1 (H,d)        b1 (H)          (w2,b2 NULL)
+ *     hidden_units  > 0 : Linear(d,m),ReLU,Linear(m,1)  w1 (H,m,d) b1 (H,m) w2 (H,m) b2 (H)
+ *   per_head_pool: average the logits over T before the sigmoid (conditional_per_head, :321-322)
+ *   gate_out (B,H,T) fp32 (or (B,H,1) when pooling) = sigmoid(logit) * scaling.
+ * Weights are fp32 device arrays. */
+int oeh_gate_fwd(const void* hidden, int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t d,
+                 int64_t hidden_stride_b, int64_t hidden_stride_t, const float* w1, const float* b1, const float* w2,
+                 const float* b2, int32_t hidden_units, int32_t per_head_pool, float scaling, float* gate_out,
+                 void* stream);
+
+/* min and max of a dense array -> out[0], out[1] (fp32 device scalars): the CurrentMinMax / RunningMinMax
+ * (no percentile) range statistics (range_estimators.py:71-72,96-97) without a device->host copy. */
+int oeh_minmax(const void* x, int64_t n, int32_t dtype, float* out2, void* stream);
+
+/* library information (host side, no device work) */
+int oeh_abi_version(void);
+const char* oeh_build_info(void);       /* "gfx950 hipcc <version> ..." */
+const char* oeh_strerror(int code);
+/* name of the kernel variant oeh_attn_fwd would launch for `desc` ("mfma16/NT32/D64/f16", "generic", ...)
+ * or NULL if unsupported; host only. */
+const char* oeh_attn_variant(const oeh_attn_desc* desc, const oeh_fq_desc* fq);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OEH_H_ */

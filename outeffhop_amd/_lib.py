@@ -1,0 +1,100 @@
+"""ctypes binding of liboeh_hip.so (C ABI: include/oeh.h).
+
+The HIP library IS the product path: if it cannot be loaded this module raises - there is no CPU or
+PyTorch fallback behind any op in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liboeh_hip.so")
+
+OEH_F16, OEH_BF16, OEH_F32 = 0, 1, 2
+OEH_SOFTMAX_VANILLA, OEH_SOFTMAX_ONE = 0, 1
+
+
+class OehError(RuntimeError):
+    pass
+
+
+class oeh_fq(C.Structure):
+    _fields_ = [
+        ("enable", C.c_int32),
+        ("scale", C.c_float),
+        ("zero_point", C.c_float),
+        ("qmax", C.c_float),
+        ("dump_idx", C.c_void_p),
+    ]
+
+
+class oeh_fq_desc(C.Structure):
+    _fields_ = [("scores", oeh_fq), ("probs", oeh_fq), ("ctx", oeh_fq), ("ctx_quant_before_gate", C.c_int32)]
+
+
+class oeh_attn_desc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("H", C.c_int32), ("Sq", C.c_int32), ("Sk", C.c_int32), ("D", C.c_int32),
+        ("dtype", C.c_int32),
+        ("q_stride", C.c_int64 * 3), ("k_stride", C.c_int64 * 3), ("v_stride", C.c_int64 * 3), ("o_stride", C.c_int64 * 3),
+        ("scale", C.c_float), ("scale_div", C.c_float),
+        ("softmax_base", C.c_int32), ("clip", C.c_int32), ("gamma", C.c_float), ("eta", C.c_float),
+        ("key_pad_mask", C.c_void_p), ("key_pad_dtype", C.c_int32), ("key_pad_stride", C.c_int64),
+        ("full_mask", C.c_void_p), ("full_mask_dtype", C.c_int32), ("full_mask_stride", C.c_int64 * 2),
+        ("causal", C.c_int32), ("clamp_min", C.c_int32), ("mask_min", C.c_float),
+        ("gate", C.c_void_p), ("gate_stride", C.c_int64 * 3),
+    ]
+
+
+# every symbol include/oeh.h declares (tests/test_abi.py checks the .so exports exactly these)
+EXPORTS = (
+    "oeh_attn_fwd", "oeh_softmax_rows", "oeh_fake_quant", "oeh_gate_fwd", "oeh_minmax",
+    "oeh_abi_version", "oeh_build_info", "oeh_strerror", "oeh_attn_variant",
+)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load liboeh_hip.so once.  torch (if it is going to be used) must be imported first so that both
+    share ONE HIP runtime: the library's DT_NEEDED libamdhip64.so.7 then resolves to the copy torch loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OehError(
+            f"{LIB_PATH} is missing: build it with `make -C outeffhop_amd/csrc -j8` (or `python -c 'import "
+            "__graft_entry__ as g; g.build()'`).  outeffhop_amd has no CPU/PyTorch fallback."
+        )
+    try:
+        import torch  # noqa: F401  (brings in torch's libamdhip64 first)
+    except Exception:  # pragma: no cover - library is usable from plain C hosts too
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.oeh_attn_fwd.argtypes = [C.POINTER(oeh_attn_desc), vp, vp, vp, vp, C.POINTER(oeh_fq_desc), vp]
+    lib.oeh_attn_fwd.restype = C.c_int
+    lib.oeh_softmax_rows.argtypes = [vp, vp, i64, i32, i32, i32, i32, f32, f32, vp]
+    lib.oeh_softmax_rows.restype = C.c_int
+    lib.oeh_fake_quant.argtypes = [vp, vp, vp, i64, i32, f32, f32, f32, vp]
+    lib.oeh_fake_quant.restype = C.c_int
+    lib.oeh_gate_fwd.argtypes = [vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp, i32, i32, f32, vp, vp]
+    lib.oeh_gate_fwd.restype = C.c_int
+    lib.oeh_minmax.argtypes = [vp, i64, i32, vp, vp]
+    lib.oeh_minmax.restype = C.c_int
+    lib.oeh_abi_version.restype = C.c_int
+    lib.oeh_build_info.restype = C.c_char_p
+    lib.oeh_strerror.argtypes = [C.c_int]
+    lib.oeh_strerror.restype = C.c_char_p
+    lib.oeh_attn_variant.argtypes = [C.POINTER(oeh_attn_desc), C.POINTER(oeh_fq_desc)]
+    lib.oeh_attn_variant.restype = C.c_char_p
+    if lib.oeh_abi_version() != 1:
+        raise OehError(f"liboeh_hip.so ABI {lib.oeh_abi_version()} != 1 (stale build?)")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise OehError(f"{what} failed: {load().oeh_strerror(rc).decode()} ({rc})")

@@ -1,0 +1,216 @@
+// extern "C" entry points of liboeh_hip.so (declared in include/oeh.h): argument validation, kernel
+// variant selection and launch.  No allocation, no synchronisation: safe under hipGraph capture.
+#include "../../include/oeh.h"
+#include "oeh_attn_params.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace oeh {
+int launch_attn_mfma_d32(const AttnParams& P, int in, bool fq, hipStream_t st);
+int launch_attn_mfma_d64(const AttnParams& P, int in, bool fq, hipStream_t st);
+int launch_attn_mfma_d128(const AttnParams& P, int in, bool fq, hipStream_t st);
+int launch_attn_generic(const AttnParams& P, int in, hipStream_t st);
+int launch_softmax_rows(const void* x, void* y, long rows, int cols, int in, int base, int clip, float w, float g, hipStream_t st);
+int launch_fake_quant(const void* x, void* y, unsigned char* idx, long n, int in, FqP f, hipStream_t st);
+int launch_gate(const void* hidden, int in, int B, int T, int H, int d, long hs_b, long hs_t, const float* w1, const float* b1,
+                const float* w2, const float* b2, int m_units, int pool, float scaling, float* out, hipStream_t st);
+int launch_minmax(const void* x, long n, int in, float* out2, hipStream_t st);
+}  // namespace oeh
+
+using oeh::AttnParams;
+using oeh::FqP;
+
+namespace {
+
+bool dtype_ok(int d) { return d == OEH_F16 || d == OEH_BF16 || d == OEH_F32; }
+int elem_bytes(int d) { return d == OEH_F32 ? 4 : 2; }
+
+FqP make_fq(const oeh_fq* f) {
+  FqP r;
+  std::memset(&r, 0, sizeof(r));
+  if (f != nullptr && f->enable) {
+    r.en = 1;
+    r.scale = f->scale;
+    r.rscale = 1.0f / f->scale;
+    r.zp = f->zero_point;
+    r.qmax = f->qmax;
+    r.dump = f->dump_idx;
+  }
+  return r;
+}
+
+enum Variant { V_NONE = 0, V_MFMA, V_GENERIC };
+
+// rows must be 16-byte aligned for the MFMA path's 16-B loads / 8..16-B stores
+bool aligned16(const void* p, const int64_t* st, int eb) {
+  if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) return false;
+  for (int i = 0; i < 3; ++i)
+    if (((st[i] * eb) & 15) != 0) return false;
+  return true;
+}
+
+int validate(const oeh_attn_desc* d, const void* q, const void* k, const void* v, void* o, const oeh_fq_desc* fq) {
+  if (d == nullptr || q == nullptr || k == nullptr || v == nullptr || o == nullptr) return OEH_EINVAL;
+  if (d->B <= 0 || d->H <= 0 || d->Sq <= 0 || d->Sk <= 0 || d->D <= 0) return OEH_EINVAL;
+  if (!dtype_ok(d->dtype)) return OEH_EINVAL;
+  if (d->softmax_base != OEH_SOFTMAX_VANILLA && d->softmax_base != OEH_SOFTMAX_ONE) return OEH_EINVAL;
+  if (d->key_pad_mask != nullptr && d->key_pad_dtype != OEH_F16 && d->key_pad_dtype != OEH_F32) return OEH_EINVAL;
+  if (d->full_mask != nullptr && d->full_mask_dtype != OEH_F16 && d->full_mask_dtype != OEH_F32) return OEH_EINVAL;
+  if (fq != nullptr) {
+    const oeh_fq* fs[3] = {&fq->scores, &fq->probs, &fq->ctx};
+    for (const oeh_fq* f : fs) {
+      if (!f->enable) continue;
+      if (!(f->scale > 0.0f) || !(f->qmax >= 1.0f) || f->zero_point < 0.0f || f->zero_point > f->qmax) return OEH_EINVAL;
+      if (f->dump_idx != nullptr && f->qmax > 255.0f) return OEH_ENOTSUP;
+    }
+  }
+  return OEH_OK;
+}
+
+bool any_fq(const oeh_fq_desc* fq) { return fq != nullptr && (fq->scores.enable || fq->probs.enable || fq->ctx.enable); }
+
+Variant pick_variant(const oeh_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const oeh_fq_desc* fq) {
+  const int eb = elem_bytes(d->dtype);
+  const bool shape_ok = (d->D == 32 || d->D == 64 || d->D == 128) && d->Sk <= 512;
+  // integer-valued (idx - zp) must be exact in the 16-bit P operand: |.| <= 2048 (f16) / 256 (bf16)
+  bool p_exact = true;
+  if (fq != nullptr && fq->probs.enable) p_exact = fq->probs.qmax <= (d->dtype == OEH_BF16 ? 255.0f : 2047.0f);
+  const bool al = (q == nullptr) || (aligned16(q, d->q_stride, eb) && aligned16(k, d->k_stride, eb) &&
+                                     aligned16(v, d->v_stride, eb) && aligned16(o, d->o_stride, eb));
+  if (shape_ok && p_exact && al) return V_MFMA;
+  if ((size_t)(d->D + d->Sk) * 4 <= 64 * 1024) return V_GENERIC;
+  return V_NONE;
+}
+
+void fill_params(AttnParams& P, const oeh_attn_desc* d, const void* q, const void* k, const void* v, void* o, const oeh_fq_desc* fq) {
+  std::memset(&P, 0, sizeof(P));
+  P.q = q; P.k = k; P.v = v; P.o = o;
+  P.B = d->B; P.H = d->H; P.Sq = d->Sq; P.Sk = d->Sk; P.D = d->D;
+  P.qs_b = d->q_stride[0]; P.qs_h = d->q_stride[1]; P.qs_s = d->q_stride[2];
+  P.ks_b = d->k_stride[0]; P.ks_h = d->k_stride[1]; P.ks_s = d->k_stride[2];
+  P.vs_b = d->v_stride[0]; P.vs_h = d->v_stride[1]; P.vs_s = d->v_stride[2];
+  P.os_b = d->o_stride[0]; P.os_h = d->o_stride[1]; P.os_s = d->o_stride[2];
+  P.scale = d->scale; P.scale_div = d->scale_div;
+  P.base = d->softmax_base;
+  P.clip = d->clip ? 1 : 0;
+  // (eta - gamma) is formed in double and rounded to fp32 once, as Python does before the tensor multiply
+  P.clip_w = (float)((double)d->eta - (double)d->gamma);
+  P.clip_g = d->gamma;
+  P.pad = d->key_pad_mask; P.pad_f16 = d->key_pad_dtype == OEH_F16; P.pad_sb = d->key_pad_stride;
+  P.full = d->full_mask; P.full_f16 = d->full_mask_dtype == OEH_F16;
+  P.full_sb = d->full_mask_stride[0]; P.full_sq = d->full_mask_stride[1];
+  P.causal = d->causal ? 1 : 0; P.clamp_min = d->clamp_min ? 1 : 0; P.mask_min = d->mask_min;
+  P.gate = d->gate; P.gs_b = d->gate_stride[0]; P.gs_h = d->gate_stride[1]; P.gs_s = d->gate_stride[2];
+  if (fq != nullptr) {
+    P.fq_s = make_fq(&fq->scores); P.fq_p = make_fq(&fq->probs); P.fq_c = make_fq(&fq->ctx);
+    P.ctx_before_gate = fq->ctx_quant_before_gate ? 1 : 0;
+  }
+  P.nQT = (d->Sq + 63) / 64;
+  P.nBH = d->B * d->H;
+  P.nBHpad = (P.nBH + 7) & ~7;
+  // Causal tiles strictly above the diagonal contribute exactly 0 to P@V (and nothing to the row statistics)
+  // and may be skipped when: masked probabilities are exactly 0 before the clip and the clip maps 0 to 0
+  // (gamma <= 0); the row can never be fully masked under vanilla softmax (which would make it uniform over
+  // ALL keys) - guaranteed by the diagonal unless another mask is present; and no index dump wants every element.
+  const bool dump = (P.fq_s.dump != nullptr) || (P.fq_p.dump != nullptr);
+  const bool other_mask = (P.pad != nullptr) || (P.full != nullptr);
+  P.skip_ok = (P.causal && d->Sq <= d->Sk && (!P.clip || d->gamma <= 0.0f) && !dump && (P.base == 1 || !other_mask) &&
+               std::isfinite(d->mask_min) && d->mask_min < -1e4f) ? 1 : 0;
+}
+
+const char* variant_name(Variant v, const oeh_attn_desc* d, bool fq) {
+  static thread_local char buf[64];
+  if (v == V_GENERIC) return "generic";
+  if (v == V_NONE) return nullptr;
+  const int nt = d->Sk <= 128 ? 8 : (d->Sk <= 256 ? 16 : 32);
+  const char* dt = d->dtype == OEH_F16 ? "f16" : (d->dtype == OEH_BF16 ? "bf16" : "f32");
+  std::snprintf(buf, sizeof(buf), "mfma16/NT%d/D%d/%s%s", nt, d->D, dt, fq ? "/fq" : "");
+  return buf;
+}
+
+}  // namespace
+
+extern "C" {
+
+int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const void* v, void* o, const oeh_fq_desc* fq,
+                 void* stream) {
+  int rc = validate(desc, q, k, v, o, fq);
+  if (rc != OEH_OK) return rc;
+  const Variant var = pick_variant(desc, q, k, v, o, fq);
+  if (var == V_NONE) return OEH_ENOTSUP;
+  AttnParams P;
+  fill_params(P, desc, q, k, v, o, fq);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (var == V_MFMA) {
+    switch (desc->D) {
+      case 32: return oeh::launch_attn_mfma_d32(P, desc->dtype, any_fq(fq), st);
+      case 64: return oeh::launch_attn_mfma_d64(P, desc->dtype, any_fq(fq), st);
+      default: return oeh::launch_attn_mfma_d128(P, desc->dtype, any_fq(fq), st);
+    }
+  }
+  return oeh::launch_attn_generic(P, desc->dtype, st);
+}
+
+const char* oeh_attn_variant(const oeh_attn_desc* desc, const oeh_fq_desc* fq) {
+  if (desc == nullptr || desc->B <= 0 || desc->H <= 0 || desc->Sq <= 0 || desc->Sk <= 0 || desc->D <= 0 || !dtype_ok(desc->dtype))
+    return nullptr;
+  return variant_name(pick_variant(desc, nullptr, nullptr, nullptr, nullptr, fq), desc, any_fq(fq));
+}
+
+int oeh_softmax_rows(const void* x, void* y, int64_t rows, int32_t cols, int32_t dtype, int32_t softmax_base, int32_t clip,
+                     float gamma, float eta, void* stream) {
+  if (x == nullptr || y == nullptr || rows < 0 || cols <= 0 || !dtype_ok(dtype)) return OEH_EINVAL;
+  if (softmax_base != OEH_SOFTMAX_VANILLA && softmax_base != OEH_SOFTMAX_ONE) return OEH_EINVAL;
+  if (rows == 0) return OEH_OK;
+  const float w = (float)((double)eta - (double)gamma);
+  return oeh::launch_softmax_rows(x, y, rows, cols, dtype, softmax_base, clip ? 1 : 0, w, gamma, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oeh_fake_quant(const void* x, void* y, uint8_t* idx, int64_t n, int32_t dtype, float scale, float zero_point, float qmax,
+                   void* stream) {
+  if (x == nullptr || n < 0 || !dtype_ok(dtype)) return OEH_EINVAL;
+  if (!(scale > 0.0f) || !(qmax >= 1.0f) || zero_point < 0.0f || zero_point > qmax) return OEH_EINVAL;
+  if (idx != nullptr && qmax > 255.0f) return OEH_ENOTSUP;
+  if (n == 0 || (y == nullptr && idx == nullptr)) return OEH_OK;
+  FqP f;
+  std::memset(&f, 0, sizeof(f));
+  f.en = 1; f.scale = scale; f.rscale = 1.0f / scale; f.zp = zero_point; f.qmax = qmax;
+  return oeh::launch_fake_quant(x, y, idx, n, dtype, f, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oeh_gate_fwd(const void* hidden, int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t d, int64_t hidden_stride_b,
+                 int64_t hidden_stride_t, const float* w1, const float* b1, const float* w2, const float* b2, int32_t hidden_units,
+                 int32_t per_head_pool, float scaling, float* gate_out, void* stream) {
+  if (hidden == nullptr || w1 == nullptr || b1 == nullptr || gate_out == nullptr || !dtype_ok(dtype)) return OEH_EINVAL;
+  if (B <= 0 || T <= 0 || H <= 0 || d <= 0 || hidden_units < 0) return OEH_EINVAL;
+  if (hidden_units > 0 && (w2 == nullptr || b2 == nullptr)) return OEH_EINVAL;
+  return oeh::launch_gate(hidden, dtype, B, T, H, d, hidden_stride_b, hidden_stride_t, w1, b1, w2, b2, hidden_units,
+                          per_head_pool ? 1 : 0, scaling, gate_out, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oeh_minmax(const void* x, int64_t n, int32_t dtype, float* out2, void* stream) {
+  if (x == nullptr || out2 == nullptr || n <= 0 || !dtype_ok(dtype)) return OEH_EINVAL;
+  return oeh::launch_minmax(x, n, dtype, out2, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oeh_abi_version(void) { return OEH_ABI_VERSION; }
+
+const char* oeh_build_info(void) {
+  return "liboeh_hip gfx950 (MI355X, CDNA4) v_mfma_f32_16x16x32_{f16,bf16}; built " __DATE__ " " __TIME__ " hipcc " __VERSION__;
+}
+
+const char* oeh_strerror(int code) {
+  switch (code) {
+    case OEH_OK: return "ok";
+    case OEH_EINVAL: return "invalid argument";
+    case OEH_ENOTSUP: return "shape/dtype/option combination not supported";
+    case OEH_EALIGN: return "pointer or stride not 16-byte aligned";
+    case OEH_ELAUNCH: return "HIP kernel launch failed";
+    case OEH_ENODEV: return "no gfx950 device";
+    default: return "unknown error";
+  }
+}
+
+}  // extern "C"

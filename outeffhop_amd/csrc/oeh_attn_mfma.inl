@@ -1,0 +1,391 @@
+// Fused modified-softmax attention for gfx950 (MI355X): QK^T -> scale -> [fq] -> mask -> softmax_n ->
+// [clip] -> [fq] -> PV -> [fq] -> gate -> [fq] -> (B,S,H,D) store, one kernel, nothing S x S in HBM.
+//
+// Replaces the eager chains bert_attention.py:222-337, opt_attention.py:204-322,
+// vit_attention.py:54-75, hopfield.py:47-49 and (FQ=true) quantized_bert.py:317-434 /
+// quantized_opt.py:151-270 of the reference.
+//
+// Design (DESIGN.md "attention kernel"):
+//  * The clip and the probability fake-quant are non-linear in the FINAL normalised probability, so the
+//    online-softmax rescaling trick is unusable.  Instead one wave keeps the complete score rows of its
+//    16 queries in registers (Sk <= 16*NT keys -> NT accumulator tiles of 4 VGPRs; NT=32 for S=512), which
+//    gives the reference's exact two-pass order (max, exp, sum, divide) with ONE pass over K and ONE over V.
+//  * "Swapped" products: S^T = K Q^T and O^T = V^T P^T with v_mfma_f32_16x16x32_{f16,bf16}.  In the C/D
+//    layout the query is then on the lane (col = lane&15) and the keys run over registers, so the row
+//    max / sum are in-lane reductions plus two cross-lane steps, every per-row scalar (max, 1/den, gate)
+//    is one VGPR, and the P^T operand of the second product is the lane's own registers (no LDS, no
+//    shuffles): element j of k-slot group g is key 16*t0+4g+j (j<4) or 16*t1+4g+j-4 (j>=4); the V^T operand
+//    is fetched in the same permuted key order with ds_read_b64_tr_b16.
+//  * K and V stream through a 2-deep LDS ring in 64-key tiles (register-staged, 16-B loads, XOR-swizzled so
+//    ds_read_b128 / ds_read_b64_tr_b16 / ds_write_b128 are conflict-free - tools/lds_bank_sim.py).
+//  * One workgroup = 4 waves = 64 query rows of one (batch, head); q tiles of a head sit on one XCD
+//    (block ids a multiple of 8 apart) so K/V re-reads hit that XCD's L2; heaviest causal tiles first.
+#pragma once
+#include "oeh_attn_params.h"
+
+namespace oeh {
+
+template <int D>
+__device__ __forceinline__ int swz_k(int row) {
+  if constexpr (D == 64) return row & 7;
+  if constexpr (D == 128) return row & 15;
+  if constexpr (D == 32) return (0x6C >> (((row >> 2) & 3) * 2)) & 3;  // {0,3,2,1}
+  return 0;
+}
+template <int D>
+__device__ __forceinline__ int swz_v(int row) {
+  if constexpr (D == 64) return (row >> 1) & 3;
+  if constexpr (D == 128) return row & 7;
+  if constexpr (D == 32) return (row >> 2) & 1;
+  return 0;
+}
+
+template <int IN>
+__device__ __forceinline__ f4 mfma16(u4 a, u4 b, f4 c) {
+  if constexpr (IN == IN_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+
+// test-only index dump: up to 4 consecutive uint8 (byte stores: rows need not be 4-byte aligned)
+__device__ __forceinline__ void dump4(unsigned char* p, unsigned int word, int nvalid) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (r < nvalid) p[r] = (unsigned char)(word >> (8 * r));
+}
+
+template <int NT>
+constexpr int occupancy_hint() { return NT >= 32 ? 2 : (NT >= 16 ? 3 : 4); }
+
+template <int NT, int D, int IN, bool FQ>
+__global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kernel(const AttnParams P) {
+  constexpr int KT = NT / 4;            // 64-key LDS tiles
+  constexpr int ROWB = 2 * D;           // bytes per LDS row (16-bit elements)
+  constexpr int TILEB = 64 * ROWB;
+  constexpr int CPR = D / 8;            // 16-B chunks per row
+  constexpr int CPT = (64 * CPR) / 256; // chunks per thread per tile
+  constexpr int KS = D / 32;            // k-steps of the first product
+  constexpr int DT = D / 16;            // 16-wide d tiles of the second product
+  static_assert(CPT >= 1, "D >= 32");
+  constexpr bool OUT16 = (IN != IN_F32);
+
+  __shared__ __attribute__((aligned(16))) unsigned char lds_tile[2 * TILEB];
+  __shared__ __attribute__((aligned(16))) float lds_pad[NT * 16];
+
+  const int bid = blockIdx.x;
+  const int qt_rev = bid / P.nBHpad;
+  const int bh = bid - qt_rev * P.nBHpad;
+  if (bh >= P.nBH) return;
+  const int qt = P.nQT - 1 - qt_rev;
+  const int b = bh / P.H, h = bh - b * P.H;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int q0 = qt * 64 + wave * 16;
+  const int qrow = q0 + c;
+  const bool qvalid = qrow < P.Sq;
+  const int off = P.Sk - P.Sq;
+
+  int kend_wg = P.Sk, kend_wave = P.Sk;
+  if (P.skip_ok) {
+    kend_wg = min(P.Sk, max(0, qt * 64 + 64 + off));
+    kend_wave = min(P.Sk, max(0, q0 + 16 + off));
+  }
+  const int n_kt = (kend_wg + 63) >> 6;    // workgroup-uniform
+  const int nt_wave = (kend_wave + 15) >> 4;  // wave-uniform
+
+  // ---- Q^T operand: this lane's query row, 8 consecutive d per k-step
+  u4 qf[KS];
+  {
+    const long qoff = (long)b * P.qs_b + (long)h * P.qs_h + (long)qrow * P.qs_s;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = u4{0, 0, 0, 0};
+      if (qvalid) qf[ks] = load8_as16<IN>(P.q, qoff + ks * 32 + 8 * g);
+    }
+  }
+  // ---- key-padding mask row -> LDS (zeros when absent)
+  for (int i = tid; i < NT * 16; i += 256) {
+    float pv = 0.0f;
+    if (P.pad != nullptr && i < P.Sk) pv = load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + i);
+    lds_pad[i] = pv;
+  }
+
+  const long kbase = (long)b * P.ks_b + (long)h * P.ks_h;
+  const long vbase = (long)b * P.vs_b + (long)h * P.vs_h;
+  u4 stage[CPT];
+  auto issue_load = [&](const void* base, long boff, long srow, int tile) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int cid = tid + 256 * i;
+      const int row = cid / CPR, ch = cid % CPR;
+      const int key = tile * 64 + row;
+      stage[i] = u4{0, 0, 0, 0};
+      if (key < P.Sk) stage[i] = load8_as16<IN>(base, boff + (long)key * srow + ch * 8);
+    }
+  };
+  auto commit_k = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int cid = tid + 256 * i;
+      const int row = cid / CPR, ch = cid % CPR;
+      *reinterpret_cast<u4*>(lds_tile + buf * TILEB + row * ROWB + ((ch ^ swz_k<D>(row)) << 4)) = stage[i];
+    }
+  };
+  auto commit_v = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int cid = tid + 256 * i;
+      const int row = cid / CPR, ch = cid % CPR;
+      *reinterpret_cast<u4*>(lds_tile + buf * TILEB + row * ROWB + (((ch >> 1) ^ swz_v<D>(row)) << 5) + ((ch & 1) << 4)) = stage[i];
+    }
+  };
+
+  // =========================== phase 1: S^T = K Q^T, all keys, into registers ===========================
+  f4 s[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) s[t] = f4{0.f, 0.f, 0.f, 0.f};
+
+  if (n_kt > 0) issue_load(P.k, kbase, P.ks_s, 0);
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt < n_kt) {
+      commit_k(kt & 1);
+      __syncthreads();
+      if (kt + 1 < n_kt) issue_load(P.k, kbase, P.ks_s, kt + 1);
+      else issue_load(P.v, vbase, P.vs_s, 0);
+      const unsigned char* tb = lds_tile + (kt & 1) * TILEB;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        const int t = kt * 4 + sub;
+        if (t < nt_wave) {
+          const int row = sub * 16 + c;
+          f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const u4 kf = *reinterpret_cast<const u4*>(tb + row * ROWB + (((ks * 4 + g) ^ swz_k<D>(row)) << 4));
+            acc = mfma16<IN>(kf, qf[ks], acc);
+          }
+          s[t] = acc;
+        }
+      }
+    }
+  }
+
+  // =========================== phase 2: elementwise chain + row statistics ===========================
+  // lane (c,g) owns query row `qrow`, keys 16t+4g+r
+  const float mask_min = P.mask_min;
+  const int klim = qrow + off;  // last key a causal row may see
+  float m = -__builtin_inff();
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t < nt_wave) {
+      const f4 padv = *reinterpret_cast<const f4*>(&lds_pad[16 * t + 4 * g]);
+      unsigned int dump_word = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * t + 4 * g + r;
+        float x = s[t][r];
+        x = (P.scale_div != 0.0f) ? x / P.scale_div : x * P.scale;
+        if constexpr (FQ) {
+          if (P.fq_s.en) {
+            const float idx = fq_index(x, P.fq_s);
+            dump_word |= ((unsigned int)idx) << (8 * r);
+            x = fq_dequant(idx, P.fq_s);
+          }
+        }
+        if (P.pad != nullptr) x = x + padv[r];
+        if (P.full != nullptr && qvalid && key < P.Sk)
+          x = x + load_mask(P.full, P.full_f16, (long)b * P.full_sb + (long)qrow * P.full_sq + key);
+        if (P.causal && key > klim) x = x + mask_min;
+        if (P.clamp_min) x = __builtin_fmaxf(x, mask_min);
+        if (key >= P.Sk) x = -__builtin_inff();
+        s[t][r] = x;
+        m = __builtin_fmaxf(m, x);
+      }
+      if constexpr (FQ) {
+        if (P.fq_s.en && P.fq_s.dump != nullptr && qvalid)
+          dump4(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + 16 * t + 4 * g, dump_word, P.Sk - (16 * t + 4 * g));
+      }
+    }
+  }
+  m = __builtin_fmaxf(m, __shfl_xor(m, 16));
+  m = __builtin_fmaxf(m, __shfl_xor(m, 32));
+
+  float sum = 0.0f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t < nt_wave) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float y = s[t][r] - m;
+        const float e = FQ ? exp_acc(y) : exp_fast(y);
+        s[t][r] = e;
+        sum += e;
+      }
+    }
+  }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  float den = sum;
+  if (P.base != 0) den = sum + exp_acc(m * -1.0f);  // softmax_1: + 1*exp(-max)  (softmax_1.py:18-20)
+  const float inv = 1.0f / den;
+
+  // probabilities -> [clip] -> [fq] -> 16-bit P^T operand, two 16-key tiles per 32-key k-step
+  u2 ph[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    ph[t] = u2{0u, 0u};
+    if (t < nt_wave) {
+      float pv[4];
+      unsigned int dump_word = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = s[t][r] * inv;
+        if (P.clip) {
+          p = p * P.clip_w;
+          p = p + P.clip_g;
+          p = __builtin_fminf(__builtin_fmaxf(p, 0.0f), 1.0f);
+        }
+        if constexpr (FQ) {
+          if (P.fq_p.en) {
+            const float idx = fq_index(p, P.fq_p);
+            dump_word |= ((unsigned int)idx) << (8 * r);
+            p = idx - P.fq_p.zp;  // integer valued: exact in f16/bf16; scale applied after the product
+          }
+        }
+        if (16 * t + 4 * g + r >= P.Sk) p = 0.0f;
+        pv[r] = p;
+      }
+      if constexpr (IN == IN_BF16) {
+        ph[t].x = pack2_bf16(pv[0], pv[1]);
+        ph[t].y = pack2_bf16(pv[2], pv[3]);
+      } else {
+        ph[t].x = pack2_f16(pv[0], pv[1]);
+        ph[t].y = pack2_f16(pv[2], pv[3]);
+      }
+      if constexpr (FQ) {
+        if (P.fq_p.en && P.fq_p.dump != nullptr && qvalid)
+          dump4(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + 16 * t + 4 * g, dump_word, P.Sk - (16 * t + 4 * g));
+      }
+    }
+  }
+
+  // =========================== phase 3: O^T = V^T P^T ===========================
+  f4 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) o[dt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt < n_kt) {
+      const int buf = (n_kt + kt) & 1;
+      commit_v(buf);
+      __syncthreads();
+      if (kt + 1 < n_kt) issue_load(P.v, vbase, P.vs_s, kt + 1);
+      const unsigned char* tb = lds_tile + buf * TILEB;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t0 = kt * 4 + 2 * u;
+        if (t0 < nt_wave) {
+          const u4 pb = u4{ph[t0].x, ph[t0].y, ph[t0 + 1].x, ph[t0 + 1].y};
+          const int row = 32 * u + 4 * g + (c >> 2);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const unsigned char* a0 = tb + row * ROWB + ((dt ^ swz_v<D>(row)) << 5) + ((c & 3) << 3);
+            const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0));
+            const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + 16 * ROWB));
+            const u2 l2 = __builtin_bit_cast(u2, lo), h2 = __builtin_bit_cast(u2, hi);
+            const u4 va = u4{l2.x, l2.y, h2.x, h2.y};
+            o[dt] = mfma16<IN>(va, pb, o[dt]);
+          }
+        }
+      }
+    }
+  }
+
+  // =========================== epilogue: [scale_p] [fq] gate [fq] store ===========================
+  // lane (c,g) holds O[qrow][16dt + 4g + r]
+  if (!qvalid) return;
+  float gatev = 1.0f;
+  if (P.gate != nullptr) gatev = P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
+  const long ooff = (long)b * P.os_b + (long)h * P.os_h + (long)qrow * P.os_s;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    float ov[4];
+    unsigned int dump_word = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x = o[dt][r];
+      if constexpr (FQ) {
+        if (P.fq_p.en) x = P.fq_p.scale * x;
+        if (P.fq_c.en && P.ctx_before_gate) {
+          const float idx = fq_index(x, P.fq_c);
+          dump_word |= ((unsigned int)idx) << (8 * r);
+          x = fq_dequant(idx, P.fq_c);
+        }
+      }
+      if (P.gate != nullptr) x = x * gatev;
+      if constexpr (FQ) {
+        if (P.fq_c.en && !P.ctx_before_gate) {
+          const float idx = fq_index(x, P.fq_c);
+          dump_word |= ((unsigned int)idx) << (8 * r);
+          x = fq_dequant(idx, P.fq_c);
+        }
+      }
+      ov[r] = x;
+    }
+    const int d0 = 16 * dt + 4 * g;
+    if constexpr (OUT16) {
+      u2 w;
+      if constexpr (IN == IN_BF16) {
+        w.x = pack2_bf16(ov[0], ov[1]);
+        w.y = pack2_bf16(ov[2], ov[3]);
+      } else {
+        w.x = pack2_f16(ov[0], ov[1]);
+        w.y = pack2_f16(ov[2], ov[3]);
+      }
+      *reinterpret_cast<u2*>(reinterpret_cast<unsigned short*>(P.o) + ooff + d0) = w;
+    } else {
+      *reinterpret_cast<f4*>(reinterpret_cast<float*>(P.o) + ooff + d0) = f4{ov[0], ov[1], ov[2], ov[3]};
+    }
+    if constexpr (FQ) {
+      if (P.fq_c.en && P.fq_c.dump != nullptr) dump4(P.fq_c.dump + (((long)b * P.H + h) * P.Sq + qrow) * D + d0, dump_word, 4);
+    }
+  }
+}
+
+// ---- explicit instantiations + launcher table ---------------------------------------------------------------
+template <int NT, int D, int IN, bool FQ>
+static int launch_one(const AttnParams& P, hipStream_t st) {
+  const unsigned grid = (unsigned)(P.nQT * P.nBHpad);
+  hipLaunchKernelGGL((oeh_attn_mfma_kernel<NT, D, IN, FQ>), dim3(grid), dim3(256), 0, st, P);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+template <int NT, int D>
+static int launch_nt_d(const AttnParams& P, int in, bool fq, hipStream_t st) {
+  if (fq) {
+    switch (in) {
+      case IN_F16: return launch_one<NT, D, IN_F16, true>(P, st);
+      case IN_BF16: return launch_one<NT, D, IN_BF16, true>(P, st);
+      default: return launch_one<NT, D, IN_F32, true>(P, st);
+    }
+  }
+  switch (in) {
+    case IN_F16: return launch_one<NT, D, IN_F16, false>(P, st);
+    case IN_BF16: return launch_one<NT, D, IN_BF16, false>(P, st);
+    default: return launch_one<NT, D, IN_F32, false>(P, st);
+  }
+}
+
+template <int D>
+static int launch_d(const AttnParams& P, int in, bool fq, hipStream_t st) {
+  if (P.Sk <= 128) return launch_nt_d<8, D>(P, in, fq, st);
+  if (P.Sk <= 256) return launch_nt_d<16, D>(P, in, fq, st);
+  return launch_nt_d<32, D>(P, in, fq, st);
+}
+
+}  // namespace oeh

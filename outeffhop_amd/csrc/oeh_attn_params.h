@@ -1,0 +1,39 @@
+// Kernel-argument block shared by the fused attention kernels (host fills it in oeh_api.hip).
+#pragma once
+#include "oeh_common.h"
+
+namespace oeh {
+
+struct AttnParams {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  int B, H, Sq, Sk, D;
+  long qs_b, qs_h, qs_s;
+  long ks_b, ks_h, ks_s;
+  long vs_b, vs_h, vs_s;
+  long os_b, os_h, os_s;
+  float scale, scale_div;     // scale_div != 0: divide (BERT), else multiply
+  int base;                   // 0 vanilla, 1 softmax_1
+  int clip;
+  float clip_w, clip_g;       // fl32(eta - gamma), fl32(gamma)
+  const void* pad;            // (B,Sk) additive or null
+  int pad_f16;
+  long pad_sb;
+  const void* full;           // (B,1,Sq,Sk) additive or null
+  int full_f16;
+  long full_sb, full_sq;
+  int causal, clamp_min;
+  float mask_min;
+  const float* gate;          // null = none
+  long gs_b, gs_h, gs_s;
+  FqP fq_s, fq_p, fq_c;
+  int ctx_before_gate;
+  // launch geometry
+  int nQT;                    // q tiles (64 rows) per (b,h)
+  int nBH, nBHpad;            // B*H and B*H rounded up to a multiple of 8 (XCD affinity of a head's q tiles)
+  int skip_ok;                // causal tiles above the diagonal may be skipped (see oeh_api.hip)
+};
+
+}  // namespace oeh

@@ -1,0 +1,114 @@
+// Shared device helpers for liboeh_hip.so (gfx950 only).  Built with -ffp-contract=off: every
+// fp32 multiply/add below is a separately rounded IEEE op exactly as in the reference's eager
+// torch chain; fused multiply-adds appear only where written explicitly (__builtin_fmaf).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace oeh {
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+
+enum { IN_F16 = 0, IN_BF16 = 1, IN_F32 = 2 };
+
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kLog2eHi = 0x1.715476p+0f;   // fl32(log2 e)
+constexpr float kLog2eLo = 0x1.4ae0bep-26f;  // log2 e - kLog2eHi
+
+// One fixed-range asymmetric fake-quantiser (uniform_quantizers.py:72-82,114-115,146).
+struct FqP {
+  int en;
+  float scale, rscale, zp, qmax;
+  unsigned char* dump;
+};
+
+// rint(x / scale) with the result of a TRUE IEEE division, at the cost of one multiply in the common
+// case: x*rscale is within 2^-23 relative of x/scale, so the two can only round differently when the
+// quotient sits within that distance of a half-integer; only then is the division carried out.
+__device__ __forceinline__ float fq_rint_div(float x, float scale, float rscale) {
+  float q = x * rscale;
+  float r = __builtin_rintf(q);
+  if (__builtin_expect(0.5f - __builtin_fabsf(q - r) <= __builtin_fabsf(q) * 6e-7f, 0)) r = __builtin_rintf(x / scale);
+  return r;
+}
+__device__ __forceinline__ float fq_index(float x, const FqP& f) {
+  float r = fq_rint_div(x, f.scale, f.rscale) + f.zp;
+  return __builtin_fminf(__builtin_fmaxf(r, 0.0f), f.qmax);
+}
+__device__ __forceinline__ float fq_dequant(float idx, const FqP& f) { return f.scale * (idx - f.zp); }
+
+// exp(y) to ~1 ulp: n = rint(y*log2e), f = y*log2e - n in two fma steps, 2^f by v_exp_f32, ldexp.
+// Used wherever a value feeds a quantiser (index parity with an IEEE-accurate expf).
+__device__ __forceinline__ float exp_acc(float y) {
+  y = __builtin_fminf(__builtin_fmaxf(y, -110.0f), 90.0f);
+  float t = y * kLog2eHi;
+  float n = __builtin_rintf(t);
+  float f = __builtin_fmaf(y, kLog2eHi, -n);
+  f = __builtin_fmaf(y, kLog2eLo, f);
+  return __builtin_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+// exp(y) by one multiply + v_exp_f32 (relative error ~|y| * 1e-7): the fp16/bf16 path.
+__device__ __forceinline__ float exp_fast(float y) { return __builtin_amdgcn_exp2f(y * kLog2e); }
+
+template <int IN>
+struct In;  // storage element helpers
+template <>
+struct In<IN_F16> {
+  typedef unsigned short elem;
+  static constexpr int bytes = 2;
+  static __device__ __forceinline__ float to_f32(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }
+  static __device__ __forceinline__ unsigned short from_f32(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+};
+template <>
+struct In<IN_BF16> {
+  typedef unsigned short elem;
+  static constexpr int bytes = 2;
+  static __device__ __forceinline__ float to_f32(unsigned short v) { return __builtin_bit_cast(float, (unsigned int)v << 16); }
+  static __device__ __forceinline__ unsigned short from_f32(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+};
+template <>
+struct In<IN_F32> {
+  typedef float elem;
+  static constexpr int bytes = 4;
+  static __device__ __forceinline__ float to_f32(float v) { return v; }
+  static __device__ __forceinline__ float from_f32(float f) { return f; }
+};
+
+__device__ __forceinline__ unsigned int pack2_f16(float a, float b) {
+  return (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)a) |
+         ((unsigned int)__builtin_bit_cast(unsigned short, (_Float16)b) << 16);
+}
+__device__ __forceinline__ unsigned int pack2_bf16(float a, float b) {
+  return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)a) |
+         ((unsigned int)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
+}
+
+// 8 consecutive storage elements -> 8 x 16-bit MFMA operand elements (f32 storage is rounded to f16).
+template <int IN>
+__device__ __forceinline__ u4 load8_as16(const void* base, long elem_off) {
+  if constexpr (IN == IN_F32) {
+    const f4* p = reinterpret_cast<const f4*>(reinterpret_cast<const float*>(base) + elem_off);
+    f4 a = p[0], b = p[1];
+    u4 r;
+    r.x = pack2_f16(a.x, a.y);
+    r.y = pack2_f16(a.z, a.w);
+    r.z = pack2_f16(b.x, b.y);
+    r.w = pack2_f16(b.z, b.w);
+    return r;
+  } else {
+    return *reinterpret_cast<const u4*>(reinterpret_cast<const unsigned short*>(base) + elem_off);
+  }
+}
+
+__device__ __forceinline__ float load_mask(const void* base, int is_f16, long off) {
+  return is_f16 ? (float)reinterpret_cast<const _Float16*>(base)[off] : reinterpret_cast<const float*>(base)[off];
+}
+
+}  // namespace oeh

@@ -1,0 +1,214 @@
+// Stand-alone row / elementwise kernels behind the C ABI: the SOFTMAX_MAPPING callables
+// (models/softmax.py:22-64), QuantizedActivation in fixed-range mode (base_quantized_classes.py:182-199),
+// the per-head gate predictors (bert_attention.py:301-327) and min/max range statistics
+// (range_estimators.py:71-72,96-97).  All HBM-bound: 16-B accesses, one pass where the row fits LDS.
+#include "oeh_common.h"
+
+namespace oeh {
+
+// ---------------------------------------------------------------------------------------------------------
+// softmax rows: one 256-thread workgroup per row; the row is staged once into LDS as fp32 (cols <= 15872),
+// otherwise re-read from HBM in the three passes.
+template <int IN, bool STAGED>
+__global__ __launch_bounds__(256) void oeh_softmax_rows_kernel(const void* __restrict__ xin, void* yout, long rows, int cols,
+                                                              int base, int clip, float clip_w, float clip_g) {
+  extern __shared__ __attribute__((aligned(16))) float rowbuf[];
+  __shared__ float red[4];
+  typedef typename In<IN>::elem E;
+  const int tid = threadIdx.x;
+  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const E* x = reinterpret_cast<const E*>(xin) + row * cols;
+    E* y = reinterpret_cast<E*>(yout) + row * cols;
+    float lmax = -__builtin_inff();
+    for (int j = tid; j < cols; j += 256) {
+      const float v = In<IN>::to_f32(x[j]);
+      if (STAGED) rowbuf[j] = v;
+      lmax = __builtin_fmaxf(lmax, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) lmax = __builtin_fmaxf(lmax, __shfl_xor(lmax, o));
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = lmax;
+    __syncthreads();
+    const float m = __builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3]));
+    float lsum = 0.0f;
+    for (int j = tid; j < cols; j += 256) {
+      const float v = STAGED ? rowbuf[j] : In<IN>::to_f32(x[j]);
+      const float e = exp_acc(v - m);
+      if (STAGED) rowbuf[j] = e;
+      lsum += e;
+    }
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = lsum;
+    __syncthreads();
+    const float sum = ((red[0] + red[1]) + red[2]) + red[3];
+    float den = sum;
+    if (base != 0) den = sum + exp_acc(m * -1.0f);
+    for (int j = tid; j < cols; j += 256) {
+      const float e = STAGED ? rowbuf[j] : exp_acc(In<IN>::to_f32(x[j]) - m);
+      float p = e / den;
+      if (clip) {
+        p = p * clip_w;
+        p = p + clip_g;
+        p = __builtin_fminf(__builtin_fmaxf(p, 0.0f), 1.0f);
+      }
+      y[j] = In<IN>::from_f32(p);
+    }
+    __syncthreads();
+  }
+}
+
+int launch_softmax_rows(const void* x, void* y, long rows, int cols, int in, int base, int clip, float w, float g, hipStream_t st) {
+  const bool staged = cols <= 15872;
+  const size_t shmem = staged ? (size_t)cols * 4 : 0;
+  const unsigned grid = (unsigned)(rows < 65536 ? rows : 65536);
+#define OEH_SMX(INV)                                                                                                   \
+  if (staged) hipLaunchKernelGGL((oeh_softmax_rows_kernel<INV, true>), dim3(grid), dim3(256), shmem, st, x, y, rows, cols, base, clip, w, g); \
+  else hipLaunchKernelGGL((oeh_softmax_rows_kernel<INV, false>), dim3(grid), dim3(256), 0, st, x, y, rows, cols, base, clip, w, g);
+  switch (in) {
+    case IN_F16: OEH_SMX(IN_F16) break;
+    case IN_BF16: OEH_SMX(IN_BF16) break;
+    default: OEH_SMX(IN_F32) break;
+  }
+#undef OEH_SMX
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fake-quant: grid-stride, 4 elements per thread-iteration.
+template <int IN>
+__global__ __launch_bounds__(256) void oeh_fake_quant_kernel(const void* __restrict__ xin, void* yout, unsigned char* idx_out, long n,
+                                                             FqP f) {
+  typedef typename In<IN>::elem E;
+  const E* x = reinterpret_cast<const E*>(xin);
+  E* y = reinterpret_cast<E*>(yout);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = In<IN>::to_f32(x[i]);
+    const float r = __builtin_rintf(v / f.scale) + f.zp;  // true IEEE division (uniform_quantizers.py:114)
+    const float idx = __builtin_fminf(__builtin_fmaxf(r, 0.0f), f.qmax);
+    if (idx_out) idx_out[i] = (unsigned char)idx;
+    if (y) y[i] = In<IN>::from_f32(f.scale * (idx - f.zp));
+  }
+}
+
+int launch_fake_quant(const void* x, void* y, unsigned char* idx, long n, int in, FqP f, hipStream_t st) {
+  long blocks = (n + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  switch (in) {
+    case IN_F16: hipLaunchKernelGGL(oeh_fake_quant_kernel<IN_F16>, dim3((unsigned)blocks), dim3(256), 0, st, x, y, idx, n, f); break;
+    case IN_BF16: hipLaunchKernelGGL(oeh_fake_quant_kernel<IN_BF16>, dim3((unsigned)blocks), dim3(256), 0, st, x, y, idx, n, f); break;
+    default: hipLaunchKernelGGL(oeh_fake_quant_kernel<IN_F32>, dim3((unsigned)blocks), dim3(256), 0, st, x, y, idx, n, f); break;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// gate: thread per (b,t,h); consecutive threads read consecutive 2d-byte slices of one hidden row.
+template <int IN>
+__global__ __launch_bounds__(256) void oeh_gate_logit_kernel(const void* __restrict__ hidden, int B, int T, int H, int d, long hs_b, long hs_t,
+                                                             const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             const float* __restrict__ w2, const float* __restrict__ b2, int m_units,
+                                                             int apply_sigmoid, float scaling, float* out) {
+  typedef typename In<IN>::elem E;
+  const long n = (long)B * T * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int h = (int)(i % H);
+    const int t = (int)((i / H) % T);
+    const int b = (int)(i / ((long)H * T));
+    const E* x = reinterpret_cast<const E*>(hidden) + (long)b * hs_b + (long)t * hs_t + (long)h * d;
+    float a;
+    if (m_units == 0) {
+      a = 0.0f;
+      for (int k = 0; k < d; ++k) a = __builtin_fmaf(In<IN>::to_f32(x[k]), w1[(long)h * d + k], a);
+      a = a + b1[h];
+    } else {
+      a = 0.0f;
+      for (int j = 0; j < m_units; ++j) {
+        const float* wr = w1 + ((long)h * m_units + j) * d;
+        float u = 0.0f;
+        for (int k = 0; k < d; ++k) u = __builtin_fmaf(In<IN>::to_f32(x[k]), wr[k], u);
+        u = __builtin_fmaxf(u + b1[(long)h * m_units + j], 0.0f);
+        a = __builtin_fmaf(u, w2[(long)h * m_units + j], a);
+      }
+      a = a + b2[h];
+    }
+    if (apply_sigmoid) a = (1.0f / (1.0f + exp_acc(-a))) * scaling;
+    out[((long)b * H + h) * T + t] = a;
+  }
+}
+
+// conditional_per_head: gate[b,h,0] = sigmoid(mean_t logit[b,h,t]) * scaling  (bert_attention.py:110,321-325)
+__global__ __launch_bounds__(64) void oeh_gate_pool_kernel(float* io, int T, float scaling) {
+  float* row = io + (long)blockIdx.x * T;
+  float s = 0.0f;
+  for (int t = threadIdx.x; t < T; t += 64) s += row[t];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (threadIdx.x == 0) {
+    const float a = s / (float)T;
+    row[0] = (1.0f / (1.0f + exp_acc(-a))) * scaling;
+  }
+}
+
+int launch_gate(const void* hidden, int in, int B, int T, int H, int d, long hs_b, long hs_t, const float* w1, const float* b1,
+                const float* w2, const float* b2, int m_units, int pool, float scaling, float* out, hipStream_t st) {
+  const long n = (long)B * T * H;
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  switch (in) {
+    case IN_F16: hipLaunchKernelGGL(oeh_gate_logit_kernel<IN_F16>, dim3((unsigned)blocks), dim3(256), 0, st, hidden, B, T, H, d, hs_b, hs_t, w1, b1, w2, b2, m_units, !pool, scaling, out); break;
+    case IN_BF16: hipLaunchKernelGGL(oeh_gate_logit_kernel<IN_BF16>, dim3((unsigned)blocks), dim3(256), 0, st, hidden, B, T, H, d, hs_b, hs_t, w1, b1, w2, b2, m_units, !pool, scaling, out); break;
+    default: hipLaunchKernelGGL(oeh_gate_logit_kernel<IN_F32>, dim3((unsigned)blocks), dim3(256), 0, st, hidden, B, T, H, d, hs_b, hs_t, w1, b1, w2, b2, m_units, !pool, scaling, out); break;
+  }
+  if (pool) hipLaunchKernelGGL(oeh_gate_pool_kernel, dim3((unsigned)(B * H)), dim3(64), 0, st, out, T, scaling);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// min / max: order-preserving int keys + atomics, decoded in place by a 1-thread kernel.
+__device__ __forceinline__ int f2key(float f) { int b = __builtin_bit_cast(int, f); return b >= 0 ? b : b ^ 0x7fffffff; }
+__device__ __forceinline__ float key2f(int k) { return __builtin_bit_cast(float, k >= 0 ? k : k ^ 0x7fffffff); }
+
+__global__ void oeh_minmax_init_kernel(int* keys) { keys[0] = 0x7fffffff; keys[1] = (int)0x80000000; }
+__global__ void oeh_minmax_fin_kernel(int* keys) {
+  const float lo = key2f(keys[0]), hi = key2f(keys[1]);
+  reinterpret_cast<float*>(keys)[0] = lo;
+  reinterpret_cast<float*>(keys)[1] = hi;
+}
+template <int IN>
+__global__ __launch_bounds__(256) void oeh_minmax_kernel(const void* __restrict__ xin, long n, int* keys) {
+  typedef typename In<IN>::elem E;
+  const E* x = reinterpret_cast<const E*>(xin);
+  float lo = __builtin_inff(), hi = -__builtin_inff();
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = In<IN>::to_f32(x[i]);
+    lo = __builtin_fminf(lo, v);
+    hi = __builtin_fmaxf(hi, v);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = __builtin_fminf(lo, __shfl_xor(lo, o));
+    hi = __builtin_fmaxf(hi, __shfl_xor(hi, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&keys[0], f2key(lo));
+    atomicMax(&keys[1], f2key(hi));
+  }
+}
+
+int launch_minmax(const void* x, long n, int in, float* out2, hipStream_t st) {
+  int* keys = reinterpret_cast<int*>(out2);
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(oeh_minmax_init_kernel, dim3(1), dim3(1), 0, st, keys);
+  switch (in) {
+    case IN_F16: hipLaunchKernelGGL(oeh_minmax_kernel<IN_F16>, dim3((unsigned)blocks), dim3(256), 0, st, x, n, keys); break;
+    case IN_BF16: hipLaunchKernelGGL(oeh_minmax_kernel<IN_BF16>, dim3((unsigned)blocks), dim3(256), 0, st, x, n, keys); break;
+    default: hipLaunchKernelGGL(oeh_minmax_kernel<IN_F32>, dim3((unsigned)blocks), dim3(256), 0, st, x, n, keys); break;
+  }
+  hipLaunchKernelGGL(oeh_minmax_fin_kernel, dim3(1), dim3(1), 0, st, keys);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+}  // namespace oeh

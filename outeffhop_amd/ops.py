@@ -1,0 +1,240 @@
+"""Tensor-level entry points over the C ABI (include/oeh.h).  torch is plumbing here: device memory,
+the current HIP stream, dtype/stride bookkeeping.  Every function launches HIP kernels from
+liboeh_hip.so; tensors that are not on a GPU are an error (there is no CPU path in this package).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import OEH_BF16, OEH_F16, OEH_F32, oeh_attn_desc, oeh_fq, oeh_fq_desc
+
+_DT = {torch.float16: OEH_F16, torch.bfloat16: OEH_BF16, torch.float32: OEH_F32}
+
+
+@dataclass(frozen=True)
+class SoftmaxSpec:
+    """One entry of the reference's --attn_softmax registry (models/softmax.py:22-64):
+    base 0 = torch softmax, 1 = softmax_1; clip -> clip(p*(eta-gamma)+gamma, 0, 1)."""
+
+    base: int = 1
+    clip: bool = False
+    gamma: float = 0.0
+    eta: float = 1.0
+
+
+@dataclass
+class FakeQuantSpec:
+    """Fixed-range asymmetric quantiser grid (uniform_quantizers.py:72-82): fp32 scale, integer zero point, qmax."""
+
+    scale: float
+    zero_point: float
+    qmax: float = 255.0
+    dump: Optional[torch.Tensor] = None  # uint8 tensor receiving the indices (tests)
+
+    @staticmethod
+    def from_delta(delta: float, zero_float: float, n_bits: int = 8, eps: float = 1e-8, dump=None) -> "FakeQuantSpec":
+        import numpy as np
+
+        qmax = float(2.0 ** n_bits - 1)
+        scale = float(np.float32(max(float(delta), eps)))
+        zp = float(min(max(float(np.rint(np.float64(zero_float))), 0.0), qmax))
+        return FakeQuantSpec(scale, zp, qmax, dump)
+
+
+@dataclass
+class AttnFakeQuant:
+    scores: Optional[FakeQuantSpec] = None
+    probs: Optional[FakeQuantSpec] = None
+    ctx: Optional[FakeQuantSpec] = None
+    ctx_before_gate: bool = True  # OPT order; False = BERT order (quantise after the gate)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.OehError("outeffhop_amd ops need GPU tensors: the HIP library is the only implementation")
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _fill_fq(dst: oeh_fq, spec: Optional[FakeQuantSpec]):
+    if spec is None:
+        dst.enable = 0
+        return
+    dst.enable = 1
+    dst.scale, dst.zero_point, dst.qmax = spec.scale, spec.zero_point, spec.qmax
+    if spec.dump is not None:
+        assert spec.dump.dtype == torch.uint8 and spec.dump.is_contiguous() and spec.dump.is_cuda
+        dst.dump_idx = spec.dump.data_ptr()
+
+
+def attn_fwd(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    *,
+    softmax: SoftmaxSpec = SoftmaxSpec(),
+    scale: float = 1.0,
+    scale_div: float = 0.0,
+    key_pad_mask: Optional[torch.Tensor] = None,
+    full_mask: Optional[torch.Tensor] = None,
+    causal: bool = False,
+    clamp_min: bool = False,
+    mask_min: Optional[float] = None,
+    gate: Optional[torch.Tensor] = None,
+    fq: Optional[AttnFakeQuant] = None,
+    out: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """Fused attention core.  q,k,v are logical (B,H,S,D) views (any batch/head/seq strides, unit head-dim
+    stride).  Returns the logical (B,H,Sq,D) result, stored (B,Sq,H,D)-contiguous unless `out` is given, so the
+    reference's head merge (bert_attention.py:335-337) is a free `.permute(0,2,1,3).reshape(B,Sq,H*D)`.
+
+    key_pad_mask: additive (B,Sk) [or anything reshapeable to it, e.g. HF's (B,1,1,Sk)];
+    full_mask: additive (B,1,Sq,Sk); gate: fp32, broadcastable to (B,H,Sq,1), already times the scaling factor."""
+    _need_gpu(q, k, v, key_pad_mask, full_mask, gate, out)
+    if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
+        raise ValueError("q, k, v must be 4-D (B,H,S,D) views")
+    B, H, Sq, D = q.shape
+    Sk = k.shape[2]
+    if k.shape != (B, H, Sk, D) or v.shape != (B, H, Sk, D):
+        raise ValueError(f"shape mismatch: q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)}")
+    if not (q.dtype == k.dtype == v.dtype) or q.dtype not in _DT:
+        raise ValueError(f"q/k/v dtypes must match and be fp16/bf16/fp32, got {q.dtype}, {k.dtype}, {v.dtype}")
+    fix = lambda t: t if t.stride(3) == 1 else t.contiguous()  # noqa: E731
+    q, k, v = fix(q), fix(k), fix(v)
+    if out is None:
+        out = torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device).permute(0, 2, 1, 3)
+    elif out.shape != (B, H, Sq, D) or out.dtype != q.dtype or out.stride(3) != 1:
+        raise ValueError("out must be a (B,H,Sq,D) view with unit head-dim stride and the input dtype")
+
+    d = oeh_attn_desc()
+    d.B, d.H, d.Sq, d.Sk, d.D = B, H, Sq, Sk, D
+    d.dtype = _DT[q.dtype]
+    for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", out)):
+        getattr(d, name)[:] = [t.stride(0), t.stride(1), t.stride(2)]
+    d.scale, d.scale_div = float(scale), float(scale_div)
+    d.softmax_base, d.clip, d.gamma, d.eta = int(softmax.base), int(bool(softmax.clip)), float(softmax.gamma), float(softmax.eta)
+    keep = []
+    if key_pad_mask is not None:
+        m = key_pad_mask.reshape(B, Sk)
+        if m.dtype not in (torch.float16, torch.float32):
+            m = m.float()
+        m = m.contiguous()
+        keep.append(m)
+        d.key_pad_mask, d.key_pad_dtype, d.key_pad_stride = m.data_ptr(), _DT[m.dtype], m.stride(0)
+    if full_mask is not None:
+        if full_mask.shape != (B, 1, Sq, Sk):
+            raise ValueError(f"Attention mask should be of size {(B, 1, Sq, Sk)}, but is {tuple(full_mask.shape)}")
+        m = full_mask if full_mask.dtype in (torch.float16, torch.float32) else full_mask.float()
+        m = m if m.stride(3) == 1 else m.contiguous()
+        keep.append(m)
+        d.full_mask, d.full_mask_dtype = m.data_ptr(), _DT[m.dtype]
+        d.full_mask_stride[:] = [m.stride(0), m.stride(2)]
+    d.causal, d.clamp_min = int(bool(causal)), int(bool(clamp_min))
+    d.mask_min = float(torch.finfo(q.dtype).min if mask_min is None else mask_min)
+    if gate is not None:
+        g = gate.to(torch.float32)
+        while g.dim() < 4:
+            g = g.unsqueeze(0)
+        g = g.expand(B, H, Sq, 1)
+        keep.append(g)
+        d.gate = g.data_ptr()
+        d.gate_stride[:] = [g.stride(0), g.stride(1), g.stride(2)]
+    fqd = None
+    if fq is not None and (fq.scores or fq.probs or fq.ctx):
+        fqd = oeh_fq_desc()
+        _fill_fq(fqd.scores, fq.scores)
+        _fill_fq(fqd.probs, fq.probs)
+        _fill_fq(fqd.ctx, fq.ctx)
+        fqd.ctx_quant_before_gate = int(bool(fq.ctx_before_gate))
+    lib = _lib.load()
+    rc = lib.oeh_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), None if fqd is None else C.byref(fqd), _stream())
+    _lib.check(rc, "oeh_attn_fwd")
+    return out
+
+
+def attn_variant(B, H, Sq, Sk, D, dtype=torch.float16, fq: bool = False) -> Optional[str]:
+    """Name of the kernel variant the library would pick (host only; no GPU needed)."""
+    d = oeh_attn_desc()
+    d.B, d.H, d.Sq, d.Sk, d.D, d.dtype = B, H, Sq, Sk, D, _DT[dtype]
+    fqd = None
+    if fq:
+        fqd = oeh_fq_desc()
+        fqd.probs.enable, fqd.probs.scale, fqd.probs.qmax = 1, 1.0, 255.0
+    r = _lib.load().oeh_attn_variant(C.byref(d), None if fqd is None else C.byref(fqd))
+    return None if r is None else r.decode()
+
+
+def softmax_rows(x: torch.Tensor, spec: SoftmaxSpec = SoftmaxSpec(), dim: int = -1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """SOFTMAX_MAPPING callable on the GPU: softmax / softmax_1 / clipped variants along `dim`."""
+    _need_gpu(x, out)
+    if x.dtype not in _DT:
+        raise ValueError(f"unsupported dtype {x.dtype}")
+    nd = x.dim()
+    dim = dim % nd
+    xt = x if dim == nd - 1 else x.transpose(dim, -1)
+    xc = xt.contiguous()
+    y = torch.empty_like(xc) if out is None or dim != nd - 1 else out
+    cols = xc.shape[-1]
+    rows = xc.numel() // max(cols, 1)
+    if xc.numel():
+        rc = _lib.load().oeh_softmax_rows(_ptr(xc), _ptr(y), rows, cols, _DT[x.dtype], int(spec.base), int(bool(spec.clip)),
+                                          float(spec.gamma), float(spec.eta), _stream())
+        _lib.check(rc, "oeh_softmax_rows")
+    return y if dim == nd - 1 else y.transpose(dim, -1)
+
+
+def fake_quant(x: torch.Tensor, spec: FakeQuantSpec, want_idx: bool = False):
+    """Fixed-range per-tensor asymmetric fake-quant; returns x_q (and the uint8 indices if asked)."""
+    _need_gpu(x)
+    if x.dtype not in _DT:
+        raise ValueError(f"unsupported dtype {x.dtype}")
+    xc = x.contiguous()
+    y = torch.empty_like(xc)
+    idx = torch.empty(xc.shape, dtype=torch.uint8, device=x.device) if want_idx else None
+    rc = _lib.load().oeh_fake_quant(_ptr(xc), _ptr(y), _ptr(idx), xc.numel(), _DT[x.dtype], spec.scale, spec.zero_point, spec.qmax, _stream())
+    _lib.check(rc, "oeh_fake_quant")
+    return (y, idx) if want_idx else y
+
+
+def gate_fwd(hidden: torch.Tensor, H: int, w1: torch.Tensor, b1: torch.Tensor, w2: Optional[torch.Tensor] = None,
+             b2: Optional[torch.Tensor] = None, per_head_pool: bool = False, scaling: float = 1.0) -> torch.Tensor:
+    """Per-head gate predictors on the module input (bert_attention.py:301-327).  hidden (B,T,H*d);
+    w1 (H,d)|(H,m,d), b1 (H)|(H,m), w2 (H,m), b2 (H).  Returns sigmoid(logit)*scaling as (B,H,T,1) or (B,H,1,1) fp32."""
+    _need_gpu(hidden, w1, b1, w2, b2)
+    B, T, E = hidden.shape
+    d = E // H
+    hc = hidden if hidden.stride(2) == 1 else hidden.contiguous()
+    m_units = 0 if w1.dim() == 2 else w1.shape[1]
+    f = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()  # noqa: E731
+    w1, b1, w2, b2 = f(w1), f(b1), f(w2), f(b2)
+    out = torch.empty((B, H, T), dtype=torch.float32, device=hidden.device)
+    rc = _lib.load().oeh_gate_fwd(_ptr(hc), _DT[hidden.dtype], B, T, H, d, hc.stride(0), hc.stride(1), _ptr(w1), _ptr(b1), _ptr(w2),
+                                  _ptr(b2), m_units, int(per_head_pool), float(scaling), _ptr(out), _stream())
+    _lib.check(rc, "oeh_gate_fwd")
+    return out[:, :, :1, None] if per_head_pool else out[..., None]
+
+
+def minmax(x: torch.Tensor) -> torch.Tensor:
+    """(min, max) of a tensor as a 2-element fp32 GPU tensor, no host round trip (range_estimators.py:96-97)."""
+    _need_gpu(x)
+    xc = x.contiguous()
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().oeh_minmax(_ptr(xc), xc.numel(), _DT[x.dtype], _ptr(out), _stream()), "oeh_minmax")
+    return out
+
+
+def sdpa_scale(d: int) -> float:
+    return 1.0 / math.sqrt(d)

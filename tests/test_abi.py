@@ -1,0 +1,81 @@
+"""CPU-side checks of the C-ABI library: it loads, exports exactly the symbols include/oeh.h declares, validates
+arguments without touching a GPU, and the product package refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, "include", "oeh.h")
+
+
+def _declared():
+    txt = open(HDR).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(oeh_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree():
+    from outeffhop_amd import _lib
+
+    assert _declared() == sorted(_lib.EXPORTS)
+
+
+def test_library_loads_and_exports_every_symbol():
+    from outeffhop_amd import _lib
+
+    lib = _lib.load()
+    for name in _declared():
+        assert hasattr(lib, name), name
+    import shutil
+
+    nm = shutil.which("nm")
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True) if nm else None
+    if out is not None and out.returncode == 0:
+        exported = {ln.split()[-1] for ln in out.stdout.splitlines() if " T " in ln}
+        assert set(_declared()) <= exported
+    assert lib.oeh_abi_version() == 1
+    assert b"gfx950" in lib.oeh_build_info()
+    assert lib.oeh_strerror(-22) == b"invalid argument"
+
+
+def test_argument_validation_without_gpu():
+    from outeffhop_amd import _lib
+
+    lib = _lib.load()
+    d = _lib.oeh_attn_desc()
+    assert lib.oeh_attn_fwd(None, None, None, None, None, None, None) == -22
+    d.B, d.H, d.Sq, d.Sk, d.D, d.dtype = 1, 1, 4, 4, 64, 7
+    one = C.c_void_p(16)
+    assert lib.oeh_attn_fwd(C.byref(d), one, one, one, one, None, None) == -22  # bad dtype
+    d.dtype = 0
+    d.softmax_base = 3
+    assert lib.oeh_attn_fwd(C.byref(d), one, one, one, one, None, None) == -22  # bad softmax base
+    assert lib.oeh_softmax_rows(one, one, 4, 0, 0, 1, 0, 0.0, 1.0, None) == -22
+    assert lib.oeh_fake_quant(one, one, None, 4, 0, 0.0, 0.0, 255.0, None) == -22  # scale must be > 0
+    assert lib.oeh_fake_quant(one, one, one, 4, 0, 1.0, 0.0, 1023.0, None) == -95  # uint8 dump of a 10-bit grid
+
+
+def test_variant_selection_host_only():
+    import torch
+    from outeffhop_amd import ops
+
+    assert ops.attn_variant(16, 12, 512, 512, 64) == "mfma16/NT32/D64/f16"
+    assert ops.attn_variant(32, 12, 128, 128, 64) == "mfma16/NT8/D64/f16"
+    assert ops.attn_variant(2, 6, 197, 197, 64, torch.bfloat16) == "mfma16/NT16/D64/bf16"
+    assert ops.attn_variant(4, 1, 64, 64, 32, torch.float32, fq=True) == "mfma16/NT8/D32/f32/fq"
+    assert ops.attn_variant(3, 4, 7, 5, 16) == "generic"
+    assert ops.attn_variant(1, 1, 8, 100000, 64) is None
+
+
+def test_no_cpu_fallback():
+    import torch
+    from outeffhop_amd import _lib, ops
+
+    x = torch.zeros(2, 2, 4, 64, dtype=torch.float16)
+    with pytest.raises(_lib.OehError):
+        ops.attn_fwd(x, x, x)
+    with pytest.raises(_lib.OehError):
+        ops.softmax_rows(torch.zeros(2, 3))

@@ -217,3 +217,30 @@ def test_int8_core_from_captured_qkv(fam):
             step = np.float32(fq["ctx"][0])
             bad = np.abs(out - ref) > 1e-5
             assert bad.mean() < 2e-3 and np.abs(out - ref).max() <= 1.01 * step
+
+
+def test_eager_torch_matches_golden():
+    """oracle/eager_torch.py (the CPU-baseline op chain) against the same reference fixtures and the numpy oracle."""
+    import torch
+
+    from oracle import eager_torch as E
+
+    g = load_golden("core_attn.npz")
+    tbl = O.softmax_table()
+    q, k, v = (torch.from_numpy(g[n]) for n in ("q", "k", "v"))
+    for sm in ("softmax1", "vanilla", "clippedsoftmax1(-.025:1)"):
+        b, ga, et = tbl[sm]
+        clip = not (ga == 0.0 and et == 1.0)
+        out = E.attn_core_eager(q, k, v, order="bert", base=b, clip=clip, gamma=ga, eta=et, mask=torch.from_numpy(g["pad_mask"]))
+        np.testing.assert_allclose(out.numpy(), g[f"bert[{sm}].ctx"], **MM)
+        qs = (q * 64 ** -0.5).half().float()
+        out = E.attn_core_eager(qs, k, v, order="opt", base=b, clip=clip, gamma=ga, eta=et, mask=torch.from_numpy(g["opt_mask"]))
+        np.testing.assert_allclose(out.numpy(), g[f"opt[{sm}].ctx"], **MM)
+    # fake-quant chain agrees with the numpy oracle (indices can flip only through matmul order)
+    fq = dict(scores=(0.05, 120.0, 255.0), probs=(1 / 255.0, 0.0, 255.0), ctx=(0.01, 130.0, 255.0))
+    out = E.attn_core_eager(qs, k, v, order="opt", mask=torch.from_numpy(g["opt_mask"]), fq=fq)
+    want = O.attn_core(qs.numpy(), k.numpy(), v.numpy(), full_mask=g["opt_mask"], clamp_min=True, fq_scores=(0.05, 120.0),
+                       fq_probs=(1 / 255.0, 0.0), fq_ctx=(0.01, 130.0))
+    assert (np.abs(out.numpy() - want) > 1e-5).mean() < 2e-3
+    m = E.causal_mask(2, 5)
+    assert m.shape == (2, 1, 5, 5) and m[0, 0, 0, 1] == torch.finfo(torch.float32).min and m[0, 0, 1, 0] == 0

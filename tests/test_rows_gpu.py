@@ -1,0 +1,103 @@
+"""GPU parity of the stand-alone row kernels (softmax family, fake-quant, gate, min/max) against the golden
+fixtures captured from the reference and against the oracle.  `-m gpu`."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import oeh_oracle as O
+from tests.conftest import load_golden
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from outeffhop_amd import ops as _ops
+
+    return _ops
+
+
+def test_softmax_rows_all_registry_keys(ops):
+    g = load_golden("softmax_rows.npz")
+    x = torch.from_numpy(g["x"]).cuda()
+    xm = torch.from_numpy(g["xm"]).cuda()
+    for k, (b, ga, et) in O.softmax_table().items():
+        spec = ops.SoftmaxSpec(base=b, clip=not (ga == 0.0 and et == 1.0), gamma=ga, eta=et)
+        np.testing.assert_allclose(ops.softmax_rows(x, spec).cpu().numpy(), g[f"y[{k}]"], rtol=2e-6, atol=1e-7, err_msg=k)
+        if f"ym[{k}]" in g.files:
+            np.testing.assert_allclose(ops.softmax_rows(xm, spec).cpu().numpy(), g[f"ym[{k}]"], rtol=2e-6, atol=1e-7, err_msg=k)
+            for e in ("known123", "known00", "allmasked", "neg", "big", "below_exp_range", "near_exp_range", "single"):
+                got = ops.softmax_rows(torch.from_numpy(g[f"edge_x[{e}]"]).cuda(), spec).cpu().numpy()
+                np.testing.assert_allclose(got, g[f"edge_y[{e}][{k}]"], rtol=2e-6, atol=1e-7, err_msg=f"{k}/{e}")
+
+
+def test_softmax_rows_dims_dtypes_and_long_rows(ops):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 40, 17, generator=g)
+    want = O.softmax_1(x.numpy(), axis=1)
+    np.testing.assert_allclose(ops.softmax_rows(x.cuda(), dim=1).cpu().numpy(), want, rtol=2e-6, atol=1e-7)
+    x = torch.randn(2, 20000, generator=g) * 3  # longer than the LDS-staged limit
+    np.testing.assert_allclose(ops.softmax_rows(x.cuda()).cpu().numpy(), O.softmax_1(x.numpy()), rtol=3e-6, atol=1e-9)
+    xh = torch.randn(64, 512, generator=g).half()
+    got = ops.softmax_rows(xh.cuda(), ops.SoftmaxSpec(1, True, -0.025, 1.1)).float().cpu().numpy()
+    np.testing.assert_allclose(got, O.apply_softmax(xh.float().numpy(), 1, -0.025, 1.1), atol=1e-3)
+    assert ops.softmax_rows(torch.empty(0, 8).cuda()).shape == (0, 8)
+
+
+def test_fake_quant_bit_exact(ops):
+    g = load_golden("fakequant.npz")
+    x = torch.from_numpy(g["x"]).cuda()
+    for m in json.loads(str(g["meta_json"])):
+        t = m["tag"]
+        spec = ops.FakeQuantSpec.from_delta(float(g[f"{t}_delta"]), float(g[f"{t}_zero_float"]), m["n_bits"])
+        assert np.float32(spec.scale) == g[f"{t}_scale"] and spec.zero_point == float(g[f"{t}_zero_point"])
+        xq, idx = ops.fake_quant(x, spec, want_idx=True)
+        assert np.array_equal(idx.cpu().numpy().astype(np.float32), g[f"{t}_idx"]), t
+        assert np.array_equal(xq.cpu().numpy(), g[f"{t}_xq"]), t
+    spec = ops.FakeQuantSpec.from_delta(float(g["pct_delta"]), float(g["pct_zero_float"]))
+    xq, idx = ops.fake_quant(torch.from_numpy(g["pct_x"]).cuda(), spec, want_idx=True)
+    assert np.array_equal(idx.cpu().numpy().astype(np.float32), g["pct_idx"]) and np.array_equal(xq.cpu().numpy(), g["pct_xq"])
+    # a large tensor of softmax1 probabilities against the oracle's true-division quantiser
+    p = torch.from_numpy(O.softmax_1(np.random.default_rng(0).standard_normal((4096, 512)).astype(np.float32)))
+    d, z = O.quant_range_to_params(*np.percentile(p.numpy(), (0.001, 99.999)))
+    want_q, want_i = O.fake_quant(p.numpy(), d, z)
+    xq, idx = ops.fake_quant(p.cuda(), ops.FakeQuantSpec.from_delta(d, z), want_idx=True)
+    assert np.array_equal(idx.cpu().numpy(), want_i.astype(np.uint8)) and np.array_equal(xq.cpu().numpy(), want_q)
+
+
+def test_gate_kernels(ops):
+    g = load_golden("bert_attn_fp.npz")
+    hidden = torch.from_numpy(g["hidden"]).cuda()
+    H = 2
+    n = 0
+    for cj in g["cases_json"]:
+        c = json.loads(str(cj))
+        sd = {k[len(c["name"]) + 3:]: g[k] for k in g.files if k.startswith(c["name"] + ".w.")}
+        kind, gp = O.gate_params_from_state(sd, H)
+        if kind not in ("linear", "mlp"):
+            continue
+        pool = c["gate"].startswith("head_")
+        scaling = float(g[f"{c['name']}.gate_scaling_factor"])
+        want = O.gate_values(g["hidden"], H, kind, gp, pool) * np.float32(scaling)
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+        if kind == "linear":
+            got = ops.gate_fwd(hidden, H, T(gp["w"]), T(gp["b"]), per_head_pool=pool, scaling=scaling)
+        else:
+            got = ops.gate_fwd(hidden, H, T(gp["w1"]), T(gp["b1"]), T(gp["w2"]), T(gp["b2"]), per_head_pool=pool, scaling=scaling)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-6, err_msg=c["name"])
+        n += 1
+    assert n >= 5
+
+
+def test_minmax(ops):
+    x = torch.randn(3, 1000, 77, generator=torch.Generator().manual_seed(9))
+    x[1, 5, 5] = -123.5
+    x[2, 999, 76] = 77.25
+    got = ops.minmax(x.cuda()).cpu().numpy()
+    assert got[0] == -123.5 and got[1] == 77.25
+    got = ops.minmax(x.half().cuda()).cpu().numpy()
+    assert got[0] == -123.5 and got[1] == 77.25
