@@ -1,0 +1,224 @@
+"""Shared host-side pieces of the drop-in attention modules: the gate-type enum, gate construction /
+evaluation, and the dispatch between the fused HIP kernel and the unfused (observable) path.
+
+Reference anchors: AttentionGateType / logit  OutEffHop/transformers_language/models/bert_attention.py:16-25
+                   gate definitions            bert_attention.py:119-162 (= opt_attention.py:105-144, vit_attention.py:152-195)
+                   gate evaluation             bert_attention.py:294-331
+"""
+from __future__ import annotations
+
+import math
+from enum import Flag
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .ops import AttnFakeQuant, SoftmaxSpec
+from .softmax import spec_of
+
+
+class BaseEnumOptions(Flag):
+    """Enum whose str() is the member name and that can list its names (quantization/utils.py:35-41)."""
+
+    def __str__(self):
+        return self.name
+
+    @classmethod
+    def list_names(cls):
+        return [m.name for m in cls]
+
+
+class AttentionGateType(BaseEnumOptions):
+    none = 0
+    unconditional_per_head = 1
+    conditional_per_head = 2
+    conditional_per_token = 3
+
+
+def logit(p, eps=1e-16):
+    p = np.clip(p, eps, 1 - eps)
+    return -np.log(1 / p - 1)
+
+
+_CONDITIONAL = (AttentionGateType.conditional_per_head, AttentionGateType.conditional_per_token)
+
+
+def build_gate(num_heads: int, head_dim: int, model_dim: int, gate_type, gate_init, use_mlp: bool, use_mlp2: bool,
+               all_features: bool, fine_tuning: bool, ft_std: float):
+    """Create the `alpha` member exactly as the reference names/initialises it:
+    Parameter[H] | Linear(E,H) | ModuleList of per-head Linear(d,1) / Sequential(Linear,ReLU,Linear) | None."""
+    if gate_type == AttentionGateType.unconditional_per_head:
+        return nn.Parameter(torch.zeros(num_heads), requires_grad=True)
+    if gate_type not in _CONDITIONAL:
+        return None
+    if all_features:
+        return nn.Linear(model_dim, num_heads, bias=True)
+    heads = []
+    for _ in range(num_heads):
+        if use_mlp or use_mlp2:
+            width = head_dim // 4 if use_mlp else head_dim
+            heads.append(nn.Sequential(nn.Linear(head_dim, width, bias=True), nn.ReLU(), nn.Linear(width, 1, bias=True)))
+            continue
+        fc = nn.Linear(head_dim, 1, bias=True)
+        if gate_init is not None:
+            nn.init.constant_(fc.bias, float(logit(gate_init)))
+        if fine_tuning:
+            nn.init.normal_(fc.weight, mean=0.0, std=ft_std)
+        heads.append(fc)
+    return nn.ModuleList(heads)
+
+
+class GateState:
+    """Evaluates the gate with HIP kernels and keeps the reference's bookkeeping attributes."""
+
+    @staticmethod
+    def packed_weights(mod: nn.Module):
+        """Per-head predictor weights stacked as (H,d)/(H) or (H,m,d)/(H,m)/(H,m)/(H); cached until a parameter changes."""
+        heads = mod.alpha
+        sig = tuple((p.data_ptr(), p._version) for p in heads.parameters())
+        cache = getattr(mod, "_oeh_gate_cache", None)
+        if cache is not None and cache[0] == sig:
+            return cache[1]
+        with torch.no_grad():
+            if isinstance(heads[0], nn.Linear):
+                packed = (torch.stack([h.weight[0] for h in heads]).float().contiguous(),
+                          torch.stack([h.bias[0] for h in heads]).float().contiguous(), None, None)
+            else:
+                packed = (torch.stack([h[0].weight for h in heads]).float().contiguous(),
+                          torch.stack([h[0].bias for h in heads]).float().contiguous(),
+                          torch.stack([h[2].weight[0] for h in heads]).float().contiguous(),
+                          torch.stack([h[2].bias[0] for h in heads]).float().contiguous())
+        mod._oeh_gate_cache = (sig, packed)
+        return packed
+
+    @staticmethod
+    def evaluate(mod: nn.Module, hidden_states: torch.Tensor, num_heads: int) -> Optional[torch.Tensor]:
+        """Gate probabilities, broadcastable to (B,H,T,1), fp32, WITHOUT the scaling factor; sets
+        last_gate_avg_prob / last_gate_all_probs like bert_attention.py:299,329-331."""
+        gt = mod.attn_gate_type
+        if gt == AttentionGateType.unconditional_per_head:
+            gate = torch.sigmoid(mod.alpha.float())
+            mod.last_gate_avg_prob = gate.view(-1)
+            return gate.view(1, -1, 1, 1)
+        if gt not in _CONDITIONAL:
+            return None
+        if mod.attn_gate_linear_all_features:
+            gate = torch.sigmoid(mod.alpha(hidden_states).float()).permute(0, 2, 1).contiguous().unsqueeze(3)
+        else:
+            w1, b1, w2, b2 = GateState.packed_weights(mod)
+            gate = ops.gate_fwd(hidden_states, num_heads, w1, b1, w2, b2,
+                                per_head_pool=(gt == AttentionGateType.conditional_per_head), scaling=1.0)
+        mod.last_gate_all_probs = gate
+        mod.last_gate_avg_prob = gate.mean(dim=0).view(num_heads, -1).mean(dim=1)
+        return gate
+
+
+def has_hooks(*mods: nn.Module) -> bool:
+    return any(len(m._forward_hooks) or len(m._forward_pre_hooks) for m in mods)
+
+
+def split_mask(mask: Optional[torch.Tensor], B: int, Sq: int, Sk: int):
+    """Classify an additive HF mask: (B,1,1,Sk) -> key padding vector; (B,1,Sq,Sk) -> full mask."""
+    if mask is None:
+        return None, None
+    if mask.dim() == 4 and mask.shape[1] == 1 and mask.shape[2] == 1 and mask.shape[0] in (1, B) and mask.shape[3] == Sk:
+        return mask.expand(B, 1, 1, Sk).reshape(B, Sk), None
+    if mask.dim() == 4 and tuple(mask.shape) == (B, 1, Sq, Sk):
+        return None, mask
+    return None, mask.expand(B, 1, Sq, Sk)
+
+
+_causal_cache = {}
+
+
+def classify_causal(mask: torch.Tensor):
+    """Recognise HF's decoder mask: a (B,1,T,S) additive tensor that equals causal(finfo.min above the shifted
+    diagonal) + key-padding(finfo.min columns), up to the clamp at finfo.min the attention applies anyway
+    (opt_attention.py:220-223).  Returns (True, pad_vector_or_None) or (False, None).  One pass over the mask per
+    distinct tensor - HF hands the same tensor to every layer - cached on identity."""
+    key = (mask.data_ptr(), tuple(mask.shape), mask._version, mask.dtype)
+    hit = _causal_cache.get(key)
+    if hit is not None:
+        return hit
+    B, _, T, S = mask.shape
+    fmin = torch.finfo(mask.dtype).min
+    causal = torch.full((T, S), fmin, dtype=mask.dtype, device=mask.device).triu(1 + S - T)
+    pad = mask[:, 0, -1, :].clamp(min=fmin)  # the last query row sees every key: what is left is padding
+    recon = (causal[None, None] + pad[:, None, None, :]).clamp(min=fmin)
+    ok = bool(torch.equal(mask.clamp(min=fmin), recon)) and bool(((pad == 0) | (pad == fmin)).all())
+    res = (True, (pad.contiguous() if bool((pad != 0).any()) else None)) if ok else (False, None)
+    if len(_causal_cache) > 64:
+        _causal_cache.clear()
+    _causal_cache[key] = res
+    return res
+
+
+def attention_core(
+    q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, softmax_fn, scale: float = 1.0, scale_div: float = 0.0,
+    attention_mask: Optional[torch.Tensor] = None, clamp_min: bool = False, detect_causal: bool = False,
+    gate: Optional[torch.Tensor] = None, fq: Optional[AttnFakeQuant] = None, mask_min: Optional[float] = None,
+) -> torch.Tensor:
+    """Fused path: logical (B,H,S,d) views in, (B,Sq,H*d) context out (head merge is free)."""
+    B, H, Sq, D = q.shape
+    Sk = k.shape[2]
+    spec = spec_of(softmax_fn)
+    pad, full = split_mask(attention_mask, B, Sq, Sk)
+    causal = False
+    if full is not None and detect_causal and Sq <= Sk:
+        causal, padvec = classify_causal(full)
+        if causal:
+            full, pad = None, padvec
+    if mask_min is None:
+        mdt = attention_mask.dtype if attention_mask is not None and attention_mask.is_floating_point() else q.dtype
+        mask_min = float(torch.finfo(mdt).min)
+    out = ops.attn_fwd(q, k, v, softmax=spec, scale=scale, scale_div=scale_div, key_pad_mask=pad, full_mask=full, causal=causal,
+                       clamp_min=clamp_min, mask_min=mask_min, gate=gate, fq=fq)
+    return out.permute(0, 2, 1, 3).reshape(B, Sq, H * D)
+
+
+def unfused_core(
+    q, k, v, *, softmax_fn, scale: float = 1.0, scale_div: float = 0.0, attention_mask=None, clamp_min: bool = False,
+    scores_tap=None, probs_tap=None, dropout=None, probs_after_tap=None, head_mask=None, extra_scores=None,
+    fq_scores=None, fq_probs=None,
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Observable path (output_attentions, forward hooks on the Identity taps, head_mask, training dropout,
+    relative position scores, user-supplied softmax callables): the (B,H,Sq,Sk) tensors exist, the two
+    contractions are rocBLAS batched GEMMs and the softmax is the HIP row kernel behind SOFTMAX_MAPPING.
+    Op order of bert_attention.py:222-292 / opt_attention.py:204-263.
+    Returns (context (B,H,Sq,d), probs before dropout/head-mask, probs actually multiplied with V)."""
+    ops._need_gpu(q, k, v)  # GPU only, like the fused path: this package has no CPU implementation
+    scores = torch.matmul(q, k.transpose(-1, -2))
+    if extra_scores is not None:
+        scores = scores + extra_scores
+    if scale_div:
+        scores = scores / scale_div
+    elif scale != 1.0:
+        scores = scores * scale
+    if fq_scores is not None:
+        scores = fq_scores(scores)
+    if scores_tap is not None:
+        scores = scores_tap(scores)
+    if attention_mask is not None:
+        scores = scores + attention_mask
+        if clamp_min:
+            scores = torch.max(scores, torch.tensor(torch.finfo(scores.dtype).min, device=scores.device))
+    probs = softmax_fn(scores, dim=-1)
+    if fq_probs is not None:
+        probs = fq_probs(probs)
+    if probs_tap is not None:
+        probs = probs_tap(probs)
+    used = probs
+    if dropout is not None:
+        used = dropout(used)
+    if probs_after_tap is not None:
+        used = probs_after_tap(used)
+    if head_mask is not None:
+        used = used * head_mask
+    return torch.matmul(used, v), probs, used
+
+
+def default_scale(d: int) -> float:
+    return 1.0 / math.sqrt(d)

@@ -11,6 +11,9 @@ namespace oeh {
 int launch_attn_mfma_d32(const AttnParams& P, int in, bool fq, hipStream_t st);
 int launch_attn_mfma_d64(const AttnParams& P, int in, bool fq, hipStream_t st);
 int launch_attn_mfma_d128(const AttnParams& P, int in, bool fq, hipStream_t st);
+int launch_attn_fast_d32(const AttnParams& P, int in, hipStream_t st);
+int launch_attn_fast_d64(const AttnParams& P, int in, hipStream_t st);
+int launch_attn_fast_d128(const AttnParams& P, int in, hipStream_t st);
 int launch_attn_generic(const AttnParams& P, int in, hipStream_t st);
 int launch_softmax_rows(const void* x, void* y, long rows, int cols, int in, int base, int clip, float w, float g, hipStream_t st);
 int launch_fake_quant(const void* x, void* y, unsigned char* idx, long n, int in, FqP f, hipStream_t st);
@@ -41,7 +44,7 @@ FqP make_fq(const oeh_fq* f) {
   return r;
 }
 
-enum Variant { V_NONE = 0, V_MFMA, V_GENERIC };
+enum Variant { V_NONE = 0, V_FAST, V_MFMA, V_GENERIC };
 
 // rows must be 16-byte aligned for the MFMA path's 16-B loads / 8..16-B stores
 bool aligned16(const void* p, const int64_t* st, int eb) {
@@ -71,6 +74,22 @@ int validate(const oeh_attn_desc* d, const void* q, const void* k, const void* v
 
 bool any_fq(const oeh_fq_desc* fq) { return fq != nullptr && (fq->scores.enable || fq->probs.enable || fq->ctx.enable); }
 
+bool is_pow2(float x) {
+  int e = 0;
+  return x > 0.0f && std::isfinite(x) && std::frexp(x, &e) == 0.5f;
+}
+
+// The fast kernel (oeh_attn_fast.inl) covers 16-bit storage, masks in {none, key padding, causal}, a positive
+// multiplicative scale (a power-of-two divisor is the same multiply, exactly) and no fake-quant.
+bool fast_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
+  if (d->dtype == OEH_F32 || any_fq(fq) || d->full_mask != nullptr) return false;
+  if (d->scale_div != 0.0f ? !is_pow2(d->scale_div) : !(d->scale > 0.0f && std::isfinite(d->scale))) return false;
+  if (d->clip && d->gamma > 0.0f) return false;
+  if (d->causal && d->Sq > d->Sk) return false;
+  if ((d->causal || d->key_pad_mask != nullptr) && !(d->mask_min < -1.0e4f)) return false;
+  return true;
+}
+
 Variant pick_variant(const oeh_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const oeh_fq_desc* fq) {
   const int eb = elem_bytes(d->dtype);
   const bool shape_ok = (d->D == 32 || d->D == 64 || d->D == 128) && d->Sk <= 512;
@@ -79,6 +98,7 @@ Variant pick_variant(const oeh_attn_desc* d, const void* q, const void* k, const
   if (fq != nullptr && fq->probs.enable) p_exact = fq->probs.qmax <= (d->dtype == OEH_BF16 ? 255.0f : 2047.0f);
   const bool al = (q == nullptr) || (aligned16(q, d->q_stride, eb) && aligned16(k, d->k_stride, eb) &&
                                      aligned16(v, d->v_stride, eb) && aligned16(o, d->o_stride, eb));
+  if (shape_ok && al && fast_eligible(d, fq)) return V_FAST;
   if (shape_ok && p_exact && al) return V_MFMA;
   if ((size_t)(d->D + d->Sk) * 4 <= 64 * 1024) return V_GENERIC;
   return V_NONE;
@@ -126,7 +146,8 @@ const char* variant_name(Variant v, const oeh_attn_desc* d, bool fq) {
   if (v == V_NONE) return nullptr;
   const int nt = d->Sk <= 128 ? 8 : (d->Sk <= 256 ? 16 : 32);
   const char* dt = d->dtype == OEH_F16 ? "f16" : (d->dtype == OEH_BF16 ? "bf16" : "f32");
-  std::snprintf(buf, sizeof(buf), "mfma16/NT%d/D%d/%s%s", nt, d->D, dt, fq ? "/fq" : "");
+  if (v == V_FAST) std::snprintf(buf, sizeof(buf), "fast16/NT%d/D%d/%s%s", nt, d->D, dt, d->clip ? "/clip" : "");
+  else std::snprintf(buf, sizeof(buf), "mfma16/NT%d/D%d/%s%s", nt, d->D, dt, fq ? "/fq" : "");
   return buf;
 }
 
@@ -143,6 +164,14 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
   AttnParams P;
   fill_params(P, desc, q, k, v, o, fq);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (var == V_FAST) {
+    if (desc->scale_div != 0.0f) { P.scale = 1.0f / desc->scale_div; P.scale_div = 0.0f; }  // exact: power of two
+    switch (desc->D) {
+      case 32: return oeh::launch_attn_fast_d32(P, desc->dtype, st);
+      case 64: return oeh::launch_attn_fast_d64(P, desc->dtype, st);
+      default: return oeh::launch_attn_fast_d128(P, desc->dtype, st);
+    }
+  }
   if (var == V_MFMA) {
     switch (desc->D) {
       case 32: return oeh::launch_attn_mfma_d32(P, desc->dtype, any_fq(fq), st);

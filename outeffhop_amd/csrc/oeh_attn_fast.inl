@@ -1,0 +1,318 @@
+// Fast fused attention kernel for 16-bit storage (f16 / bf16) - the headline path.
+//
+// Same structure as the general kernel in oeh_attn_mfma.inl (full score rows in registers, swapped
+// products S^T = K Q^T / O^T = V^T P^T on v_mfma_f32_16x16x32) with everything the hot configurations do
+// not need taken out of the per-element chain:
+//   * masks: none | key-padding vector | analytic causal.  Tiles strictly below the diagonal and inside Sk
+//     take a mask-free path (wave-uniform test per 16-key tile); masked / tail elements are set to a large
+//     negative constant, their exponential is exactly 0 as in the reference.
+//   * scale is folded into the exponent: exp(x*s - m*s) = exp2(fma(x, s*log2e, -m*s*log2e)); the row max is
+//     taken on the raw scores (s > 0).  One fma + v_exp_f32 + add per element.
+//   * without clipping the probabilities stay un-normalised (e <= 1) through P@V and each output row is
+//     multiplied by 1/den once (16 multiplies instead of Sk); with clipping (CLIP) the normalised value is
+//     formed first because clip(p*(eta-gamma)+gamma, 0, 1) is not linear.
+//   * K/V tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging) into a 4-slot ring, three
+//     tiles in flight; the ring keeps running through the softmax phase so the first V tiles are already
+//     resident when P@V starts.  The XOR swizzle is applied on the per-lane SOURCE address (the LDS image of
+//     one wave-instruction is lane-linear), reads use the same swizzle: conflict-free (tools/lds_bank_sim.py).
+//     One raw s_barrier per tile, counted s_waitcnt vmcnt(N) (never 0 in the loop).
+// Everything else (fake-quant, (B,1,Sq,Sk) masks, fp32 storage, non-power-of-two score division, gamma > 0)
+// runs the general kernel.
+#pragma once
+#include "oeh_attn_mfma.inl"
+
+namespace oeh {
+
+template <int G>
+__device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
+  // wait until all but the youngest G*tiles LDS-DMA instructions of this wave have landed
+  if (tiles <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (tiles == 1) {
+    if constexpr (G == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (G == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    if constexpr (G == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (G == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  }
+}
+
+template <int NT, int D, int IN, bool CLIP>
+__global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kernel(const AttnParams P) {
+  static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
+  constexpr int KT = NT / 4;
+  constexpr int ROWB = 2 * D;
+  constexpr int TILEB = 64 * ROWB;
+  constexpr int CPR = D / 8;          // 16-B chunks per row
+  constexpr int RPP = 64 / CPR;       // rows per 1-KiB LDS-DMA piece
+  constexpr int G = D / 32;           // pieces per wave per tile (tile = 4*G pieces)
+  constexpr int KS = D / 32;
+  constexpr int DT = D / 16;
+  constexpr int R = 4;                // ring slots
+  constexpr float NEG = -3.0e38f;
+
+  __shared__ __attribute__((aligned(16))) unsigned char lds[R * TILEB + NT * 16 * 4];
+  float* lds_pad = reinterpret_cast<float*>(lds + R * TILEB);
+
+  const int bid = blockIdx.x;
+  const int qt_rev = bid / P.nBHpad;
+  const int bh = bid - qt_rev * P.nBHpad;
+  if (bh >= P.nBH) return;
+  const int qt = P.nQT - 1 - qt_rev;
+  const int b = bh / P.H, h = bh - b * P.H;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int q0 = qt * 64 + wave * 16;
+  const int qrow = q0 + c;
+  const bool qvalid = qrow < P.Sq;
+  const int off = P.Sk - P.Sq;
+
+  int kend_wg = P.Sk, kend_wave = P.Sk;
+  if (P.skip_ok) {
+    kend_wg = min(P.Sk, max(0, qt * 64 + 64 + off));
+    kend_wave = min(P.Sk, max(0, q0 + 16 + off));
+  }
+  const int n_kt = (kend_wg + 63) >> 6;
+  const int nt_wave = (kend_wave + 15) >> 4;
+  const int T = 2 * n_kt;  // tiles in the K-then-V stream
+
+  // ---- LDS-DMA source addressing: lane -> (row inside the piece, swizzled chunk)
+  const unsigned short* kbase = reinterpret_cast<const unsigned short*>(P.k) + (long)b * P.ks_b + (long)h * P.ks_h;
+  const unsigned short* vbase = reinterpret_cast<const unsigned short*>(P.v) + (long)b * P.vs_b + (long)h * P.vs_h;
+  const int prow = lane / CPR, pch = lane % CPR;
+  auto issue_tile = [&](int i) {
+    const bool isv = i >= n_kt;
+    const int tile = isv ? i - n_kt : i;
+    const unsigned short* base = isv ? vbase : kbase;
+    const long srow = isv ? P.vs_s : P.ks_s;
+    unsigned char* slot = lds + (i & (R - 1)) * TILEB;
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int piece = wave * G + j;
+      const int row = piece * RPP + prow;
+      const int chunk = isv ? ((((pch >> 1) ^ swz_v<D>(row)) << 1) | (pch & 1)) : (pch ^ swz_k<D>(row));
+      const int key = min(tile * 64 + row, P.Sk - 1);
+      const unsigned short* src = base + (long)key * srow + chunk * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- Q^T operand
+  u4 qf[KS];
+  {
+    const long qoff = (long)b * P.qs_b + (long)h * P.qs_h + (long)qrow * P.qs_s;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = u4{0, 0, 0, 0};
+      if (qvalid) qf[ks] = load8_as16<IN>(P.q, qoff + ks * 32 + 8 * g);
+    }
+  }
+  const bool has_pad = P.pad != nullptr;
+  if (has_pad) {
+    for (int i = tid; i < NT * 16; i += 256) lds_pad[i] = (i < P.Sk) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + i) : 0.0f;
+  }
+  // ring prologue: R-1 tiles in flight
+#pragma unroll
+  for (int i = 0; i < R - 1; ++i)
+    if (i < T) issue_tile(i);
+
+  // =========================== phase 1: S^T = K Q^T ===========================
+  f4 s[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) s[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt < n_kt) {
+      const int i = kt;
+      wait_tiles_in_flight<G>(min(R - 2, T - 1 - i));
+      __builtin_amdgcn_s_barrier();
+      if (i + R - 1 < T) issue_tile(i + R - 1);
+      const unsigned char* tb = lds + (kt & (R - 1)) * TILEB;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        const int t = kt * 4 + sub;
+        if (t < nt_wave) {
+          const int row = sub * 16 + c;
+          f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const u4 kf = *reinterpret_cast<const u4*>(tb + row * ROWB + (((ks * 4 + g) ^ swz_k<D>(row)) << 4));
+            acc = mfma16<IN>(kf, qf[ks], acc);
+          }
+          s[t] = acc;
+        }
+      }
+    }
+  }
+
+  // =========================== phase 2: row statistics and exponentials ===========================
+  const float sc = P.scale;
+  const int first_lim = q0 + off;  // causal limit of the wave's first row (the tightest)
+  const int klim = qrow + off;
+  float m = -__builtin_inff();
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t < nt_wave) {
+      if (has_pad) {
+        const f4 padv = *reinterpret_cast<const f4*>(&lds_pad[16 * t + 4 * g]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[t][r] = __builtin_fmaf(s[t][r], sc, padv[r]);
+      }
+      const bool special = (P.causal && (16 * t + 15 > first_lim)) || (16 * t + 16 > P.Sk);
+      if (special) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * t + 4 * g + r;
+          if ((P.causal && key > klim) || key >= P.Sk) s[t][r] = NEG;
+        }
+      }
+      m = __builtin_fmaxf(__builtin_fmaxf(m, s[t][0]), s[t][1]);
+      m = __builtin_fmaxf(__builtin_fmaxf(m, s[t][2]), s[t][3]);
+    }
+  }
+  m = __builtin_fmaxf(m, __shfl_xor(m, 16));
+  m = __builtin_fmaxf(m, __shfl_xor(m, 32));
+
+  // in pad mode the registers hold scaled+masked scores, otherwise raw dot products
+  const float c1 = has_pad ? kLog2e : sc * kLog2e;
+  // A row whose every key is masked (only possible with a padding mask) has exp(x - m) == 1 for every key in
+  // the reference; zeroing the lane's exponent constants gives exp2(fma(x, 0, 0)) = 1 without any select.
+  const bool dead = m < -1.0e30f;
+  const float c1l = dead ? 0.0f : c1;
+  const float mcl = dead ? 0.0f : m * c1;
+  const float m_true = has_pad ? m : m * sc;
+  float sum = 0.0f;
+  u2 ph[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    ph[t] = u2{0u, 0u};
+    if (t < nt_wave) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], c1l, -mcl));
+      if (16 * t + 16 > P.Sk) {  // keys past Sk exist only in the last tile (matters for dead rows)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * t + 4 * g + r >= P.Sk) s[t][r] = 0.0f;
+      }
+      sum += (s[t][0] + s[t][1]) + (s[t][2] + s[t][3]);
+      if constexpr (!CLIP) {
+        if constexpr (IN == IN_BF16) {
+          ph[t].x = pack2_bf16(s[t][0], s[t][1]);
+          ph[t].y = pack2_bf16(s[t][2], s[t][3]);
+        } else {
+          ph[t].x = pack2_f16(s[t][0], s[t][1]);
+          ph[t].y = pack2_f16(s[t][2], s[t][3]);
+        }
+      }
+    }
+  }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  float den = sum;
+  if (P.base != 0) den = sum + exp_acc(m_true * -1.0f);
+  const float inv = 1.0f / den;
+
+  if constexpr (CLIP) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t < nt_wave) {
+        float pv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = s[t][r] * inv;
+          p = p * P.clip_w;
+          p = p + P.clip_g;
+          pv[r] = __builtin_amdgcn_fmed3f(p, 0.0f, 1.0f);
+        }
+        if (16 * t + 16 > P.Sk) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * t + 4 * g + r >= P.Sk) pv[r] = 0.0f;
+        }
+        if constexpr (IN == IN_BF16) {
+          ph[t].x = pack2_bf16(pv[0], pv[1]);
+          ph[t].y = pack2_bf16(pv[2], pv[3]);
+        } else {
+          ph[t].x = pack2_f16(pv[0], pv[1]);
+          ph[t].y = pack2_f16(pv[2], pv[3]);
+        }
+      }
+    }
+  }
+
+  // =========================== phase 3: O^T = V^T P^T ===========================
+  f4 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) o[dt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt < n_kt) {
+      const int i = n_kt + kt;
+      wait_tiles_in_flight<G>(min(R - 2, T - 1 - i));
+      __builtin_amdgcn_s_barrier();
+      if (i + R - 1 < T) issue_tile(i + R - 1);
+      const unsigned char* tb = lds + (i & (R - 1)) * TILEB;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t0 = kt * 4 + 2 * u;
+        if (t0 < nt_wave) {
+          const u4 pb = u4{ph[t0].x, ph[t0].y, ph[t0 + 1].x, ph[t0 + 1].y};
+          const int row = 32 * u + 4 * g + (c >> 2);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const unsigned char* a0 = tb + row * ROWB + ((dt ^ swz_v<D>(row)) << 5) + ((c & 3) << 3);
+            const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0));
+            const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + 16 * ROWB));
+            const u2 l2 = __builtin_bit_cast(u2, lo), h2 = __builtin_bit_cast(u2, hi);
+            o[dt] = mfma16<IN>(u4{l2.x, l2.y, h2.x, h2.y}, pb, o[dt]);
+          }
+        }
+      }
+    }
+  }
+
+  // =========================== epilogue ===========================
+  if (!qvalid) return;
+  float rowscale = CLIP ? 1.0f : inv;
+  if (P.gate != nullptr) rowscale = rowscale * P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
+  unsigned short* op = reinterpret_cast<unsigned short*>(P.o) + (long)b * P.os_b + (long)h * P.os_h + (long)qrow * P.os_s;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    u2 w;
+    if constexpr (IN == IN_BF16) {
+      w.x = pack2_bf16(o[dt][0] * rowscale, o[dt][1] * rowscale);
+      w.y = pack2_bf16(o[dt][2] * rowscale, o[dt][3] * rowscale);
+    } else {
+      w.x = pack2_f16(o[dt][0] * rowscale, o[dt][1] * rowscale);
+      w.y = pack2_f16(o[dt][2] * rowscale, o[dt][3] * rowscale);
+    }
+    *reinterpret_cast<u2*>(op + 16 * dt + 4 * g) = w;
+  }
+}
+
+template <int NT, int D>
+static int launch_fast_nt_d(const AttnParams& P, int in, hipStream_t st) {
+  const unsigned grid = (unsigned)(P.nQT * P.nBHpad);
+  if (P.clip) {
+    if (in == IN_BF16) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN_BF16, true>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN_F16, true>), dim3(grid), dim3(256), 0, st, P);
+  } else {
+    if (in == IN_BF16) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN_BF16, false>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN_F16, false>), dim3(grid), dim3(256), 0, st, P);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+template <int D>
+static int launch_fast_d(const AttnParams& P, int in, hipStream_t st) {
+  if (P.Sk <= 128) return launch_fast_nt_d<8, D>(P, in, st);
+  if (P.Sk <= 256) return launch_fast_nt_d<16, D>(P, in, st);
+  return launch_fast_nt_d<32, D>(P, in, st);
+}
+
+}  // namespace oeh

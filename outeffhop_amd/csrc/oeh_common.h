@@ -81,13 +81,15 @@ struct In<IN_F32> {
   static __device__ __forceinline__ float from_f32(float f) { return f; }
 };
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+// one v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32 (round to nearest even) per pair
 __device__ __forceinline__ unsigned int pack2_f16(float a, float b) {
-  return (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)a) |
-         ((unsigned int)__builtin_bit_cast(unsigned short, (_Float16)b) << 16);
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector((f2{a, b}), h2));
 }
 __device__ __forceinline__ unsigned int pack2_bf16(float a, float b) {
-  return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)a) |
-         ((unsigned int)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector((f2{a, b}), b2));
 }
 
 // 8 consecutive storage elements -> 8 x 16-bit MFMA operand elements (f32 storage is rounded to f16).

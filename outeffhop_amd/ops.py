@@ -96,6 +96,7 @@ def attn_fwd(
     gate: Optional[torch.Tensor] = None,
     fq: Optional[AttnFakeQuant] = None,
     out: Optional[torch.Tensor] = None,
+    _prepared: Optional[list] = None,
 ) -> torch.Tensor:
     """Fused attention core.  q,k,v are logical (B,H,S,D) views (any batch/head/seq strides, unit head-dim
     stride).  Returns the logical (B,H,Sq,D) result, stored (B,Sq,H,D)-contiguous unless `out` is given, so the
@@ -160,15 +161,35 @@ def attn_fwd(
         _fill_fq(fqd.ctx, fq.ctx)
         fqd.ctx_quant_before_gate = int(bool(fq.ctx_before_gate))
     lib = _lib.load()
+    if _prepared is not None:  # hand back the prebuilt C call instead of launching (bench / hipGraph loops)
+        args = (C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), None if fqd is None else C.byref(fqd))
+        _prepared.extend([lib.oeh_attn_fwd, args, (d, fqd, keep, q, k, v, out)])
+        return out
     rc = lib.oeh_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), None if fqd is None else C.byref(fqd), _stream())
     _lib.check(rc, "oeh_attn_fwd")
     return out
+
+
+class PreparedAttn:
+    """A fully built `oeh_attn_fwd` call (descriptor + pointers) for launch loops where Python argument
+    marshalling would otherwise dominate: `p = PreparedAttn(q, k, v, causal=True, ...); p(); p.out`."""
+
+    def __init__(self, q, k, v, **kw):
+        box = []
+        self.out = attn_fwd(q, k, v, _prepared=box, **kw)
+        self._fn, self._args, self._keep = box
+
+    def __call__(self, stream: Optional[C.c_void_p] = None) -> None:
+        rc = self._fn(*self._args, _stream() if stream is None else stream)
+        if rc != 0:
+            _lib.check(rc, "oeh_attn_fwd")
 
 
 def attn_variant(B, H, Sq, Sk, D, dtype=torch.float16, fq: bool = False) -> Optional[str]:
     """Name of the kernel variant the library would pick (host only; no GPU needed)."""
     d = oeh_attn_desc()
     d.B, d.H, d.Sq, d.Sk, d.D, d.dtype = B, H, Sq, Sk, D, _DT[dtype]
+    d.scale, d.mask_min = 1.0, float(torch.finfo(torch.float32).min)
     fqd = None
     if fq:
         fqd = oeh_fq_desc()

@@ -1,0 +1,744 @@
+"""INT8 post-training fake-quant around the attention path, MI355X side.
+
+Host-side mirror of the part of the reference's `quantization/` package that the attention hot path touches
+(SURVEY.md section 2 rows 9-12 and the attention classes of rows 6-7):
+
+  AsymmetricUniformQuantizer / SymmetricUniformQuantizer   quantization/quantizers/uniform_quantizers.py:12-310
+  CurrentMinMaxEstimator / RunningMinMaxEstimator           quantization/range_estimators.py:54-106
+  QuantizationManager (estimate -> fix state machine)       quantization/quantization_manager.py:11-108
+  QuantizedModule / QuantizedActivation                     quantization/base_quantized_classes.py:38-199
+  QuantLinear (weight + output-activation quant)            quantization/hijacker.py:27-134, autoquant_utils.py:18-20
+  Quantized{Bert,OPT}...AttentionWithExtras                 models/quantized_bert.py:221-440, quantized_opt.py:54-274
+
+Same class / attribute / buffer names (`activation_quantizer.quantizer._delta`, `_zero_float`, ...) so calibrated
+state dicts are interchangeable.  Activation fake-quant runs on the GPU: fused into the attention kernel once the
+three ranges are fixed (the INT8 validate path), as the stand-alone HIP kernel otherwise.  Range estimation keeps
+everything on the device (the reference copies each (B,H,S,S) tensor to the host for np.percentile).
+"""
+from __future__ import annotations
+
+import copy
+from enum import Enum
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .attention import AttentionGateType, BaseEnumOptions, GateState, attention_core, unfused_core
+from .ops import AttnFakeQuant, FakeQuantSpec
+from .softmax import spec_of
+
+
+class QuantizerNotInitializedError(Exception):
+    def __init__(self):
+        super().__init__("Quantizer has  not been initialized yet")
+
+
+class Qstates(BaseEnumOptions):
+    estimate_ranges = 1
+    fix_ranges = 2
+    learn_ranges = 4
+    estimate_ranges_train = 8
+
+
+# ------------------------------------------------------------------------------------------------------------
+# quantisers
+# ------------------------------------------------------------------------------------------------------------
+class AsymmetricUniformQuantizer(nn.Module):
+    """Per-tensor asymmetric uniform fake-quant: idx = clamp(round(x/scale)+zp, 0, 2^n-1); x_q = scale*(idx-zp)."""
+
+    def __init__(self, n_bits, scale_domain="linear", grad_scaling=False, eps=1e-8, per_channel=False, act_quant=False, **kwargs):
+        super().__init__()
+        if scale_domain != "linear" or per_channel or grad_scaling:
+            raise NotImplementedError("only linear-domain per-tensor quantisers are on the MI355X attention path")
+        self.n_bits = n_bits
+        self.act_quant = act_quant
+        self.per_channel = per_channel
+        self.state = None
+        self.x_min_fp32 = self.x_max_fp32 = None
+        self.register_buffer("_delta", None)
+        self.register_buffer("_zero_float", None)
+        self.scale_domain = scale_domain
+        self.eps = eps
+        self._spec_cache = None
+
+    @property
+    def delta(self):
+        if self._delta is None:
+            raise QuantizerNotInitializedError()
+        return self._delta
+
+    @property
+    def zero_float(self):
+        if self._zero_float is None:
+            raise QuantizerNotInitializedError()
+        return self._zero_float
+
+    @property
+    def is_initialized(self):
+        return self._delta is not None
+
+    @property
+    def symmetric(self):
+        return False
+
+    @property
+    def int_min(self):
+        return 0.0
+
+    @property
+    def int_max(self):
+        return 2.0 ** self.n_bits - 1
+
+    @property
+    def scale(self):
+        return torch.clamp(self.delta, min=self.eps)
+
+    @property
+    def zero_point(self):
+        return torch.clamp(torch.round(self.zero_float), self.int_min, self.int_max)
+
+    @property
+    def x_max(self):
+        return self.scale * (self.int_max - self.zero_point)
+
+    @property
+    def x_min(self):
+        return self.scale * (self.int_min - self.zero_point)
+
+    def spec(self) -> FakeQuantSpec:
+        """Host-side (scale, zero_point, qmax) for the kernels; one device->host read per range change."""
+        key = (self._delta.data_ptr(), self._delta._version, self._zero_float.data_ptr(), self._zero_float._version)
+        if self._spec_cache is None or self._spec_cache[0] != key:
+            self._spec_cache = (key, FakeQuantSpec.from_delta(float(self._delta), float(self._zero_float), self.n_bits, self.eps))
+        return self._spec_cache[1]
+
+    def to_integer_forward(self, x_float):
+        _, idx = ops.fake_quant(x_float, self.spec(), want_idx=True)
+        return idx.to(x_float.dtype)
+
+    def forward(self, x_float):
+        return ops.fake_quant(x_float, self.spec())
+
+    def _tensorize_min_max(self, x_min, x_max):
+        if not torch.is_tensor(x_min):
+            x_min = torch.tensor(x_min).float()
+            x_max = torch.tensor(x_max).float()
+        if x_min.dim() > 0 and len(x_min) > 1:
+            raise ValueError("x_min and x_max must be a float or 1-D Tensor for per-tensor quantization (per_channel=False)")
+        x_min = torch.min(x_min, torch.zeros_like(x_min))
+        x_max = torch.max(x_max, torch.ones_like(x_max) * self.eps)
+        return x_min, x_max
+
+    def set_quant_range(self, x_min, x_max):
+        self.x_min_fp32, self.x_max_fp32 = x_min, x_max
+        x_min, x_max = self._tensorize_min_max(x_min, x_max)
+        self._delta = ((x_max - x_min) / self.int_max).detach()
+        self._zero_float = (-x_min / self._delta).detach()
+
+    def fix_ranges(self):
+        pass  # ranges are plain buffers here (no learnable-range mode on this path)
+
+    def make_range_trainable(self):
+        raise NotImplementedError("learned ranges (QAT) are outside the inference hot path")
+
+    def reset(self):
+        self._delta = None
+        self._zero_float = None
+
+    def extra_repr(self):
+        return f"n_bits={self.n_bits}, per_channel={self.per_channel}, is_initalized={self.is_initialized}"
+
+
+class SymmetricUniformQuantizer(AsymmetricUniformQuantizer):
+    """Signed symmetric grid for WEIGHTS (quant_configs.py:26); evaluated once per weight and cached by QuantLinear,
+    so plain device tensor ops are enough (not on the attention core: SURVEY 8a row a12)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.register_buffer("_signed", None)
+
+    @property
+    def signed(self):
+        if self._signed is None:
+            raise QuantizerNotInitializedError()
+        return bool(self._signed.item())
+
+    @property
+    def symmetric(self):
+        return True
+
+    @property
+    def int_min(self):
+        return -(2.0 ** (self.n_bits - 1)) if self.signed else 0
+
+    @property
+    def int_max(self):
+        return 2.0 ** (self.n_bits - int(self.signed)) - 1
+
+    @property
+    def zero_point(self):
+        return 0.0
+
+    def set_quant_range(self, x_min, x_max):
+        self.x_min_fp32, self.x_max_fp32 = x_min, x_max
+        x_min, x_max = self._tensorize_min_max(x_min, x_max)
+        self._signed = x_min.min() < 0
+        self._delta = (torch.max(x_min.abs(), x_max) / self.int_max).detach()
+
+    def forward(self, x_float):
+        scale = self.scale
+        x_int = torch.clamp(torch.round(x_float / scale), self.int_min, self.int_max)
+        return scale * x_int
+
+    def to_integer_forward(self, x_float):
+        return torch.clamp(torch.round(x_float / self.scale), self.int_min, self.int_max)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# range estimators
+# ------------------------------------------------------------------------------------------------------------
+def percentile_pair(x: torch.Tensor, lo_q: float, hi_q: float):
+    """np.percentile(x, (lo_q, hi_q)) (linear interpolation, float64 result) computed on the device: the tails are
+    extracted with top-k instead of copying the tensor to the host and sorting it (range_estimators.py:90-94)."""
+    flat = x.detach().reshape(-1).float()
+    n = flat.numel()
+
+    def one(q):
+        h = (n - 1) * (q / 100.0)
+        i = int(np.floor(h))
+        frac = h - i
+        from_top = n - 1 - i  # 0 = the maximum
+        if from_top + 2 <= min(n, 1 << 20):
+            vals = torch.topk(flat, min(n, from_top + 1), largest=True, sorted=True).values  # descending
+            a = float(vals[from_top])
+            b = float(vals[from_top - 1]) if from_top >= 1 else a
+        elif i + 3 <= min(n, 1 << 20):
+            vals = torch.topk(flat, min(n, i + 2), largest=False, sorted=True).values  # ascending
+            a = float(vals[i])
+            b = float(vals[i + 1]) if i + 1 < n else a
+        else:
+            srt = torch.sort(flat).values
+            a = float(srt[i])
+            b = float(srt[min(i + 1, n - 1)])
+        # numpy's _lerp on float32 data: the difference is formed in float32, the interpolation in float64,
+        # anchored at b for frac >= 0.5
+        diff = np.float64(np.float32(b) - np.float32(a))
+        if frac >= 0.5:
+            return np.float64(np.float32(b)) - diff * (1.0 - np.float64(frac))
+        return np.float64(np.float32(a)) + diff * np.float64(frac)
+
+    return one(lo_q), one(hi_q)
+
+
+class RangeEstimatorBase(nn.Module):
+    def __init__(self, *args, per_channel=False, quantizer=None, **kwargs):
+        super().__init__()
+        if per_channel:
+            raise NotImplementedError("per-channel ranges are a weights-only option outside the attention path")
+        self.register_buffer("current_xmin", None)
+        self.register_buffer("current_xmax", None)
+        self.per_channel = per_channel
+        object.__setattr__(self, "quantizer", quantizer)  # not a submodule (keeps state-dict keys like the reference's repr)
+
+    def reset(self):
+        self.current_xmin = None
+        self.current_xmax = None
+
+
+class CurrentMinMaxEstimator(RangeEstimatorBase):
+    def __init__(self, *args, percentile=None, **kwargs):
+        self.percentile = percentile
+        super().__init__(*args, **kwargs)
+
+    def forward(self, x):
+        if self.percentile:
+            lo, hi = percentile_pair(x, self.percentile, 100 - self.percentile)
+            self.current_xmin = torch.tensor(lo).to(x.device)
+            self.current_xmax = torch.tensor(hi).to(x.device)
+        else:
+            mm = ops.minmax(x) if x.is_cuda else torch.stack([x.min(), x.max()]).float()
+            self.current_xmin, self.current_xmax = mm[0].to(x.dtype).detach(), mm[1].to(x.dtype).detach()
+        return self.current_xmin, self.current_xmax
+
+
+class RunningMinMaxEstimator(RangeEstimatorBase):
+    def __init__(self, *args, momentum=0.9, percentile=None, **kwargs):
+        self.momentum = momentum
+        self.percentile = percentile
+        super().__init__(*args, **kwargs)
+
+    def forward(self, x):
+        if self.percentile:
+            lo, hi = percentile_pair(x, 100 - self.percentile, self.percentile)
+            x_min, x_max = torch.tensor(lo).to(x.device), torch.tensor(hi).to(x.device)  # float64, like the reference
+        else:
+            mm = ops.minmax(x)
+            x_min, x_max = mm[0].to(x.dtype).detach(), mm[1].to(x.dtype).detach()
+        if self.current_xmin is None:
+            self.current_xmin, self.current_xmax = x_min, x_max
+        else:
+            self.current_xmin = (1 - self.momentum) * x_min + self.momentum * self.current_xmin
+            self.current_xmax = (1 - self.momentum) * x_max + self.momentum * self.current_xmax
+        return self.current_xmin, self.current_xmax
+
+
+class _ClsEnum(Enum):
+    @property
+    def cls(self):
+        return self.value
+
+    def __call__(self, *a, **k):
+        return self.value(*a, **k)
+
+    def __str__(self):
+        return self.name
+
+    @classmethod
+    def list_names(cls):
+        return [m.name for m in cls]
+
+
+class QMethods(_ClsEnum):
+    symmetric_uniform = SymmetricUniformQuantizer
+    asymmetric_uniform = AsymmetricUniformQuantizer
+
+
+class RangeEstimators(_ClsEnum):
+    current_minmax = CurrentMinMaxEstimator
+    running_minmax = RunningMinMaxEstimator
+
+
+# ------------------------------------------------------------------------------------------------------------
+# manager + module wrappers
+# ------------------------------------------------------------------------------------------------------------
+class QuantizationManager(nn.Module):
+    """estimate_ranges: every forward updates the range, then quantises; fix_ranges: quantise with frozen buffers."""
+
+    def __init__(self, qmethod=SymmetricUniformQuantizer, init=CurrentMinMaxEstimator, per_channel=False, x_min=None, x_max=None,
+                 qparams=None, init_params=None):
+        super().__init__()
+        self.state = Qstates.estimate_ranges
+        self.qmethod, self.init, self.per_channel = qmethod, init, per_channel
+        self.qparams = qparams if qparams else {}
+        self.init_params = init_params if init_params else {}
+        self.range_estimator = None
+        self.quantizer = self.qmethod(per_channel=self.per_channel, **self.qparams)
+        self.quantizer.state = self.state
+        if x_min is not None and x_max is not None:
+            self.set_quant_range(x_min, x_max)
+            self.fix_ranges()
+        else:
+            self.range_estimator = self.init(per_channel=self.per_channel, quantizer=self.quantizer, **self.init_params)
+
+    @property
+    def n_bits(self):
+        return self.quantizer.n_bits
+
+    def estimate_ranges(self):
+        self.state = self.quantizer.state = Qstates.estimate_ranges
+
+    def fix_ranges(self):
+        if not self.quantizer.is_initialized:
+            raise QuantizerNotInitializedError()
+        self.state = self.quantizer.state = Qstates.fix_ranges
+        self.quantizer.fix_ranges()
+
+    def estimate_ranges_train(self):
+        self.state = self.quantizer.state = Qstates.estimate_ranges_train
+
+    def reset_ranges(self):
+        self.range_estimator.reset()
+        self.quantizer.reset()
+        self.estimate_ranges()
+
+    def set_quant_range(self, x_min, x_max):
+        self.quantizer.set_quant_range(x_min, x_max)
+
+    @property
+    def is_fixed(self) -> bool:
+        return self.state == Qstates.fix_ranges or (self.state == Qstates.estimate_ranges_train and not self.training)
+
+    def forward(self, x):
+        if not self.is_fixed:
+            self.set_quant_range(*self.range_estimator(x))
+        return self.quantizer(x)
+
+    def extra_repr(self):
+        return f"state={self.state.name}"
+
+
+def _apply_qm(root: nn.Module, fn):
+    for m in root.modules():
+        if isinstance(m, QuantizationManager):
+            fn(m)
+
+
+class QuantizedModule(nn.Module):
+    """Switches a module between quantised and full-precision mode (`_quant_a` / `_quant_w` buffers)."""
+
+    def __init__(self, *args, method=AsymmetricUniformQuantizer, act_method=None, weight_range_method=CurrentMinMaxEstimator,
+                 act_range_method=RunningMinMaxEstimator, n_bits=8, n_bits_act=None, per_channel_weights=False, percentile=None,
+                 weight_range_options=None, act_range_options=None, scale_domain="linear", **kwargs):
+        for junk in ("act_quant_dict", "quant_dict", "quant_setup", "bayesian_bits_kwargs", "prune_method", "prune_kwargs"):
+            kwargs.pop(junk, None)
+        super().__init__(*args, **kwargs)
+        self.method = method
+        self.act_method = act_method or method
+        self.n_bits = n_bits
+        self.n_bits_act = n_bits_act or n_bits
+        self.per_channel_weights = per_channel_weights
+        self.percentile = percentile
+        self.weight_range_method = weight_range_method
+        self.weight_range_options = weight_range_options if weight_range_options else {}
+        self.act_range_method = act_range_method
+        self.act_range_options = act_range_options if act_range_options else {}
+        self.scale_domain = scale_domain
+        self.cached_params = None
+        self._caching = True
+        self.register_buffer("_quant_w", torch.BoolTensor([False]))
+        self.register_buffer("_quant_a", torch.BoolTensor([False]))
+        self._qa = self._qw = False  # host copies of the flags (no device read per forward)
+        self.act_qparams = dict(n_bits=self.n_bits_act, scale_domain=self.scale_domain, act_quant=True)
+        self.weight_qparams = dict(n_bits=self.n_bits, scale_domain=self.scale_domain, act_quant=False)
+
+    def quantized_weights(self):
+        self.cached_params = None
+        self._quant_w = torch.BoolTensor([True]).to(self._quant_w.device)
+        self._qw = True
+
+    def full_precision_weights(self):
+        self.cached_params = None
+        self._quant_w = torch.BoolTensor([False]).to(self._quant_w.device)
+        self._qw = False
+
+    def quantized_acts(self):
+        self._quant_a = torch.BoolTensor([True]).to(self._quant_a.device)
+        self._qa = True
+
+    def full_precision_acts(self):
+        self._quant_a = torch.BoolTensor([False]).to(self._quant_a.device)
+        self._qa = False
+
+    def quantized(self):
+        self.quantized_weights()
+        self.quantized_acts()
+
+    def full_precision(self):
+        self.full_precision_weights()
+        self.full_precision_acts()
+
+    def get_quantizer_status(self):
+        return dict(quant_a=self._qa, quant_w=self._qw)
+
+    def fix_ranges(self):
+        _apply_qm(self, lambda m: m.fix_ranges() if m.quantizer.is_initialized else None)
+
+    def estimate_ranges(self):
+        _apply_qm(self, lambda m: m.estimate_ranges())
+
+    def estimate_ranges_train(self):
+        _apply_qm(self, lambda m: m.estimate_ranges_train() if m.quantizer.is_initialized else None)
+
+    def train(self, mode=True):
+        super().train(mode)
+        if mode:
+            self.cached_params = None
+        return self
+
+    def _apply(self, *args, **kwargs):
+        self.cached_params = None
+        return super()._apply(*args, **kwargs)
+
+    def extra_repr(self):
+        return f"weight_quant={self._qw}, act_quant={self._qa}"
+
+
+class QuantizedActivation(QuantizedModule):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.activation_quantizer = QuantizationManager(qmethod=self.act_method, qparams=self.act_qparams, init=self.act_range_method,
+                                                        init_params=self.act_range_options)
+
+    def quantize_activations(self, x):
+        return self.activation_quantizer(x) if self._qa else x
+
+    def forward(self, x):
+        return self.quantize_activations(x)
+
+    def fixed_spec(self) -> Optional[FakeQuantSpec]:
+        """FakeQuantSpec if this quantiser is active with frozen ranges (fusable), None if inactive."""
+        return self.activation_quantizer.quantizer.spec() if self._qa else None
+
+    @property
+    def fusable(self) -> bool:
+        return (not self._qa) or self.activation_quantizer.is_fixed
+
+
+class QuantLinear(QuantizedModule, nn.Linear):
+    """nn.Linear with fake-quantised weights (cached in eval) and fake-quantised output activations."""
+
+    def __init__(self, *args, activation=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.activation_function = copy.deepcopy(activation) if activation else None
+        self.activation_quantizer = QuantizationManager(qmethod=self.act_method, init=self.act_range_method, qparams=self.act_qparams,
+                                                        init_params=self.act_range_options)
+        w_init = dict(percentile=self.percentile) if self.weight_range_method is CurrentMinMaxEstimator else self.weight_range_options
+        self.weight_quantizer = QuantizationManager(qmethod=self.method, init=self.weight_range_method,
+                                                    per_channel=self.per_channel_weights, qparams=self.weight_qparams, init_params=w_init)
+
+    def get_params(self):
+        if not self.training and self.cached_params:
+            return self.cached_params
+        weight, bias = self.weight, self.bias
+        if self._qw:
+            weight = self.weight_quantizer(weight)
+        if self._caching and not self.training and self.cached_params is None:
+            self.cached_params = (weight.detach().clone(), None if bias is None else bias.detach().clone())
+        return weight, bias
+
+    def forward(self, x, offsets=None):
+        weight, bias = self.get_params()
+        res = nn.functional.linear(x.contiguous(), weight.contiguous(), bias=bias)
+        if self.activation_function is not None:
+            res = self.activation_function(res)
+        if self._qa:
+            res = self.activation_quantizer(res)
+        return res
+
+
+def quantize_model(model: nn.Module, **quant_params) -> nn.Module:
+    """The nn.Linear case of the reference's recursive rewriter (autoquant_utils.py:236-270): the only one the attention
+    classes need (query/key/value, q_proj/k_proj/v_proj/out_proj)."""
+    if type(model) is nn.Linear:
+        q = QuantLinear(model.in_features, model.out_features, bias=model.bias is not None, **quant_params)
+        q.weight.data = model.weight.data
+        if model.bias is not None:
+            q.bias.data = model.bias.data
+        return q.to(model.weight.device)
+    raise NotImplementedError(f"quantize_model: {type(model).__name__} is outside the attention path")
+
+
+class QuantizedModel(nn.Module):
+    """Convenience switches over every QuantizedModule inside (base_quantized_model.py:18-162)."""
+
+    def _each(self, fn):
+        for m in self.modules():
+            if isinstance(m, QuantizedModule):
+                fn(m)
+
+    def quantized_weights(self):
+        self._each(lambda m: m.quantized_weights())
+
+    def full_precision_weights(self):
+        self._each(lambda m: m.full_precision_weights())
+
+    def quantized_acts(self):
+        self._each(lambda m: m.quantized_acts())
+
+    def full_precision_acts(self):
+        self._each(lambda m: m.full_precision_acts())
+
+    def quantized(self):
+        self._each(lambda m: m.quantized())
+
+    def full_precision(self):
+        self._each(lambda m: m.full_precision())
+
+    def fix_ranges(self):
+        _apply_qm(self, lambda m: m.fix_ranges() if m.quantizer.is_initialized else None)
+
+    def estimate_ranges(self):
+        _apply_qm(self, lambda m: m.estimate_ranges())
+
+    def estimate_ranges_train(self):
+        _apply_qm(self, lambda m: m.estimate_ranges_train() if m.quantizer.is_initialized else None)
+
+    def set_quant_state(self, weight_quant, act_quant):
+        (self.quantized_acts if act_quant else self.full_precision_acts)()
+        (self.quantized_weights if weight_quant else self.full_precision_weights)()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the two quantised attention classes
+# ------------------------------------------------------------------------------------------------------------
+class _QuantAttnBase(QuantizedModel):
+    def _init_common(self, org_model, quant_params):
+        self.attn_scores_act_quantizer = QuantizedActivation(**quant_params)
+        self.attn_probs_act_quantizer = QuantizedActivation(**quant_params)
+        self.context_act_quantizer = QuantizedActivation(**quant_params)
+        self.softmax_fn = org_model.softmax_fn
+        self.attn_gate_type = org_model.attn_gate_type
+        self.attn_gate_init = org_model.attn_gate_init
+        self.attn_gate_mlp = org_model.attn_gate_mlp
+        self.attn_gate_mlp2 = org_model.attn_gate_mlp2
+        self.attn_gate_linear_all_features = org_model.attn_gate_linear_all_features
+        self.alpha = org_model.alpha  # the gate is not quantised (quantized_bert.py:256)
+        self.gate_fn = org_model.gate_fn
+        self.pooling_fn = org_model.pooling_fn
+        self.last_gate_avg_prob = None
+        self.last_gate_all_probs = None
+
+    def _fq(self, ctx_before_gate: bool) -> Optional[AttnFakeQuant]:
+        trio = (self.attn_scores_act_quantizer, self.attn_probs_act_quantizer, self.context_act_quantizer)
+        if not all(t.fusable for t in trio):
+            return None  # still estimating ranges: the tensors must be materialised
+        return AttnFakeQuant(trio[0].fixed_spec(), trio[1].fixed_spec(), trio[2].fixed_spec(), ctx_before_gate=ctx_before_gate)
+
+
+class QuantizedBertSelfAttentionWithExtras(_QuantAttnBase):
+    """quantized_bert.py:221-440: fake-quant on scores (after /sqrt(d), before the mask), on probs, and on the context
+    AFTER gating and head merge; the gate is applied without gate_scaling_factor (:422)."""
+
+    def __init__(self, org_model, **quant_params):
+        super().__init__()
+        self.num_attention_heads = org_model.num_attention_heads
+        self.attention_head_size = org_model.attention_head_size
+        self.all_head_size = org_model.all_head_size
+        self.position_embedding_type = getattr(org_model, "position_embedding_type", None)
+        self.is_decoder = org_model.is_decoder
+        self.query = quantize_model(org_model.query, **quant_params)
+        self.key = quantize_model(org_model.key, **quant_params)
+        self.value = quantize_model(org_model.value, **quant_params)
+        self.dropout = org_model.dropout
+        self._init_common(org_model, quant_params)
+
+    def transpose_for_scores(self, x):
+        return x.view(x.size()[:-1] + (self.num_attention_heads, self.attention_head_size)).permute(0, 2, 1, 3)
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                past_key_value=None, output_attentions=False):
+        if self.position_embedding_type in ("relative_key", "relative_key_query"):
+            raise NotImplementedError("relative position embeddings are not on the quantised MI355X path")
+        q = self.transpose_for_scores(self.query(hidden_states))
+        src = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+        if encoder_hidden_states is not None:
+            attention_mask = encoder_attention_mask
+        if encoder_hidden_states is not None and past_key_value is not None:
+            k, v = past_key_value[0], past_key_value[1]
+        else:
+            k, v = self.transpose_for_scores(self.key(src)), self.transpose_for_scores(self.value(src))
+            if encoder_hidden_states is None and past_key_value is not None:
+                k, v = torch.cat([past_key_value[0], k], dim=2), torch.cat([past_key_value[1], v], dim=2)
+        new_past = (k, v) if self.is_decoder else None
+        gate = GateState.evaluate(self, hidden_states, self.num_attention_heads)
+        div = float(np.sqrt(self.attention_head_size))
+        fq = self._fq(ctx_before_gate=False)
+        fusable = (fq is not None and spec_of(self.softmax_fn) is not None and head_mask is None and not output_attentions
+                   and not (self.training and self.dropout.p > 0.0))
+        probs = None
+        if fusable:
+            context = attention_core(q, k, v, softmax_fn=self.softmax_fn, scale_div=div, attention_mask=attention_mask, gate=gate, fq=fq)
+        else:
+            ctx, _, probs = unfused_core(q, k, v, softmax_fn=self.softmax_fn, scale_div=div, attention_mask=attention_mask,
+                                         dropout=self.dropout, head_mask=head_mask, fq_scores=self.attn_scores_act_quantizer,
+                                         fq_probs=self.attn_probs_act_quantizer)
+            if gate is not None:
+                ctx = ctx * gate.to(ctx.dtype)
+            context = ctx.permute(0, 2, 1, 3).contiguous().view(ctx.shape[0], ctx.shape[2], self.all_head_size)
+            context = self.context_act_quantizer(context)
+        outputs = (context, probs) if output_attentions else (context,)
+        if self.is_decoder:
+            outputs = outputs + (new_past,)
+        return outputs
+
+
+class QuantizedOPTAttentionWithExtras(_QuantAttnBase):
+    """quantized_opt.py:54-274: fake-quant on the bmm output (before mask), on probs, and on P@V BEFORE gating; gate without
+    scaling (:257); q/k/v/out projections are QuantLinear."""
+
+    def __init__(self, org_model, **quant_params):
+        super().__init__()
+        self.embed_dim = org_model.embed_dim
+        self.num_heads = org_model.num_heads
+        self.dropout = org_model.dropout
+        self.head_dim = org_model.head_dim
+        self.scaling = org_model.scaling
+        self.is_decoder = org_model.is_decoder
+        self.k_proj = quantize_model(org_model.k_proj, **quant_params)
+        self.v_proj = quantize_model(org_model.v_proj, **quant_params)
+        self.q_proj = quantize_model(org_model.q_proj, **quant_params)
+        self.out_proj = quantize_model(org_model.out_proj, **quant_params)
+        self._init_common(org_model, quant_params)
+
+    def _heads(self, t, bsz):
+        return t.view(bsz, -1, self.num_heads, self.head_dim).permute(0, 2, 1, 3)
+
+    def _shape(self, tensor, seq_len, bsz):
+        return tensor.view(bsz, seq_len, self.num_heads, self.head_dim).transpose(1, 2).contiguous()
+
+    def forward(self, hidden_states, key_value_states=None, past_key_value=None, attention_mask=None, layer_head_mask=None,
+                output_attentions=False):
+        bsz, tgt_len, _ = hidden_states.size()
+        q = self._heads(self.q_proj(hidden_states) * self.scaling, bsz)
+        if key_value_states is not None and past_key_value is not None:
+            k, v = past_key_value[0], past_key_value[1]
+        else:
+            src = hidden_states if key_value_states is None else key_value_states
+            k, v = self._heads(self.k_proj(src), bsz), self._heads(self.v_proj(src), bsz)
+            if key_value_states is None and past_key_value is not None:
+                k, v = torch.cat([past_key_value[0], k], dim=2), torch.cat([past_key_value[1], v], dim=2)
+        new_past = (k, v) if self.is_decoder else past_key_value
+        src_len = k.size(2)
+        if attention_mask is not None and attention_mask.size() != (bsz, 1, tgt_len, src_len):
+            raise ValueError(f"Attention mask should be of size {(bsz, 1, tgt_len, src_len)}, but is {attention_mask.size()}")
+        gate = GateState.evaluate(self, hidden_states, self.num_heads)
+        fq = self._fq(ctx_before_gate=True)
+        fusable = (fq is not None and spec_of(self.softmax_fn) is not None and layer_head_mask is None and not output_attentions
+                   and not (self.training and self.dropout > 0.0))
+        weights = None
+        if fusable:
+            merged = attention_core(q, k, v, softmax_fn=self.softmax_fn, attention_mask=attention_mask, clamp_min=attention_mask is not None,
+                                    detect_causal=True, gate=gate, fq=fq)
+        else:
+            hm = None if layer_head_mask is None else layer_head_mask.view(1, -1, 1, 1)
+            drop = (lambda p: nn.functional.dropout(p, p=self.dropout, training=self.training))
+            ctx, _, used = unfused_core(q, k, v, softmax_fn=self.softmax_fn, attention_mask=attention_mask, clamp_min=attention_mask is not None,
+                                        dropout=drop, head_mask=hm, fq_scores=self.attn_scores_act_quantizer,
+                                        fq_probs=self.attn_probs_act_quantizer)
+            weights = used if output_attentions else None
+            ctx = self.context_act_quantizer(ctx)
+            if gate is not None:
+                ctx = ctx * gate.to(ctx.dtype)
+            merged = ctx.transpose(1, 2).reshape(bsz, tgt_len, self.embed_dim)
+        return self.out_proj(merged), weights, new_past
+
+
+# ------------------------------------------------------------------------------------------------------------
+# config helpers (flag names / defaults of transformers_language/quant_configs.py:7-33, utils.py:27-47)
+# ------------------------------------------------------------------------------------------------------------
+class DotDict(dict):
+    __setattr__ = dict.__setitem__
+    __delattr__ = dict.__delitem__
+
+    def __getattr__(self, key):
+        if key in self:
+            return self[key]
+        raise AttributeError(f"DotDict instance has no key '{key}' ({self.keys()})")
+
+
+def get_quant_config() -> DotDict:
+    cfg = DotDict()
+    cfg.act_quant = DotDict(cross_entropy_layer=None, num_batches=16, options={}, quant_method=RangeEstimators.running_minmax, std_dev=None)
+    cfg.quant = DotDict(act_quant=True, n_bits=8, n_bits_act=8, num_candidates=None, per_channel=False, percentile=None, quant_setup="all",
+                        qmethod=QMethods.symmetric_uniform, qmethod_act=QMethods.asymmetric_uniform, weight_quant=True,
+                        weight_quant_method=RangeEstimators.current_minmax)
+    return cfg
+
+
+def val_qparams(config) -> dict:
+    return {
+        "method": config.quant.qmethod.cls,
+        "n_bits": config.quant.n_bits,
+        "n_bits_act": config.quant.n_bits_act,
+        "act_method": config.quant.qmethod_act.cls,
+        "per_channel_weights": config.quant.per_channel,
+        "percentile": config.quant.percentile,
+        "quant_setup": config.quant.quant_setup,
+        "weight_range_method": config.quant.weight_quant_method.cls,
+        "weight_range_options": {},
+        "act_range_method": config.act_quant.quant_method.cls,
+        "act_range_options": config.act_quant.options,
+    }

@@ -604,9 +604,9 @@ def gen_theory_cfg1():
 
 
 def gen_vit():
-    from transformers_language.models.bert_attention import AttentionGateType
     from transformers_language.models.softmax import SOFTMAX_MAPPING
-    from transformers_language.models.vit_attention import ViTSelfAttentionWithExtras
+    # vit_attention.py:40-44 defines its OWN AttentionGateType class; the bert one never compares equal to it
+    from transformers_language.models.vit_attention import AttentionGateType, ViTSelfAttentionWithExtras
 
     g = torch.Generator().manual_seed(1010)
     B, N, C, H = 2, 19, 128, 2
@@ -667,19 +667,16 @@ def gen_core_cases():
 
 
 def main():
+    only = set(sys.argv[1:])
     assert os.path.isdir(REF), "reference not mounted: golden fixtures can only be generated in the build container"
     torch.set_num_threads(1)  # deterministic reduction order for the captured outputs
     _shim()
-    gen_softmax_rows()
-    gen_fakequant()
-    gen_range_estimators()
-    gen_bert_fp()
-    gen_opt_fp()
-    gen_int8()
-    gen_vit()
-    gen_core_cases()
-    gen_stanhop()
-    gen_theory_cfg1()
+    gens = [gen_softmax_rows, gen_fakequant, gen_range_estimators, gen_bert_fp, gen_opt_fp, gen_int8, gen_vit, gen_core_cases,
+            gen_stanhop, gen_theory_cfg1]
+    sys.path.insert(0, os.path.join(REF, "OutEffHop"))
+    for fn in gens:  # `make_golden.py gen_vit` regenerates one file
+        if not only or fn.__name__ in only:
+            fn()
 
 
 if __name__ == "__main__":

@@ -182,7 +182,7 @@ def test_generic_kernel_shapes(ops):
         want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=1 / math.sqrt(D), **SPECS["clippedsoftmax1(-.025:1)"])
         got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=_spec(ops, "clippedsoftmax1(-.025:1)"), scale=1 / math.sqrt(D))
         _check(got, want, msg=f"{(B, H, Sq, Sk, D)}")
-    assert ops.attn_variant(16, 12, 512, 512, 64) == "mfma16/NT32/D64/f16"
+    assert ops.attn_variant(16, 12, 512, 512, 64) == "fast16/NT32/D64/f16"
 
 
 def test_reference_golden_core(ops):

@@ -1,0 +1,49 @@
+"""N > 1 plumbing with world_size-2 gloo on CPU: contiguous batch sharding, max-over-ranks timing, parity gather.
+The per-shard computation here is a stand-in row-independent function - the GPU kernel itself is covered by
+tests/test_attn_gpu.py::test_bit_reproducible_and_batch_shard_invariant (a shard's rows are bit-identical)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from outeffhop_amd.dist import gather_batch, max_over_ranks, run_sharded, shard_bounds
+
+
+def test_shard_bounds_cover_batch_exactly():
+    for B in (1, 7, 16, 256, 257):
+        for W in (1, 2, 3, 8):
+            spans = [shard_bounds(B, W, r) for r in range(W)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert [shard_bounds(256, 8, r) for r in (0, 7)] == [(0, 32), (224, 256)]  # BASELINE config 5: 8 x 32
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+def _worker(rank, world, port, B):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(0)
+        q, k = torch.randn(B, 3, 5, generator=g), torch.randn(B, 3, 5, generator=g)
+        fn = lambda a, b: torch.softmax(a @ b.transpose(1, 2), dim=-1)  # noqa: E731  row-independent stand-in
+        full = fn(q, k)
+        local = run_sharded(fn, [q, k])
+        lo, hi = shard_bounds(B, world, rank)
+        assert torch.equal(local, full[lo:hi])  # no cross-sample dependence: a shard equals the full batch's rows
+        assert torch.equal(run_sharded(fn, [q, k], gather=True), full)
+        assert torch.equal(gather_batch(local, B), full)
+        assert max_over_ranks(1.0 + rank) == float(world)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [8, 5])
+def test_two_rank_gloo(B):
+    port = 29500 + (os.getpid() % 1000) + B
+    mp.spawn(_worker, args=(2, port, B), nprocs=2, join=True)

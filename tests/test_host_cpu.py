@@ -1,0 +1,170 @@
+"""Host-side logic that needs no GPU: the plugin registry, enum, module construction / parameter names / error
+behaviour, the device-side percentile algorithm (run on CPU tensors), and the multi-process batch-shard plumbing."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import outeffhop_amd as oa
+from outeffhop_amd import quantization as Q
+from tests.conftest import load_golden
+
+
+class Cfg:
+    hidden_size = 128
+    num_attention_heads = 2
+    attention_probs_dropout_prob = 0.1
+    position_embedding_type = "absolute"
+    is_decoder = False
+    max_position_embeddings = 64
+
+
+GATE_KW = {
+    "nogate": {},
+    "uncond_head": dict(attn_gate_type="unconditional_per_head"),
+    "tok_linear": dict(attn_gate_type="conditional_per_token", attn_gate_init=0.25),
+    "tok_mlp": dict(attn_gate_type="conditional_per_token", attn_gate_mlp=True),
+    "tok_mlp2": dict(attn_gate_type="conditional_per_token", attn_gate_mlp2=True),
+    "head_linear": dict(attn_gate_type="conditional_per_head", attn_gate_init=0.5),
+    "head_mlp": dict(attn_gate_type="conditional_per_head", attn_gate_mlp=True),
+    "tok_allfeat": dict(attn_gate_type="conditional_per_token", attn_gate_linear_all_features=True),
+    "tok_linear_ft": dict(attn_gate_type="conditional_per_token", attn_gate_init=0.25, fine_tuning=True),
+}
+
+
+def gate_kwargs(name):
+    kw = dict(GATE_KW[name])
+    if "attn_gate_type" in kw:
+        kw["attn_gate_type"] = oa.AttentionGateType[kw["attn_gate_type"]]
+    return kw
+
+
+def test_registry_matches_reference_keys_and_parameters():
+    g = load_golden("softmax_rows.npz")
+    assert list(oa.SOFTMAX_MAPPING.keys()) == [str(k) for k in g["all_keys_in_order"]]
+    for k, b, ga, et in zip(g["keys"], g["key_base"], g["key_gamma"], g["key_eta"]):
+        s = oa.SOFTMAX_MAPPING[str(k)].spec
+        assert (s.base, s.gamma if s.clip else 0.0, s.eta if s.clip else 1.0) == (int(b), float(ga), float(et)), k
+    with pytest.raises(NotImplementedError):
+        oa.SOFTMAX_MAPPING["entmax"](torch.zeros(2, 2))
+    with pytest.raises(TypeError, match="unexpected keyword argument 'dtype'"):
+        oa.SOFTMAX_MAPPING["softmax1"](torch.zeros(2, 2), dim=-1, dtype=torch.float32)  # vutils/softmax_1.py:24
+    with pytest.raises(TypeError):
+        oa.SOFTMAX_MAPPING["clippedsoftmax1(-.025:1)"](torch.zeros(2, 2), dim=-1, dtype=torch.float32)
+
+
+def test_gate_enum():
+    T = oa.AttentionGateType
+    assert T.list_names() == ["none", "unconditional_per_head", "conditional_per_head", "conditional_per_token"]
+    assert str(T.conditional_per_token) == "conditional_per_token" and T["conditional_per_head"].value == 2
+    assert abs(oa.logit(0.25) - np.log(0.25 / 0.75)) < 1e-12
+
+
+def test_parameter_names_load_reference_checkpoints_strictly():
+    g = load_golden("bert_attn_fp.npz")
+    base = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    for cj in g["cases_json"]:
+        c = json.loads(str(cj))
+        m = oa.BertSelfAttentionWithExtras(Cfg(), softmax_fn=oa.SOFTMAX_MAPPING[c["softmax"]], **gate_kwargs(c["gate"]))
+        sd = dict(base)
+        sd.update({k[len(c["name"]) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(c["name"] + ".w.")})
+        m.load_state_dict(sd, strict=True)
+        assert m.gate_scaling_factor == float(g[f"{c['name']}.gate_scaling_factor"])
+    g = load_golden("opt_attn_fp.npz")
+    base = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    for cj in g["cases_json"]:
+        c = json.loads(str(cj))
+        m = oa.OPTAttentionWithExtras(128, 2, is_decoder=True, softmax_fn=oa.SOFTMAX_MAPPING[c["softmax"]], **gate_kwargs(c["gate"]))
+        sd = dict(base)
+        sd.update({k[len(c["name"]) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(c["name"] + ".w.")})
+        m.load_state_dict(sd, strict=True)
+    g = load_golden("vit_attn_fp.npz")
+    for cj in g["cases_json"]:
+        c = json.loads(str(cj))
+        m = oa.ViTSelfAttentionWithExtras(128, num_heads=2, qkv_bias=True, softmax_fn=oa.SOFTMAX_MAPPING[c["softmax"]], **gate_kwargs(c["gate"]))
+        m.load_state_dict({k[len(c["name"]) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(c["name"] + ".w.")}, strict=True)
+    g = load_golden("stanhop_assoc.npz")
+    oa.Hopfield(64, 4, mode="softmax1").load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("hop.w.")}, strict=True)
+    oa.HopfieldPooling(64, 4, num_pattern=3, mode="softmax1").load_state_dict(
+        {k[7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("pool.w.")}, strict=True)
+
+
+def test_constructor_semantics_and_errors():
+    class Bad(Cfg):
+        hidden_size = 129
+
+    with pytest.raises(ValueError, match="not a multiple"):
+        oa.BertSelfAttentionWithExtras(Bad())
+    with pytest.raises(ValueError, match="embed_dim must be divisible"):
+        oa.OPTAttentionWithExtras(130, 4)
+    with pytest.raises(AssertionError):
+        oa.BertSelfAttentionWithExtras(Cfg(), alpha=4.0)  # alpha needs max_seq_length (bert_attention.py:90)
+    m = oa.BertSelfAttentionWithExtras(Cfg(), alpha=4.0, max_seq_length=32)
+    assert (m.softmax_fn.spec.base, m.softmax_fn.spec.gamma, m.softmax_fn.spec.eta) == (0, -0.125, 1.0)
+    m = oa.OPTAttentionWithExtras(128, 2, alpha=12.0, max_seq_length=32, attn_softmax="softmax1")
+    assert (m.softmax_fn.spec.base, m.softmax_fn.spec.gamma) == (1, -0.375)
+    m = oa.BertSelfAttentionWithExtras(Cfg(), skip_attn=True)
+    x = torch.randn(2, 5, 128)
+    assert not m(x)[0].any() and m(x)[0].shape == x.shape  # skip_attn needs no GPU
+    m = oa.BertSelfAttentionWithExtras(Cfg(), attn_gate_type=oa.AttentionGateType.conditional_per_token, attn_gate_init=0.25)
+    assert abs(float(m.alpha[0].bias) - oa.logit(0.25)) < 1e-6
+    with pytest.raises(NotImplementedError):
+        oa.Association(mode="entmax")
+    oa.Association(mode="clip_softmax1")  # TypeError in the reference (clip_softmax.py:46), works here
+    o = oa.OPTAttentionWithExtras(128, 2)
+    with pytest.raises(ValueError, match="Attention mask should be of size"):
+        o(torch.zeros(2, 4, 128), attention_mask=torch.zeros(2, 1, 4, 5))
+    with pytest.raises(oa._lib.OehError):  # no CPU path
+        oa.BertSelfAttentionWithExtras(Cfg())(x)
+
+
+def test_device_percentile_equals_numpy():
+    g = torch.Generator().manual_seed(3)
+    for n, p in ((1000, 99.0), (200000, 99.999), (7, 75.0), (3_000_000, 99.999), (50, 100.0)):
+        x = torch.randn(n, generator=g) ** 3
+        lo, hi = Q.percentile_pair(x, 100 - p, p)
+        want = np.percentile(x.numpy(), (100 - p, p))
+        assert lo == want[0] and hi == want[1] and isinstance(lo, np.float64), (n, p)
+
+
+def test_running_minmax_percentile_matches_reference_trajectory():
+    g = load_golden("range_estimators.npz")
+    for tag, pct in (("pct", 99.999), ("pct99", 99.0)):
+        est = Q.RunningMinMaxEstimator(percentile=pct)
+        qz = Q.AsymmetricUniformQuantizer(n_bits=8)
+        for i in range(4):
+            lo, hi = est(torch.from_numpy(g[f"batch{i}"]))
+            qz.set_quant_range(lo, hi)
+            got = [float(lo), float(hi), float(qz.delta), float(qz.zero_float)]
+            np.testing.assert_allclose(got, g[f"running_{tag}_traj"][i], rtol=1e-12, atol=0)
+        assert qz.delta.dtype == torch.float64
+
+
+def test_quantizer_state_machine_and_names():
+    qp = {**oa.val_qparams(oa.get_quant_config()), "quant_dict": {}}
+    act = oa.QuantizedActivation(**qp)
+    assert act(torch.ones(3)).equal(torch.ones(3))  # identity until activation quant is switched on
+    with pytest.raises(Q.QuantizerNotInitializedError):
+        act.activation_quantizer.fix_ranges()
+    with pytest.raises(Q.QuantizerNotInitializedError):
+        _ = act.activation_quantizer.quantizer.delta
+    act.activation_quantizer.set_quant_range(-1.0, 3.0)
+    act.activation_quantizer.fix_ranges()
+    assert act.activation_quantizer.state == Q.Qstates.fix_ranges
+    assert {"activation_quantizer.quantizer._delta", "activation_quantizer.quantizer._zero_float", "_quant_a", "_quant_w"} <= set(act.state_dict())
+    s = act.activation_quantizer.quantizer.spec()
+    assert (np.float32(s.scale), s.zero_point, s.qmax) == (np.float32(4.0 / 255.0), 64.0, 255.0)
+    org = oa.OPTAttentionWithExtras(128, 2, softmax_fn=oa.SOFTMAX_MAPPING["softmax1"])
+    qm = oa.QuantizedOPTAttentionWithExtras(org, **qp)
+    qm.set_quant_state(weight_quant=True, act_quant=True)
+    assert qm.q_proj.get_quantizer_status() == dict(quant_a=True, quant_w=True)
+    assert qm._fq(True) is None  # not calibrated yet -> cannot fuse
+    names = set(qm.state_dict())
+    assert {"q_proj.weight", "out_proj.bias", "attn_scores_act_quantizer._quant_a", "context_act_quantizer._quant_w"} <= names
+    # symmetric weight grid equals the reference's
+    g = load_golden("fakequant.npz")
+    wq = Q.SymmetricUniformQuantizer(n_bits=8)
+    w = torch.from_numpy(g["sym_w"])
+    wq.set_quant_range(w.min(), w.max())
+    assert np.array_equal(wq(w).numpy(), g["sym_wq"]) and float(wq.delta) == float(g["sym_delta"])

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark (GPU box): mean launch time of oeh_attn_fwd for a list of shapes / options,
+rotating over enough buffer sets to exceed the 256 MiB Infinity Cache.  Usage:
+    python tools/microbench.py "B=16,H=12,S=512,D=64,causal=1" "B=32,H=12,S=128,D=64,pad=1" ...
+keys: B H S D causal pad clip int8 dtype(f16|bf16|f32) full iters
+"""
+import ctypes as C
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from outeffhop_amd import _lib, ops
+
+
+def run(spec):
+    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1)
+    for item in spec.split(","):
+        k, v = item.split("=")
+        kv[k] = v if k == "dtype" else int(v)
+    B, H, S, D = kv["B"], kv["H"], kv["S"], kv["D"]
+    dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[kv["dtype"]]
+    eb = 4 if dt == torch.float32 else 2
+    per_set = 4 * B * H * S * D * eb
+    nsets = max(2, int(700e6 // per_set) + 1)
+    nsets = min(nsets, 64)
+    fmin = float(np.finfo(np.float32).min)
+    sets = []
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for _ in range(nsets):
+        q = (torch.randn(B, S, H * D, device="cuda", generator=g) * D ** -0.5).to(dt).view(B, S, H, D).permute(0, 2, 1, 3)
+        k = torch.randn(B, S, H * D, device="cuda", generator=g).to(dt).view(B, S, H, D).permute(0, 2, 1, 3)
+        v = torch.randn(B, S, H * D, device="cuda", generator=g).to(dt).view(B, S, H, D).permute(0, 2, 1, 3)
+        sets.append((q, k, v))
+    pad = None
+    if kv["pad"]:
+        pad = torch.zeros(B, S, device="cuda")
+        lens = torch.randint(S // 2, S + 1, (B,))
+        for b, n in enumerate(lens.tolist()):
+            pad[b, n:] = fmin
+    full = None
+    if kv["full"]:
+        full = torch.full((S, S), fmin, device="cuda").triu(1)[None, None].expand(B, 1, S, S).contiguous()
+    gate = torch.rand(B, H, S, 1, device="cuda") if kv["gate"] else None
+    fq = None
+    if kv["int8"]:
+        FQ = ops.FakeQuantSpec
+        fq = ops.AttnFakeQuant(FQ(0.08, 128.0), FQ(1.0 / 255.0, 0.0), FQ(0.02, 128.0))
+    spec_sm = ops.SoftmaxSpec(kv["base"], bool(kv["clip"]), -0.025 if kv["clip"] else 0.0, 1.1 if kv["clip"] else 1.0)
+    out = torch.empty(B, S, H, D, dtype=dt, device="cuda").permute(0, 2, 1, 3)
+    kw = dict(softmax=spec_sm, causal=bool(kv["causal"]), clamp_min=bool(kv["causal"] or kv["full"]), key_pad_mask=pad, full_mask=full,
+              gate=gate, fq=fq, mask_min=fmin, out=out)
+    calls = [ops.PreparedAttn(*st, **kw) for st in sets]
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for i in range(10):
+        calls[i % nsets](stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = kv["iters"]
+    e0.record()
+    for i in range(n):
+        calls[i % nsets](stream)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / n
+    alg = per_set
+    var = _lib.load().oeh_attn_variant  # noqa: F841
+    print(f"{spec:60s} {us:8.2f} us  {alg / us / 1e3:8.1f} GB/s alg  frac {alg / us / 1e3 / 8000:.3f}  "
+          f"{4 * B * H * S * S * D / us / 1e6:7.1f} TF(dense)  sets={nsets}", flush=True)
+
+
+if __name__ == "__main__":
+    for s in sys.argv[1:]:
+        run(s)
