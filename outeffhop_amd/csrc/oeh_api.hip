@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace oeh {
@@ -90,6 +91,8 @@ bool fast_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
   return true;
 }
 
+unsigned long long* g_stamps = nullptr;  // tools/timeline.py only
+
 Variant pick_variant(const oeh_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const oeh_fq_desc* fq) {
   const int eb = elem_bytes(d->dtype);
   const bool shape_ok = (d->D == 32 || d->D == 64 || d->D == 128) && d->Sk <= 512;
@@ -127,6 +130,7 @@ void fill_params(AttnParams& P, const oeh_attn_desc* d, const void* q, const voi
     P.fq_s = make_fq(&fq->scores); P.fq_p = make_fq(&fq->probs); P.fq_c = make_fq(&fq->ctx);
     P.ctx_before_gate = fq->ctx_quant_before_gate ? 1 : 0;
   }
+  P.stamps = g_stamps;
   P.nQT = (d->Sq + 63) / 64;
   P.nBH = d->B * d->H;
   P.nBHpad = (P.nBH + 7) & ~7;
@@ -223,6 +227,10 @@ int oeh_minmax(const void* x, int64_t n, int32_t dtype, float* out2, void* strea
   if (x == nullptr || out2 == nullptr || n <= 0 || !dtype_ok(dtype)) return OEH_EINVAL;
   return oeh::launch_minmax(x, n, dtype, out2, reinterpret_cast<hipStream_t>(stream));
 }
+
+// Diagnostic hook (not part of the ABI in include/oeh.h): device buffer of 16 u64 per wave that the resident kernel
+// fills with s_memtime stamps when non-null.  Used by tools/timeline.py only.
+void oeh_debug_set_stamps(void* device_buffer) { g_stamps = static_cast<unsigned long long*>(device_buffer); }
 
 int oeh_abi_version(void) { return OEH_ABI_VERSION; }
 

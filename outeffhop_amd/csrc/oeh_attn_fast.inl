@@ -71,25 +71,24 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kerne
   const bool qvalid = qrow < P.Sq;
   const int off = P.Sk - P.Sq;
 
-  int kend_wg = P.Sk, kend_wave = P.Sk;
+  int kend_wg = P.Sk;
   if (P.skip_ok) {
     kend_wg = min(P.Sk, max(0, qt * 64 + 64 + off));
-    kend_wave = min(P.Sk, max(0, q0 + 16 + off));
   }
   const int n_kt = (kend_wg + 63) >> 6;
-  const int nt_wave = (kend_wave + 15) >> 4;
   const int T = 2 * n_kt;  // tiles in the K-then-V stream
 
   // ---- LDS-DMA source addressing: lane -> (row inside the piece, swizzled chunk)
   const unsigned short* kbase = reinterpret_cast<const unsigned short*>(P.k) + (long)b * P.ks_b + (long)h * P.ks_h;
   const unsigned short* vbase = reinterpret_cast<const unsigned short*>(P.v) + (long)b * P.vs_b + (long)h * P.vs_h;
   const int prow = lane / CPR, pch = lane % CPR;
+  const unsigned lds_base = lds_offset(lds);
   auto issue_tile = [&](int i) {
     const bool isv = i >= n_kt;
     const int tile = isv ? i - n_kt : i;
     const unsigned short* base = isv ? vbase : kbase;
     const long srow = isv ? P.vs_s : P.ks_s;
-    unsigned char* slot = lds + (i & (R - 1)) * TILEB;
+    const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((i & (R - 1)) * TILEB + wave * G * 1024));
 #pragma unroll
     for (int j = 0; j < G; ++j) {
       const int piece = wave * G + j;
@@ -97,8 +96,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kerne
       const int chunk = isv ? ((((pch >> 1) ^ swz_v<D>(row)) << 1) | (pch & 1)) : (pch ^ swz_k<D>(row));
       const int key = min(tile * 64 + row, P.Sk - 1);
       const unsigned short* src = base + (long)key * srow + chunk * 8;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
+      glds16(src, slot + j * 1024);
     }
   };
 
@@ -116,63 +114,79 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kerne
   if (has_pad) {
     for (int i = tid; i < NT * 16; i += 256) lds_pad[i] = (i < P.Sk) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + i) : 0.0f;
   }
+  // the compiler must wait for its own loads (Q, padding row) BEFORE the first LDS-DMA is issued: later it would
+  // have to use vmcnt(0) and drain the ring
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ring prologue: R-1 tiles in flight
 #pragma unroll
   for (int i = 0; i < R - 1; ++i)
     if (i < T) issue_tile(i);
 
+  // Instruction stream: the 64-key LDS tile is also the unit of control flow.  Every wave of the workgroup runs all
+  // four 16-key sub-tiles of every tile it has waited for as straight-line code with compile-time LDS offsets and
+  // register indices - one uniform branch per tile and pass instead of one per sub-tile (the per-sub-tile guards of
+  // the first version cost ~100 scalar/branch/select instructions per 16-key tile: the kernel was ISSUE-bound).
+  // Surplus sub-tiles (above the diagonal in the last tile, or past Sk) are computed and masked; masking only runs
+  // on tiles at or after the first masked key.
   // =========================== phase 1: S^T = K Q^T ===========================
   f4 s[NT];
+  const unsigned char* kaddr[KS];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) s[t] = f4{0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < KS; ++ks) kaddr[ks] = lds + c * ROWB + (((ks * 4 + g) ^ swz_k<D>(c)) << 4);  // swz_k(16*sub + c) == swz_k(c)
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     if (kt < n_kt) {
       const int i = kt;
       wait_tiles_in_flight<G>(min(R - 2, T - 1 - i));
-      __builtin_amdgcn_s_barrier();
+      barrier_mem();
       if (i + R - 1 < T) issue_tile(i + R - 1);
-      const unsigned char* tb = lds + (kt & (R - 1)) * TILEB;
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
-        const int t = kt * 4 + sub;
-        if (t < nt_wave) {
-          const int row = sub * 16 + c;
-          f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+        f4 acc = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            const u4 kf = *reinterpret_cast<const u4*>(tb + row * ROWB + (((ks * 4 + g) ^ swz_k<D>(row)) << 4));
-            acc = mfma16<IN>(kf, qf[ks], acc);
-          }
-          s[t] = acc;
-        }
+        for (int ks = 0; ks < KS; ++ks)
+          acc = mfma16<IN>(*reinterpret_cast<const u4*>(kaddr[ks] + (kt & (R - 1)) * TILEB + sub * 16 * ROWB), qf[ks], acc);
+        s[kt * 4 + sub] = acc;
       }
     }
   }
 
   // =========================== phase 2: row statistics and exponentials ===========================
   const float sc = P.scale;
-  const int first_lim = q0 + off;  // causal limit of the wave's first row (the tightest)
-  const int klim = qrow + off;
+  const int causal = P.causal;
+  const int Sk = P.Sk;
+  const int klim = causal ? min(qrow + off, Sk - 1) : Sk - 1;            // last admissible key of this lane's row
+  const int gm0 = ((causal ? min(q0 + off, Sk - 1) : Sk - 1) + 1) >> 6;  // first 64-key tile holding a masked key (wave-uniform)
   float m = -__builtin_inff();
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (t < nt_wave) {
-      if (has_pad) {
-        const f4 padv = *reinterpret_cast<const f4*>(&lds_pad[16 * t + 4 * g]);
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt < n_kt) {
+      if (has_pad) {  // scores become scale*s + pad (BERT order); otherwise raw dot products are kept, scale folded below
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[t][r] = __builtin_fmaf(s[t][r], sc, padv[r]);
-      }
-      const bool special = (P.causal && (16 * t + 15 > first_lim)) || (16 * t + 16 > P.Sk);
-      if (special) {
+        for (int sub = 0; sub < 4; ++sub) {
+          const int t = kt * 4 + sub;
+          const f4 padv = *reinterpret_cast<const f4*>(&lds_pad[16 * t + 4 * g]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = 16 * t + 4 * g + r;
-          if ((P.causal && key > klim) || key >= P.Sk) s[t][r] = NEG;
+          for (int r = 0; r < 4; ++r) s[t][r] = __builtin_fmaf(s[t][r], sc, padv[r]);
         }
       }
-      m = __builtin_fmaxf(__builtin_fmaxf(m, s[t][0]), s[t][1]);
-      m = __builtin_fmaxf(__builtin_fmaxf(m, s[t][2]), s[t][3]);
+      if (kt >= gm0) {
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          const int t = kt * 4 + sub;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * t + 4 * g + r > klim) s[t][r] = NEG;
+        }
+      }
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        const int t = kt * 4 + sub;
+        m = __builtin_fmaxf(__builtin_fmaxf(m, s[t][0]), s[t][1]);
+        m = __builtin_fmaxf(__builtin_fmaxf(m, s[t][2]), s[t][3]);
+      }
     }
   }
   m = __builtin_fmaxf(m, __shfl_xor(m, 16));
@@ -187,26 +201,34 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kerne
   const float mcl = dead ? 0.0f : m * c1;
   const float m_true = has_pad ? m : m * sc;
   float sum = 0.0f;
-  u2 ph[NT];
+  // the packed 16-bit P^T operand overwrites the first two registers of its own score tile (no second array)
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    ph[t] = u2{0u, 0u};
-    if (t < nt_wave) {
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt < n_kt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], c1l, -mcl));
-      if (16 * t + 16 > P.Sk) {  // keys past Sk exist only in the last tile (matters for dead rows)
+      for (int sub = 0; sub < 4; ++sub) {
+        const int t = kt * 4 + sub;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (16 * t + 4 * g + r >= P.Sk) s[t][r] = 0.0f;
+        for (int r = 0; r < 4; ++r) s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], c1l, -mcl));
       }
-      sum += (s[t][0] + s[t][1]) + (s[t][2] + s[t][3]);
-      if constexpr (!CLIP) {
-        if constexpr (IN == IN_BF16) {
-          ph[t].x = pack2_bf16(s[t][0], s[t][1]);
-          ph[t].y = pack2_bf16(s[t][2], s[t][3]);
-        } else {
-          ph[t].x = pack2_f16(s[t][0], s[t][1]);
-          ph[t].y = pack2_f16(s[t][2], s[t][3]);
+      if (dead && kt >= gm0) {  // dead rows gave exp == 1 to keys past Sk as well: remove them
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          const int t = kt * 4 + sub;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * t + 4 * g + r >= Sk) s[t][r] = 0.0f;
+        }
+      }
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        const int t = kt * 4 + sub;
+        sum += (s[t][0] + s[t][1]) + (s[t][2] + s[t][3]);
+        if constexpr (!CLIP) {
+          const unsigned lo = (IN == IN_BF16) ? pack2_bf16(s[t][0], s[t][1]) : pack2_f16(s[t][0], s[t][1]);
+          const unsigned hi = (IN == IN_BF16) ? pack2_bf16(s[t][2], s[t][3]) : pack2_f16(s[t][2], s[t][3]);
+          s[t][0] = bits_f32(lo);
+          s[t][1] = bits_f32(hi);
         }
       }
     }
@@ -217,29 +239,26 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kerne
   if (P.base != 0) den = sum + exp_acc(m_true * -1.0f);
   const float inv = 1.0f / den;
 
-  if constexpr (CLIP) {
+  if constexpr (CLIP) {  // clip(p*(eta-gamma)+gamma, 0, 1); masked keys have p == 0 and stay 0 (this path requires gamma <= 0)
+    const float clip_w = P.clip_w, clip_g = P.clip_g;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (t < nt_wave) {
-        float pv[4];
+    for (int kt = 0; kt < KT; ++kt) {
+      if (kt < n_kt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float p = s[t][r] * inv;
-          p = p * P.clip_w;
-          p = p + P.clip_g;
-          pv[r] = __builtin_amdgcn_fmed3f(p, 0.0f, 1.0f);
-        }
-        if (16 * t + 16 > P.Sk) {
+        for (int sub = 0; sub < 4; ++sub) {
+          const int t = kt * 4 + sub;
+          float pv[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (16 * t + 4 * g + r >= P.Sk) pv[r] = 0.0f;
-        }
-        if constexpr (IN == IN_BF16) {
-          ph[t].x = pack2_bf16(pv[0], pv[1]);
-          ph[t].y = pack2_bf16(pv[2], pv[3]);
-        } else {
-          ph[t].x = pack2_f16(pv[0], pv[1]);
-          ph[t].y = pack2_f16(pv[2], pv[3]);
+          for (int r = 0; r < 4; ++r) {
+            float p = s[t][r] * inv;
+            p = p * clip_w;
+            p = p + clip_g;
+            pv[r] = __builtin_amdgcn_fmed3f(p, 0.0f, 1.0f);
+          }
+          const unsigned lo = (IN == IN_BF16) ? pack2_bf16(pv[0], pv[1]) : pack2_f16(pv[0], pv[1]);
+          const unsigned hi = (IN == IN_BF16) ? pack2_bf16(pv[2], pv[3]) : pack2_f16(pv[2], pv[3]);
+          s[t][0] = bits_f32(lo);
+          s[t][1] = bits_f32(hi);
         }
       }
     }
@@ -249,28 +268,29 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kerne
   f4 o[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) o[dt] = f4{0.f, 0.f, 0.f, 0.f};
+  const int vrow = 4 * g + (c >> 2);
+  const unsigned char* vaddr[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) vaddr[dt] = lds + vrow * ROWB + ((dt ^ swz_v<D>(vrow)) << 5) + ((c & 3) << 3);  // swz_v(32u+vrow) == swz_v(vrow)
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     if (kt < n_kt) {
       const int i = n_kt + kt;
       wait_tiles_in_flight<G>(min(R - 2, T - 1 - i));
-      __builtin_amdgcn_s_barrier();
+      barrier_mem();
       if (i + R - 1 < T) issue_tile(i + R - 1);
-      const unsigned char* tb = lds + (i & (R - 1)) * TILEB;
+      const int slot_off = (i & (R - 1)) * TILEB;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int t0 = kt * 4 + 2 * u;
-        if (t0 < nt_wave) {
-          const u4 pb = u4{ph[t0].x, ph[t0].y, ph[t0 + 1].x, ph[t0 + 1].y};
-          const int row = 32 * u + 4 * g + (c >> 2);
+        const u4 pb = u4{f32_bits(s[t0][0]), f32_bits(s[t0][1]), f32_bits(s[t0 + 1][0]), f32_bits(s[t0 + 1][1])};
 #pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            const unsigned char* a0 = tb + row * ROWB + ((dt ^ swz_v<D>(row)) << 5) + ((c & 3) << 3);
-            const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0));
-            const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + 16 * ROWB));
-            const u2 l2 = __builtin_bit_cast(u2, lo), h2 = __builtin_bit_cast(u2, hi);
-            o[dt] = mfma16<IN>(u4{l2.x, l2.y, h2.x, h2.y}, pb, o[dt]);
-          }
+        for (int dt = 0; dt < DT; ++dt) {
+          const unsigned char* a0 = vaddr[dt] + slot_off + u * 32 * ROWB;
+          const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0));
+          const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + 16 * ROWB));
+          const u2 l2 = __builtin_bit_cast(u2, lo), h2 = __builtin_bit_cast(u2, hi);
+          o[dt] = mfma16<IN>(u4{l2.x, l2.y, h2.x, h2.y}, pb, o[dt]);
         }
       }
     }

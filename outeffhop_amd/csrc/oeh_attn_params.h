@@ -34,6 +34,7 @@ struct AttnParams {
   int nQT;                    // q tiles (64 rows) per (b,h)
   int nBH, nBHpad;            // B*H and B*H rounded up to a multiple of 8 (XCD affinity of a head's q tiles)
   int skip_ok;                // causal tiles above the diagonal may be skipped (see oeh_api.hip)
+  unsigned long long* stamps; // diagnostic builds only: per-wave s_memtime stamps (null in production)
 };
 
 }  // namespace oeh

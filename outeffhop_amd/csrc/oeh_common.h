@@ -92,6 +92,12 @@ __device__ __forceinline__ unsigned int pack2_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned int, __builtin_convertvector((f2{a, b}), b2));
 }
 
+// Bit views of a float BY VALUE.  Never write __builtin_bit_cast(unsigned, vec[i]) on an ext_vector element: clang
+// (ROCm 7.2, clang 22) lowers that lvalue form to a load from the vector's BASE address, i.e. element 0 for every i
+// (seen as every attention row wrong with row sums of 2*(e0+e1)/den; minimal repro: tools/clang_bitcast_repro.hip).
+__device__ __forceinline__ unsigned f32_bits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float bits_f32(unsigned u) { return __builtin_bit_cast(float, u); }
+
 // 8 consecutive storage elements -> 8 x 16-bit MFMA operand elements (f32 storage is rounded to f16).
 template <int IN>
 __device__ __forceinline__ u4 load8_as16(const void* base, long elem_off) {
@@ -107,6 +113,38 @@ __device__ __forceinline__ u4 load8_as16(const void* base, long elem_off) {
   } else {
     return *reinterpret_cast<const u4*>(reinterpret_cast<const unsigned short*>(base) + elem_off);
   }
+}
+
+// LDS-DMA of 16 B per lane: LDS[lds_addr + lane*16] <- *gsrc (global_load_lds_dwordx4; 1 KiB per wave-instruction).
+// Issued through inline asm on purpose: hipcc tracks the __builtin_amdgcn_global_load_lds form as a pending LDS write
+// and puts `s_waitcnt vmcnt(0)` in front of every later LDS read, which drains a multi-tile ring right after it was
+// issued (measured: SQ_WAIT_ANY 54 % of wave cycles).  Invisible to the compiler, the transfers are ordered only by
+// the caller's counted `s_waitcnt vmcnt(N)` + s_barrier, as intended.  M0 (the LDS destination base) is saved and
+// restored inside the statement; `lds_addr` must be wave-uniform.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_addr)
+      : "memory");
+}
+// Workgroup barrier that is ALSO a compiler barrier for memory operations.  __builtin_amdgcn_s_barrier() is
+// "no memory, has side effects" to LLVM, so with the LDS-DMA hidden in inline asm the compiler may hoist LDS reads
+// of a freshly landed tile above it (seen as wholesale wrong results after an unrelated scheduling change).
+__device__ __forceinline__ void barrier_mem() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// byte offset of an LDS object inside the workgroup's allocation (what M0 / ds_* addresses are made of)
+__device__ __forceinline__ unsigned lds_offset(const void* p) {
+  return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p;
 }
 
 __device__ __forceinline__ float load_mask(const void* base, int is_f16, long off) {
