@@ -11,9 +11,9 @@
 //   * without clipping the probabilities stay un-normalised (e <= 1) through P@V and each output row is
 //     multiplied by 1/den once (16 multiplies instead of Sk); with clipping (CLIP) the normalised value is
 //     formed first because clip(p*(eta-gamma)+gamma, 0, 1) is not linear.
-//   * K/V tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging) into a 4-slot ring, three
-//     tiles in flight; the ring keeps running through the softmax phase so the first V tiles are already
-//     resident when P@V starts.  The XOR swizzle is applied on the per-lane SOURCE address (the LDS image of
+//   * K/V tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging) into two 3-slot rings (K, V),
+//     two tiles in flight; the stream keeps running through the softmax phase so the first V tiles are already
+//     resident when P@V starts.  Separate rings make every LDS slot offset a compile-time constant in the unrolled loops.  The XOR swizzle is applied on the per-lane SOURCE address (the LDS image of
 //     one wave-instruction is lane-linear), reads use the same swizzle: conflict-free (tools/lds_bank_sim.py).
 //     One raw s_barrier per tile, counted s_waitcnt vmcnt(N) (never 0 in the loop).
 // Everything else (fake-quant, (B,1,Sq,Sk) masks, fp32 storage, non-power-of-two score division, gamma > 0)
@@ -38,8 +38,12 @@ __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
   }
 }
 
+// waves per SIMD the register allocator must leave room for: 3 at NT=32 (<= 168 VGPRs), LDS allows 3 workgroups (50 KB each)
+template <int NT, int D>
+constexpr int fast_occupancy() { return D >= 128 ? 2 : (NT >= 32 ? 3 : (NT >= 16 ? 3 : 4)); }
+
 template <int NT, int D, int IN, bool CLIP>
-__global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kernel(const AttnParams P) {
+__global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_kernel(const AttnParams P) {
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
   constexpr int KT = NT / 4;
   constexpr int ROWB = 2 * D;
@@ -49,11 +53,11 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kerne
   constexpr int G = D / 32;           // pieces per wave per tile (tile = 4*G pieces)
   constexpr int KS = D / 32;
   constexpr int DT = D / 16;
-  constexpr int R = 4;                // ring slots
+  constexpr int R = 3;                // slots per ring (K ring, V ring)
   constexpr float NEG = -3.0e38f;
 
-  __shared__ __attribute__((aligned(16))) unsigned char lds[R * TILEB + NT * 16 * 4];
-  float* lds_pad = reinterpret_cast<float*>(lds + R * TILEB);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * R * TILEB + NT * 16 * 4];
+  float* lds_pad = reinterpret_cast<float*>(lds + 2 * R * TILEB);
 
   const int bid = blockIdx.x;
   const int qt_rev = bid / P.nBHpad;
@@ -81,25 +85,54 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kerne
   // ---- LDS-DMA source addressing: lane -> (row inside the piece, swizzled chunk)
   const unsigned short* kbase = reinterpret_cast<const unsigned short*>(P.k) + (long)b * P.ks_b + (long)h * P.ks_h;
   const unsigned short* vbase = reinterpret_cast<const unsigned short*>(P.v) + (long)b * P.vs_b + (long)h * P.vs_h;
+  // Per-lane source offsets of this wave's G pieces inside a tile (row of the piece, swizzled 16-B chunk); a tile
+  // further on is +64 rows.  Rows past Sk (last tile only) are redirected to row Sk-1.
   const int prow = lane / CPR, pch = lane % CPR;
   const unsigned lds_base = lds_offset(lds);
-  auto issue_tile = [&](int i) {
-    const bool isv = i >= n_kt;
-    const int tile = isv ? i - n_kt : i;
-    const unsigned short* base = isv ? vbase : kbase;
-    const long srow = isv ? P.vs_s : P.ks_s;
-    const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((i & (R - 1)) * TILEB + wave * G * 1024));
+  auto piece_row = [&](int j) { return (wave * G + j) * RPP + prow; };
+  auto k_lane_off = [&](int j) { const int row = piece_row(j); return (long)row * P.ks_s + (pch ^ swz_k<D>(row)) * 8; };
+  auto v_lane_off = [&](int j) { const int row = piece_row(j); return (long)row * P.vs_s + ((((pch >> 1) ^ swz_v<D>(row)) << 1) | (pch & 1)) * 8; };
+  // The K-then-V tile stream is issued strictly in order by `issue_next()`; its position (tile, ring slot, per-lane
+  // source offsets) is carried incrementally - no multiply / modulo per tile.
+  const long kstep = 64 * P.ks_s, vstep = 64 * P.vs_s;
+  int nx_tile = 0, nx_slot = 0;
+  bool nx_isv = false;
+  long nx_off[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) nx_off[j] = k_lane_off(j);
+  auto issue_next = [&]() {
+    const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(((nx_isv ? R : 0) + nx_slot) * TILEB + wave * G * 1024));
+    const unsigned short* base = nx_isv ? vbase : kbase;
+    const long srow = nx_isv ? P.vs_s : P.ks_s;
+    const bool tail = nx_tile * 64 + 64 > P.Sk;  // wave-uniform; rows past Sk are redirected to row Sk-1
 #pragma unroll
     for (int j = 0; j < G; ++j) {
-      const int piece = wave * G + j;
-      const int row = piece * RPP + prow;
-      const int chunk = isv ? ((((pch >> 1) ^ swz_v<D>(row)) << 1) | (pch & 1)) : (pch ^ swz_k<D>(row));
-      const int key = min(tile * 64 + row, P.Sk - 1);
-      const unsigned short* src = base + (long)key * srow + chunk * 8;
-      glds16(src, slot + j * 1024);
+      long off = nx_off[j];
+      if (tail) {
+        const int over = nx_tile * 64 + piece_row(j) - (P.Sk - 1);
+        if (over > 0) off -= (long)over * srow;
+      }
+      glds16(base + off, slot + j * 1024);
+      nx_off[j] += nx_isv ? vstep : kstep;
+    }
+    ++nx_tile;
+    nx_slot = (nx_slot == R - 1) ? 0 : nx_slot + 1;
+    if (!nx_isv && nx_tile == n_kt) {  // K exhausted: continue with V tile 0 in the V ring
+      nx_isv = true;
+      nx_tile = 0;
+      nx_slot = 0;
+#pragma unroll
+      for (int j = 0; j < G; ++j) nx_off[j] = v_lane_off(j);
     }
   };
 
+  unsigned long long* stamp = nullptr;  // diagnostic builds of tools/timeline.py only
+  if (P.stamps != nullptr) stamp = P.stamps + ((long)bid * 4 + wave) * 32;
+#define OEH_STAMP(slot)                                                                               \
+  do {                                                                                                \
+    if (stamp != nullptr && lane == 0) stamp[(slot)] = __builtin_amdgcn_s_memtime();                  \
+  } while (0)
+  OEH_STAMP(0);
   // ---- Q^T operand
   u4 qf[KS];
   {
@@ -119,10 +152,10 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kerne
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  // ring prologue: R-1 tiles in flight
-#pragma unroll
-  for (int i = 0; i < R - 1; ++i)
-    if (i < T) issue_tile(i);
+  // stream prologue: two tiles in flight
+  issue_next();
+  if (1 < T) issue_next();
+  OEH_STAMP(1);
 
   // Instruction stream: the 64-key LDS tile is also the unit of control flow.  Every wave of the workgroup runs all
   // four 16-key sub-tiles of every tile it has waited for as straight-line code with compile-time LDS offsets and
@@ -139,20 +172,22 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kerne
   for (int kt = 0; kt < KT; ++kt) {
     if (kt < n_kt) {
       const int i = kt;
-      wait_tiles_in_flight<G>(min(R - 2, T - 1 - i));
+      wait_tiles_in_flight<G>(min(1, T - 1 - i));  // tile i landed; tile i+1 may still be in flight
       barrier_mem();
-      if (i + R - 1 < T) issue_tile(i + R - 1);
+      OEH_STAMP(2 + kt);
+      if (i + 2 < T) issue_next();                 // stream tile i+2, into the slot every wave finished reading one iteration ago
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
         f4 acc = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-          acc = mfma16<IN>(*reinterpret_cast<const u4*>(kaddr[ks] + (kt & (R - 1)) * TILEB + sub * 16 * ROWB), qf[ks], acc);
+          acc = mfma16<IN>(*reinterpret_cast<const u4*>(kaddr[ks] + (kt % R) * TILEB + sub * 16 * ROWB), qf[ks], acc);
         s[kt * 4 + sub] = acc;
       }
     }
   }
 
+  OEH_STAMP(10);
   // =========================== phase 2: row statistics and exponentials ===========================
   const float sc = P.scale;
   const int causal = P.causal;
@@ -192,6 +227,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kerne
   m = __builtin_fmaxf(m, __shfl_xor(m, 16));
   m = __builtin_fmaxf(m, __shfl_xor(m, 32));
 
+  OEH_STAMP(11);
   // in pad mode the registers hold scaled+masked scores, otherwise raw dot products
   const float c1 = has_pad ? kLog2e : sc * kLog2e;
   // A row whose every key is masked (only possible with a padding mask) has exp(x - m) == 1 for every key in
@@ -264,6 +300,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kerne
     }
   }
 
+  OEH_STAMP(12);
   // =========================== phase 3: O^T = V^T P^T ===========================
   f4 o[DT];
 #pragma unroll
@@ -276,10 +313,12 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kerne
   for (int kt = 0; kt < KT; ++kt) {
     if (kt < n_kt) {
       const int i = n_kt + kt;
-      wait_tiles_in_flight<G>(min(R - 2, T - 1 - i));
+      wait_tiles_in_flight<G>(min(1, T - 1 - i));
       barrier_mem();
-      if (i + R - 1 < T) issue_tile(i + R - 1);
-      const int slot_off = (i & (R - 1)) * TILEB;
+      OEH_STAMP(13 + kt);
+      if (i + 2 < T) issue_next();
+      constexpr int slot_off_base = R * TILEB;
+      const int slot_off = slot_off_base + (kt % R) * TILEB;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int t0 = kt * 4 + 2 * u;
@@ -296,6 +335,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kerne
     }
   }
 
+  OEH_STAMP(21);
   // =========================== epilogue ===========================
   if (!qvalid) return;
   float rowscale = CLIP ? 1.0f : inv;
@@ -313,7 +353,9 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_fast_kerne
     }
     *reinterpret_cast<u2*>(op + 16 * dt + 4 * g) = w;
   }
+  OEH_STAMP(22);
 }
+#undef OEH_STAMP
 
 template <int NT, int D>
 static int launch_fast_nt_d(const AttnParams& P, int in, hipStream_t st) {

@@ -22,24 +22,22 @@ v = torch.randn(B, S, H * D, device="cuda", generator=g).half().view(B, S, H, D)
 kw = dict(causal=bool(causal), clamp_min=bool(causal), mask_min=float(np.finfo(np.float32).min))
 for _ in range(3):
     ops.attn_fwd(q, k, v, **kw)
-nwg = 192
-buf = torch.zeros(nwg * 8 * 16, dtype=torch.int64, device="cuda")
+nwg = 1536
+buf = torch.zeros(nwg * 4 * 32, dtype=torch.int64, device="cuda")
 lib.oeh_debug_set_stamps(C.c_void_p(buf.data_ptr()))
 ops.attn_fwd(q, k, v, **kw)
 torch.cuda.synchronize()
 lib.oeh_debug_set_stamps(C.c_void_p(0))
-st = buf.cpu().numpy().reshape(nwg, 8, 16).astype(np.int64)
-t0 = st[:, :, 0].min()
-names = ["start", "DMA issued", "own K landed", "barrier1", "b0 QK", "b0 max", "b0 exp", "b0 inv", "barrier2", "b0 PV", "b0 st",
-         "b1 QK", "b1 max", "b1 exp", "b1 inv", "b1 PV"]
-print(f"all-WG kernel span: {(st.max() - t0) / 100.0:.1f} us-ish at 100 MHz? raw ticks {st.max() - t0}")
-for wg in (0, 95, 191):
-    print(f"--- workgroup {wg} (ticks relative to the first stamp of the launch; s_memtime ticks)")
-    for w in range(8):
+st = buf.cpu().numpy().reshape(nwg, 4, 32).astype(np.int64)
+names = ["start", "prologue"] + [f"K{i}" for i in range(8)] + ["QKdone", "max", "exp"] + [f"V{i}" for i in range(8)] + ["PVdone", "end"]
+for wg in (0, 100, 700, 1535):   # block ids: heaviest q tiles first
+    w0 = st[wg, :, 0].min()
+    print(f"--- workgroup {wg}: s_memtime ticks since its first wave started")
+    for w in range(4):
         row = st[wg, w]
-        w0 = st[wg, :, 0].min()
-        rel = [(int(x - w0) if x else -1) for x in row]
-        print(f" wave {w}: " + " ".join(f"{n}={r}" for n, r in zip(names, rel) if r >= 0))
-dur = st[:, :, :15].max(axis=(1, 2)) - st[:, :, 0].min(axis=1)
+        print(f" wave {w}: " + " ".join(f"{n}={int(x - w0)}" for n, x in zip(names, row) if x))
+dur = st[:, :, 22].max(axis=1) - st[:, :, 0].min(axis=1)
 print("per-WG duration ticks: min/median/max", int(dur.min()), int(np.median(dur)), int(dur.max()))
-print("WG start spread ticks:", int(st[:, :, 0].min(axis=1).max() - t0))
+for qt in range(8):
+    sel = dur[(7 - qt) * 192:(8 - qt) * 192]
+    print(f" q tile {qt}: median WG duration {int(np.median(sel))} ticks")
