@@ -15,6 +15,9 @@ int launch_attn_mfma_d128(const AttnParams& P, int in, bool fq, hipStream_t st);
 int launch_attn_fast_d32(const AttnParams& P, int in, hipStream_t st);
 int launch_attn_fast_d64(const AttnParams& P, int in, hipStream_t st);
 int launch_attn_fast_d128(const AttnParams& P, int in, hipStream_t st);
+int launch_attn_flash_d32(const AttnParams& P, int in, int mq, hipStream_t st);
+int launch_attn_flash_d64(const AttnParams& P, int in, int mq, hipStream_t st);
+int launch_attn_flash_d128(const AttnParams& P, int in, int mq, hipStream_t st);
 int launch_attn_generic(const AttnParams& P, int in, hipStream_t st);
 int launch_softmax_rows(const void* x, void* y, long rows, int cols, int in, int base, int clip, float w, float g, hipStream_t st);
 int launch_fake_quant(const void* x, void* y, unsigned char* idx, long n, int in, FqP f, hipStream_t st);
@@ -45,7 +48,7 @@ FqP make_fq(const oeh_fq* f) {
   return r;
 }
 
-enum Variant { V_NONE = 0, V_FAST, V_MFMA, V_GENERIC };
+enum Variant { V_NONE = 0, V_FLASH, V_FAST, V_MFMA, V_GENERIC };
 
 // rows must be 16-byte aligned for the MFMA path's 16-B loads / 8..16-B stores
 bool aligned16(const void* p, const int64_t* st, int eb) {
@@ -91,7 +94,32 @@ bool fast_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
   return true;
 }
 
+int g_force_flash = 0;                   // tools/microbench.py only
+int g_lds_pad = 0;                       // tools/microbench.py only
+
+// The one-pass kernel (oeh_attn_flash.inl) additionally needs the plain softmax_n (no clip) and, with key padding,
+// softmax_1 (a fully padded row is 0 there; under vanilla softmax it is uniform over all keys, which a one-pass
+// kernel that may skip tiles cannot reproduce).  No Sk limit.
+bool flash_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
+  if (!fast_eligible(d, fq) || d->clip) return false;
+  if (d->key_pad_mask != nullptr && d->softmax_base != OEH_SOFTMAX_ONE) return false;
+  // short rows (<= 128 keys) fit the full-row kernel's registers in one pass, which measures faster there
+  // (BERT-base S=128: 10.0 vs 11.7 us per launch)
+  if (d->Sk <= 128 && !g_force_flash) return false;
+  return true;
+}
+
 unsigned long long* g_stamps = nullptr;  // tools/timeline.py only
+int g_variant_off = 0;                   // tools/microbench.py only: bit (1 << Variant) disables a variant
+int g_flash_mq = 0;                      // tools/microbench.py only: force query blocks per wave
+
+// query blocks (16 rows) per wave of the one-pass kernel: 2 (128-row workgroups) once that still gives every CU two
+// workgroups, else 1
+int flash_mq(const oeh_attn_desc* d) {
+  if (g_flash_mq != 0) return g_flash_mq;
+  const long wg2 = (long)((d->Sq + 127) / 128) * d->B * d->H;
+  return (d->Sq > 64 && wg2 >= 512) ? 2 : 1;
+}
 
 Variant pick_variant(const oeh_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const oeh_fq_desc* fq) {
   const int eb = elem_bytes(d->dtype);
@@ -101,7 +129,9 @@ Variant pick_variant(const oeh_attn_desc* d, const void* q, const void* k, const
   if (fq != nullptr && fq->probs.enable) p_exact = fq->probs.qmax <= (d->dtype == OEH_BF16 ? 255.0f : 2047.0f);
   const bool al = (q == nullptr) || (aligned16(q, d->q_stride, eb) && aligned16(k, d->k_stride, eb) &&
                                      aligned16(v, d->v_stride, eb) && aligned16(o, d->o_stride, eb));
-  if (shape_ok && al && fast_eligible(d, fq)) return V_FAST;
+  const bool d_ok = d->D == 32 || d->D == 64 || d->D == 128;
+  if (d_ok && al && flash_eligible(d, fq) && !(g_variant_off & (1 << V_FLASH))) return V_FLASH;
+  if (shape_ok && al && fast_eligible(d, fq) && !(g_variant_off & (1 << V_FAST))) return V_FAST;
   if (shape_ok && p_exact && al) return V_MFMA;
   if ((size_t)(d->D + d->Sk) * 4 <= 64 * 1024) return V_GENERIC;
   return V_NONE;
@@ -131,6 +161,7 @@ void fill_params(AttnParams& P, const oeh_attn_desc* d, const void* q, const voi
     P.ctx_before_gate = fq->ctx_quant_before_gate ? 1 : 0;
   }
   P.stamps = g_stamps;
+  P.dbg_lds_pad = g_lds_pad;
   P.nQT = (d->Sq + 63) / 64;
   P.nBH = d->B * d->H;
   P.nBHpad = (P.nBH + 7) & ~7;
@@ -150,7 +181,8 @@ const char* variant_name(Variant v, const oeh_attn_desc* d, bool fq) {
   if (v == V_NONE) return nullptr;
   const int nt = d->Sk <= 128 ? 8 : (d->Sk <= 256 ? 16 : 32);
   const char* dt = d->dtype == OEH_F16 ? "f16" : (d->dtype == OEH_BF16 ? "bf16" : "f32");
-  if (v == V_FAST) std::snprintf(buf, sizeof(buf), "fast16/NT%d/D%d/%s%s", nt, d->D, dt, d->clip ? "/clip" : "");
+  if (v == V_FLASH) std::snprintf(buf, sizeof(buf), "flash16/MQ%d/D%d/%s", flash_mq(d), d->D, dt);
+  else if (v == V_FAST) std::snprintf(buf, sizeof(buf), "fast16/NT%d/D%d/%s%s", nt, d->D, dt, d->clip ? "/clip" : "");
   else std::snprintf(buf, sizeof(buf), "mfma16/NT%d/D%d/%s%s", nt, d->D, dt, fq ? "/fq" : "");
   return buf;
 }
@@ -168,6 +200,16 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
   AttnParams P;
   fill_params(P, desc, q, k, v, o, fq);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (var == V_FLASH) {
+    if (desc->scale_div != 0.0f) { P.scale = 1.0f / desc->scale_div; P.scale_div = 0.0f; }  // exact: power of two
+    const int mq = flash_mq(desc);
+    P.nQT = (desc->Sq + 64 * mq - 1) / (64 * mq);
+    switch (desc->D) {
+      case 32: return oeh::launch_attn_flash_d32(P, desc->dtype, mq, st);
+      case 64: return oeh::launch_attn_flash_d64(P, desc->dtype, mq, st);
+      default: return oeh::launch_attn_flash_d128(P, desc->dtype, mq, st);
+    }
+  }
   if (var == V_FAST) {
     if (desc->scale_div != 0.0f) { P.scale = 1.0f / desc->scale_div; P.scale_div = 0.0f; }  // exact: power of two
     switch (desc->D) {
@@ -230,6 +272,9 @@ int oeh_minmax(const void* x, int64_t n, int32_t dtype, float* out2, void* strea
 
 // Diagnostic hook (not part of the ABI in include/oeh.h): device buffer of 16 u64 per wave that the resident kernel
 // fills with s_memtime stamps when non-null.  Used by tools/timeline.py only.
+void oeh_debug_set_variant(int off_mask, int flash_mq_force) {
+  g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_lds_pad = (off_mask >> 16) * 1024; g_flash_mq = flash_mq_force;
+}
 void oeh_debug_set_stamps(void* device_buffer) { g_stamps = static_cast<unsigned long long*>(device_buffer); }
 
 int oeh_abi_version(void) { return OEH_ABI_VERSION; }

@@ -35,6 +35,7 @@ struct AttnParams {
   int nBH, nBHpad;            // B*H and B*H rounded up to a multiple of 8 (XCD affinity of a head's q tiles)
   int skip_ok;                // causal tiles above the diagonal may be skipped (see oeh_api.hip)
   unsigned long long* stamps; // diagnostic builds only: per-wave s_memtime stamps (null in production)
+  int dbg_lds_pad;            // tools/microbench.py only: extra dynamic LDS bytes per workgroup (occupancy experiments)
 };
 
 }  // namespace oeh

@@ -185,11 +185,13 @@ class PreparedAttn:
             _lib.check(rc, "oeh_attn_fwd")
 
 
-def attn_variant(B, H, Sq, Sk, D, dtype=torch.float16, fq: bool = False) -> Optional[str]:
+def attn_variant(B, H, Sq, Sk, D, dtype=torch.float16, fq: bool = False, clip: bool = False) -> Optional[str]:
     """Name of the kernel variant the library would pick (host only; no GPU needed)."""
     d = oeh_attn_desc()
     d.B, d.H, d.Sq, d.Sk, d.D, d.dtype = B, H, Sq, Sk, D, _DT[dtype]
     d.scale, d.mask_min = 1.0, float(torch.finfo(torch.float32).min)
+    if clip:
+        d.clip, d.gamma, d.eta = 1, -0.025, 1.0
     fqd = None
     if fq:
         fqd = oeh_fq_desc()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic (GPU box): per-wave s_memtime timeline of the K/V-resident attention kernel.
+"""Diagnostic (GPU box): per-wave s_memtime timeline of the one-pass attention kernel (flash16, MQ=2).
 Never quote run times from this build path: the stamps perturb the schedule; read the SHARES."""
 import ctypes as C
 import os
@@ -22,22 +22,25 @@ v = torch.randn(B, S, H * D, device="cuda", generator=g).half().view(B, S, H, D)
 kw = dict(causal=bool(causal), clamp_min=bool(causal), mask_min=float(np.finfo(np.float32).min))
 for _ in range(3):
     ops.attn_fwd(q, k, v, **kw)
-nwg = 1536
+nwg = 768
 buf = torch.zeros(nwg * 4 * 32, dtype=torch.int64, device="cuda")
 lib.oeh_debug_set_stamps(C.c_void_p(buf.data_ptr()))
 ops.attn_fwd(q, k, v, **kw)
 torch.cuda.synchronize()
 lib.oeh_debug_set_stamps(C.c_void_p(0))
 st = buf.cpu().numpy().reshape(nwg, 4, 32).astype(np.int64)
-names = ["start", "prologue"] + [f"K{i}" for i in range(8)] + ["QKdone", "max", "exp"] + [f"V{i}" for i in range(8)] + ["PVdone", "end"]
-for wg in (0, 100, 700, 1535):   # block ids: heaviest q tiles first
+names = ["start", "prologue", "loopdone", "end"] + [f"{a}{i}" for i in range(14) for a in ("bar", "cmp")]
+order = [0, 1] + list(range(4, 32)) + [2, 3]
+for wg in (0, 100, 300, 500, 767):   # block ids: heaviest q tiles first
     w0 = st[wg, :, 0].min()
     print(f"--- workgroup {wg}: s_memtime ticks since its first wave started")
     for w in range(4):
         row = st[wg, w]
-        print(f" wave {w}: " + " ".join(f"{n}={int(x - w0)}" for n, x in zip(names, row) if x))
-dur = st[:, :, 22].max(axis=1) - st[:, :, 0].min(axis=1)
+        print(f" wave {w}: " + " ".join(f"{names[i]}={int(row[i] - w0)}" for i in order if row[i]))
+dur = st[:, :, 3].max(axis=1) - st[:, :, 0].min(axis=1)
 print("per-WG duration ticks: min/median/max", int(dur.min()), int(np.median(dur)), int(dur.max()))
-for qt in range(8):
-    sel = dur[(7 - qt) * 192:(8 - qt) * 192]
-    print(f" q tile {qt}: median WG duration {int(np.median(sel))} ticks")
+t0 = st[:, :, 0].min()
+print("kernel span ticks (first start .. last end):", int(st[:, :, 3].max() - t0))
+for qt in range(4):
+    sel = slice((3 - qt) * 192, (4 - qt) * 192)
+    print(f" q tile {qt}: median WG duration {int(np.median(dur[sel]))} ticks, median start {int(np.median(st[sel, :, 0].min(axis=1) - t0))}")
