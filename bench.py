@@ -245,7 +245,7 @@ def main():
             "dtype": "f16 storage, f32 accumulate" if not w["int8"] else "f16 storage, f32 accumulate, 8-bit fake-quant grids",
             "data": "synthetic",
             "config": {
-                "workload": w["desc"], "variant": ops.attn_variant(B, H, S, S, d, fq=w["int8"]),
+                "workload": w["desc"], "variant": ops.attn_variant(B, H, S, S, d, fq=w["int8"], clip=bool(w["sm"][1])),
                 "batch_per_gpu": B, "seq_len": S, "heads": H, "head_dim": d, "layers_per_step": L,
                 "launches_per_step": L, "model_tokens_per_s": world * B * S * a.steps / wall,
                 "parallelism": f"batch-shard x{world}, no collective in the timed region",

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liboeh_hip.so")
+# OEH_LIB: explicit path of another build of the same library (A/B timing of compiler flags; tools/ only)
+LIB_PATH = os.environ.get("OEH_LIB") or os.path.join(_HERE, "lib", "liboeh_hip.so")
 
 OEH_F16, OEH_BF16, OEH_F32 = 0, 1, 2
 OEH_SOFTMAX_VANILLA, OEH_SOFTMAX_ONE = 0, 1

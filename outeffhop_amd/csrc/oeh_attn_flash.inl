@@ -1,49 +1,41 @@
 // One-pass ("online") fused attention for the PLAIN softmax / softmax_1 case, 16-bit storage - the headline
-// configuration (OPT-125m softmax1, BERT softmax1 with key padding, gated variants).
+// configuration (OPT-125m softmax1, gated variants, long BERT/ViT rows).
 //
 // Why a second structure: the full-row kernel (oeh_attn_fast.inl) must keep a query block's complete score row in
 // registers because clipping and fake-quant are non-linear in the final probability; that caps a workgroup at 64
 // query rows, so a head's K/V is re-streamed through LDS once per 64 rows (4.5x for causal S=512) and the in-kernel
-// timeline (tools/timeline.py) shows its K and V phases paced by that LDS-DMA traffic (~780 cycles per 64-key tile
-// against ~200 cycles of work).  Plain softmax_n has no such constraint (hard part 1): with the running
-// state (m, l) per row, exp(x - m_run) is accumulated tile by tile and the output rescaled when the maximum moves.
-// softmax_1's "+1" is exp(0 - m) added to l once at the end - the reference formula, including rows that are exactly 0
-// when exp(-m) overflows.  Hence:
+// timeline (tools/timeline.py) shows its K and V phases paced by that LDS-DMA traffic.  Plain softmax_n has no such
+// constraint (hard part 1): with a per-row reference score, exp(x - reference) is accumulated tile by tile
+// and the sums rescaled when the reference moves.  softmax_1's "+1" is exp(0 - reference) added to the row sum once
+// at the end - the reference formula, including rows that are exactly 0 when every key is masked.  Hence:
 //   * one workgroup = 4 waves x MQ query blocks of 16 rows (MQ=2: 128 rows) -> K/V stream 2.3x smaller, and K and V
 //     tiles arrive TOGETHER: one barrier per 64 keys instead of two;
-//   * registers: Q, O and one 64-key score tile per block only (no Sk limit, ~110 VGPRs at MQ=2 -> 4 waves/SIMD);
+//   * registers: Q, O and one 64-key score tile per block only (no Sk limit);
 //   * every K fragment read from LDS feeds MQ MFMAs and every V^T fragment feeds MQ MFMAs (LDS bandwidth / MQ);
-//   * row max all-reduce by v_permlane16_swap / v_permlane32_swap (VALU), not ds_bpermute (LDS round trip).
+//   * row max all-reduce by v_permlane16_swap / v_permlane32_swap (VALU), not ds_bpermute (LDS round trip);
+//   * row sums by one extra MFMA per 32 keys against a ones operand (sums exactly the rounded P the second product
+//     uses, and frees 16 v_add per block and tile - the loop is VALU-issue bound, not MFMA bound);
+//   * lazy reference: it moves only when a row's tile maximum exceeds it by 2^8, so the O/l rescale (20 multiplies per
+//     block) almost never runs after the first tiles;
+//   * causal BALANCING (P.pair): query rows are cut into 64-row slabs and workgroup a of a head takes slab a AND slab
+//     N-1-a, 16 rows of each per wave.  Every workgroup then has the same number of (block x tile) products, all
+//     co-resident workgroups stay busy to the end (a lone wave per SIMD runs the loop 2.5x slower per tile than three
+//     sharing it), and the kernel no longer ends on the heavy last-rows workgroups.
 // Same swapped products (S^T = K Q^T, O^T = V^T P^T on v_mfma_f32_16x16x32), LDS images, swizzles and LDS-DMA ring
 // as the full-row kernel.  Masks: none | analytic causal | key padding (softmax_1 only: a fully masked row must be 0).
 #pragma once
 #include "oeh_attn_fast.inl"
 
+#include <type_traits>
+
 namespace oeh {
 
-// single-instruction forms: plain -O3 puts a canonicalising v_max in front of fmaxf on MFMA outputs and SLP-packs
-// neighbouring f32 multiplies into v_pk_mul_f32, both slower beside MFMAs (MI355X_MICROARCH, per-instruction constants)
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-__device__ __forceinline__ float vmax(float a, float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float vmul(float a, float b) {
-  float r;
-  asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 // all-reduce over the 4 lanes (c, c+16, c+32, c+48) that hold one query row, without LDS
 __device__ __forceinline__ float row_allreduce_max(float x) {
   auto a = __builtin_amdgcn_permlane16_swap(f32_bits(x), f32_bits(x), false, false);
-  x = vmax(bits_f32(a[0]), bits_f32(a[1]));
+  x = __builtin_fmaxf(bits_f32(a[0]), bits_f32(a[1]));
   auto b = __builtin_amdgcn_permlane32_swap(f32_bits(x), f32_bits(x), false, false);
-  return vmax(bits_f32(b[0]), bits_f32(b[1]));
+  return __builtin_fmaxf(bits_f32(b[0]), bits_f32(b[1]));
 }
 
 template <int D, int MQ>
@@ -52,6 +44,7 @@ constexpr int flash_occupancy() { return D >= 128 ? 2 : (MQ >= 4 ? 2 : 3); }
 template <int D, int IN, int MQ>
 __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flash_kernel(const AttnParams P) {
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
+  static_assert(MQ == 1 || MQ == 2, "one or two query blocks per wave");
   constexpr int ROWB = 2 * D;
   constexpr int TILEB = 64 * ROWB;      // one operand tile (64 keys)
   constexpr int STAGEB = 2 * TILEB;     // K tile + V tile
@@ -62,7 +55,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   constexpr int DT = D / 16;
   constexpr int R = 3;                  // stages
   constexpr int QROWS = 64 * MQ;        // query rows per workgroup
-  constexpr float NEG = -1.0e30f;       // masked score / initial running max (finite: NEG * log2e does not overflow)
+  constexpr float NEG = -1.0e30f;       // floor of a padded score (finite: NEG * log2e does not overflow)
+  constexpr float NEGT = -1.0e30f;      // exponent argument of a masked key: exp2 -> 0 exactly
+  constexpr float kThr = 8.0f;          // lazy reference: P stays <= 2^8 (exact range for f16 / bf16 operands)
 
   __shared__ __attribute__((aligned(16))) unsigned char lds[R * STAGEB];
 
@@ -70,7 +65,6 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   const int qt_rev = bid / P.nBHpad;
   const int bh = bid - qt_rev * P.nBHpad;
   if (bh >= P.nBH) return;
-  const int qt = P.nQT - 1 - qt_rev;    // heaviest causal tiles first
   const int b = bh / P.H, h = bh - b * P.H;
 
   const int tid = threadIdx.x;
@@ -80,43 +74,42 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   const int Sk = P.Sk, Sq = P.Sq;
   const int off = Sk - Sq;
   const int causal = P.causal;
-  const int q0w = qt * QROWS + wave * (16 * MQ);   // first query row of this wave
 
-  int kend_wg = Sk, kend_wave = Sk;
-  if (causal) {
-    kend_wg = min(Sk, max(0, qt * QROWS + QROWS + off));
-    kend_wave = min(Sk, max(0, q0w + 16 * MQ + off));
+  // ---- query blocks of this wave: rb[j] = first row of block j, nkb[j] = 64-key tiles it needs (nkb[0] <= nkb[MQ-1])
+  int rb[MQ], nkb[MQ];
+  int last_row_wg;                      // last query row of the workgroup (bounds the tiles it streams)
+  if (MQ == 2 && P.pair) {
+    const int lo = qt_rev, hi = P.nSlab - 1 - qt_rev;
+    rb[0] = (lo == hi) ? -1 : 64 * lo + 16 * wave;  // odd slab count: the middle workgroup has one block only
+    rb[MQ - 1] = 64 * hi + 16 * wave;
+    last_row_wg = 64 * hi + 63;
+  } else {
+    const int qt = P.nQT - 1 - qt_rev;  // heaviest causal tiles first
+#pragma unroll
+    for (int j = 0; j < MQ; ++j) rb[j] = qt * QROWS + wave * (16 * MQ) + 16 * j;
+    last_row_wg = qt * QROWS + QROWS - 1;
   }
-  const int n_kt = (kend_wg + 63) >> 6;        // tiles the workgroup streams (uniform)
-  const int n_kt_wave = (kend_wave + 63) >> 6; // tiles this wave computes on
+  const int n_kt = ((causal ? min(Sk, max(0, last_row_wg + 1 + off)) : Sk) + 63) >> 6;  // tiles the workgroup streams
+  int tm0[MQ];                          // first tile that holds a masked key for the block's first row
+#pragma unroll
+  for (int j = 0; j < MQ; ++j) {
+    if (rb[j] < 0) {
+      rb[j] = (Sq + 15) & ~15;          // disabled block: rows >= Sq are neither loaded nor stored
+      nkb[j] = 0;
+    } else {
+      nkb[j] = ((causal ? min(Sk, max(0, rb[j] + 16 + off)) : Sk) + 63) >> 6;
+    }
+    tm0[j] = ((causal ? min(rb[j] + off, Sk - 1) : Sk - 1) + 1) >> 6;
+  }
 
-  unsigned long long* stamp = nullptr;  // diagnostic builds of tools/timeline.py only
+  unsigned long long* stamp = nullptr;  // diagnostic runs of tools/timeline.py only
   if (P.stamps != nullptr) stamp = P.stamps + ((long)bid * 4 + wave) * 32;
 #define OEH_STAMP(slot)                                                                \
   do {                                                                                 \
     if (stamp != nullptr && lane == 0) stamp[(slot)] = __builtin_amdgcn_s_memtime();   \
   } while (0)
   OEH_STAMP(0);
-
-  // ---- Q^T operands of this wave's MQ query blocks
-  u4 qf[MQ][KS];
-#pragma unroll
-  for (int j = 0; j < MQ; ++j) {
-    const int qrow = q0w + 16 * j + c;
-    const long qoff = (long)b * P.qs_b + (long)h * P.qs_h + (long)qrow * P.qs_s;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      qf[j][ks] = u4{0, 0, 0, 0};
-      if (qrow < Sq) qf[j][ks] = load8_as16<IN>(P.q, qoff + ks * 32 + 8 * g);
-    }
-  }
-  // consume the Q registers before the first LDS-DMA: the compiler's wait for them must not land inside the DMA stream
-#pragma unroll
-  for (int j = 0; j < MQ; ++j)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      asm volatile("" : "+v"(qf[j][ks].x), "+v"(qf[j][ks].y), "+v"(qf[j][ks].z), "+v"(qf[j][ks].w));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (stamp != nullptr && lane == 0) stamp[30] = __builtin_amdgcn_s_memrealtime();
 
   // ---- LDS-DMA stream of (K tile, V tile) stages, strictly in order, position carried incrementally
   const unsigned short* kbase = reinterpret_cast<const unsigned short*>(P.k) + (long)b * P.ks_b + (long)h * P.ks_h;
@@ -153,6 +146,27 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   };
   issue_next();
   if (1 < n_kt) issue_next();
+
+  // ---- Q^T operands of this wave's query blocks.  Q goes out AFTER the first two stages (one exposed memory
+  // latency, not two) and is consumed here, before the loop: the compiler's own wait for these loads must not land
+  // inside the DMA stream, where it would drain the ring.
+  u4 qf[MQ][KS];
+#pragma unroll
+  for (int j = 0; j < MQ; ++j) {
+    const int qrow = rb[j] + c;
+    const long qoff = (long)b * P.qs_b + (long)h * P.qs_h + (long)qrow * P.qs_s;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[j][ks] = u4{0, 0, 0, 0};
+      if (qrow < Sq) qf[j][ks] = load8_as16<IN>(P.q, qoff + ks * 32 + 8 * g);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MQ; ++j)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      asm volatile("" : "+v"(qf[j][ks].x), "+v"(qf[j][ks].y), "+v"(qf[j][ks].z), "+v"(qf[j][ks].w));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   OEH_STAMP(1);
 
   // lane-constant parts of the LDS fragment addresses
@@ -167,23 +181,143 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   const bool has_pad = P.pad != nullptr;
   const float sc = P.scale;
   const float c1 = has_pad ? kLog2e : sc * kLog2e;   // pad mode keeps scaled+masked scores, otherwise raw dot products
-  constexpr float kThr = 8.0f;          // lazy rescale: the reference maximum moves only when a row's tile maximum
-                                        // exceeds it by 2^8 (P stays <= 256, exact range for f16/bf16 operands)
   const u4 ones = (IN == IN_BF16) ? u4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}
                                   : u4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
-  float m_run[MQ], mcneg[MQ];           // reference maximum of the exponent and -(max(m_run,-1e20) * c1)
+  // Per-row state: mcneg = -(reference score) * c1 in exponent (log2) units, so that t = fma(s, c1, mcneg) is the
+  // exponent argument; O and l are sums of exp2(t).  The reference is the first tile's row maximum and afterwards
+  // moves only when a tile maximum exceeds it by 2^8.  softmax_1's "+1" is exp2(mcneg) (= exp(-reference)).
+  float mcneg[MQ];
   f4 lacc[MQ];                          // row sums of the ROUNDED P, accumulated by a ones-row MFMA (every register = l)
   f4 o[MQ][DT];
 #pragma unroll
   for (int j = 0; j < MQ; ++j) {
-    m_run[j] = NEG;
-    mcneg[j] = 1.0e20f * c1;
+    mcneg[j] = 0.0f;
     lacc[j] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[j][dt] = f4{0.f, 0.f, 0.f, 0.f};
   }
-  // first 64-key tile that holds a masked key for the wave's first row (masks only run from there on)
-  const int tm0 = ((causal ? min(q0w + off, Sk - 1) : Sk - 1) + 1) >> 6;
+
+  // ---- one 64-key tile for blocks J0..MQ-1 of this wave (J0 = 1: block 0's rows end before this tile)
+  auto tile = [&](auto j0c, const int i, const int soff) {
+    constexpr int J0 = decltype(j0c)::value;
+    // S^T = K Q^T; every K fragment is read once and used by all active blocks
+    f4 s[MQ][4];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      u4 kf[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const u4*>(kaddr[ks] + soff + sub * 16 * ROWB);
+#pragma unroll
+      for (int j = J0; j < MQ; ++j) {
+        f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = mfma16<IN>(kf[ks], qf[j][ks], acc);
+        s[j][sub] = acc;
+      }
+    }
+    // exponent arguments t = (s - reference) * log2e  [key padding: BERT order scale*s + pad first]
+    if (has_pad) {
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        const int kb = 64 * i + 16 * sub + 4 * g;
+        f4 padv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) padv[r] = (kb + r < Sk) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + kb + r) : 0.0f;
+#pragma unroll
+        for (int j = J0; j < MQ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[j][sub][r] = __builtin_fmaxf(__builtin_fmaf(s[j][sub][r], sc, padv[r]), NEG);
+      }
+    }
+#pragma unroll
+    for (int j = J0; j < MQ; ++j)
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[j][sub][r] = __builtin_fmaf(s[j][sub][r], c1, mcneg[j]);
+    // causal / tail mask, classified per 16x16 sub-tile with wave-uniform tests: untouched, all masked, or mixed
+#pragma unroll
+    for (int j = J0; j < MQ; ++j) {
+      if (i < tm0[j]) continue;
+      const int lim_lo = causal ? min(rb[j] + off, Sk - 1) : Sk - 1;        // last visible key of the block's first row
+      const int lim_hi = causal ? min(rb[j] + 15 + off, Sk - 1) : Sk - 1;   // ... of its last row
+      const int klim = causal ? min(rb[j] + c + off, Sk - 1) : Sk - 1;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        const int k0 = 64 * i + 16 * sub;
+        if (k0 > lim_hi) {
+          s[j][sub] = f4{NEGT, NEGT, NEGT, NEGT};
+        } else if (k0 + 15 > lim_lo) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (k0 + 4 * g + r > klim) s[j][sub][r] = NEGT;
+        }
+      }
+    }
+    // online softmax per block, P^T packed for the second product
+    const float thr = (i == 0) ? -1.0e20f : kThr;
+    u4 pb[MQ][2];
+#pragma unroll
+    for (int j = J0; j < MQ; ++j) {
+      // row maximum of the exponent arguments (fma / select results: no canonicalising v_max is needed in front)
+      float mt = __builtin_fmaxf(__builtin_fmaxf(s[j][0][0], s[j][0][1]), s[j][0][2]);
+      mt = __builtin_fmaxf(__builtin_fmaxf(mt, s[j][0][3]), s[j][1][0]);
+      mt = __builtin_fmaxf(__builtin_fmaxf(mt, s[j][1][1]), s[j][1][2]);
+      mt = __builtin_fmaxf(__builtin_fmaxf(mt, s[j][1][3]), s[j][2][0]);
+      mt = __builtin_fmaxf(__builtin_fmaxf(mt, s[j][2][1]), s[j][2][2]);
+      mt = __builtin_fmaxf(__builtin_fmaxf(mt, s[j][2][3]), s[j][3][0]);
+      mt = __builtin_fmaxf(__builtin_fmaxf(mt, s[j][3][1]), s[j][3][2]);
+      mt = __builtin_fmaxf(mt, s[j][3][3]);
+      mt = row_allreduce_max(mt);
+      // Move the reference: always on the first tile (to that tile's maximum, unless every key of it is masked), later
+      // only for rows whose maximum exceeds it by 2^8.  Decided per ROW, so that a row's result depends on its own keys
+      // only (bitwise causality); the wave-uniform branch merely skips the code when no row of the block moves.
+      const bool move = mt > thr;
+      if (__builtin_amdgcn_ballot_w64(move) != 0) {
+        const float delta = move ? mt : 0.0f;
+        mcneg[j] -= delta;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[j][sub][r] -= delta;
+        if (i != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lacc[j][r] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[j][dt][r] *= alpha;
+        }
+      }
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[j][sub][r] = __builtin_amdgcn_exp2f(s[j][sub][r]);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f4 a = s[j][2 * u], bb = s[j][2 * u + 1];
+        if constexpr (IN == IN_BF16) pb[j][u] = u4{pack2_bf16(a[0], a[1]), pack2_bf16(a[2], a[3]), pack2_bf16(bb[0], bb[1]), pack2_bf16(bb[2], bb[3])};
+        else pb[j][u] = u4{pack2_f16(a[0], a[1]), pack2_f16(a[2], a[3]), pack2_f16(bb[0], bb[1]), pack2_f16(bb[2], bb[3])};
+      }
+    }
+    // O^T += V^T P^T and l += 1^T P^T; every V^T fragment is read once and used by all active blocks
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int j = J0; j < MQ; ++j) lacc[j] = mfma16<IN>(ones, pb[j][u], lacc[j]);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const unsigned char* a0 = vaddr[dt] + soff + u * 32 * ROWB;
+        const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0));
+        const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + 16 * ROWB));
+        const u2 l2 = __builtin_bit_cast(u2, lo), h2 = __builtin_bit_cast(u2, hi);
+        const u4 va = u4{l2.x, l2.y, h2.x, h2.y};
+#pragma unroll
+        for (int j = J0; j < MQ; ++j) o[j][dt] = mfma16<IN>(va, pb[j][u], o[j][dt]);
+      }
+    }
+  };
 
   int slot_i = 0;
   for (int i = 0; i < n_kt; ++i) {
@@ -196,110 +330,18 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     barrier_mem();
-    if (i < 14) OEH_STAMP(4 + 2 * i);
+    if (i < 13) OEH_STAMP(4 + 2 * i);
     if (i + 2 < n_kt) issue_next();  // into the stage every wave finished reading one iteration ago
     const int soff = slot_i * STAGEB;
     slot_i = (slot_i == R - 1) ? 0 : slot_i + 1;
-    if (i >= n_kt_wave) continue;    // this wave's rows end before this tile (causal): nothing to compute
-
-    // ---- S^T = K Q^T for the MQ blocks; every K fragment is read once and used MQ times
-    f4 s[MQ][4];
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
-      u4 kf[KS];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const u4*>(kaddr[ks] + soff + sub * 16 * ROWB);
-#pragma unroll
-      for (int j = 0; j < MQ; ++j) {
-        f4 acc = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = mfma16<IN>(kf[ks], qf[j][ks], acc);
-        s[j][sub] = acc;
-      }
+    if (i >= nkb[MQ - 1]) continue;  // this wave's rows end before this tile (causal): nothing to compute
+    if constexpr (MQ == 2) {
+      if (i >= nkb[0]) tile(std::integral_constant<int, 1>{}, i, soff);
+      else tile(std::integral_constant<int, 0>{}, i, soff);
+    } else {
+      tile(std::integral_constant<int, 0>{}, i, soff);
     }
-    // ---- masks
-    if (has_pad) {  // BERT order: scale*s + pad; clamped so a masked score stays a finite, harmless number
-#pragma unroll
-      for (int sub = 0; sub < 4; ++sub) {
-        const int kb = 64 * i + 16 * sub + 4 * g;
-        f4 padv;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) padv[r] = (kb + r < Sk) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + kb + r) : 0.0f;
-#pragma unroll
-        for (int j = 0; j < MQ; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s[j][sub][r] = vmax(__builtin_fmaf(s[j][sub][r], sc, padv[r]), NEG);
-      }
-    }
-    if (i >= tm0) {
-#pragma unroll
-      for (int j = 0; j < MQ; ++j) {
-        const int klim = causal ? min(q0w + 16 * j + c + off, Sk - 1) : Sk - 1;
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (64 * i + 16 * sub + 4 * g + r > klim) s[j][sub][r] = NEG;
-      }
-    }
-    // ---- online softmax per block, P^T packed for the second product
-    u4 pb[MQ][2];
-#pragma unroll
-    for (int j = 0; j < MQ; ++j) {
-      float mt = vmax3(s[j][0][0], s[j][0][1], s[j][0][2]);
-      mt = vmax3(mt, s[j][0][3], s[j][1][0]);
-      mt = vmax3(mt, s[j][1][1], s[j][1][2]);
-      mt = vmax3(mt, s[j][1][3], s[j][2][0]);
-      mt = vmax3(mt, s[j][2][1], s[j][2][2]);
-      mt = vmax3(mt, s[j][2][3], s[j][3][0]);
-      mt = vmax3(mt, s[j][3][1], s[j][3][2]);
-      mt = vmax(mt, s[j][3][3]);
-      mt = row_allreduce_max(mt);
-      // (mt - m_run) * c1 > 8: move the row's reference maximum to mt and rescale its O and l.
-      // Decided per ROW (a row's result depends on its own keys only - bitwise causality); the wave-uniform branch
-      // merely skips the code when no row of the block moves.
-      const bool move = __builtin_fmaf(mt, c1, mcneg[j]) > kThr;
-      if (__builtin_amdgcn_ballot_w64(move) != 0) {
-        const float m_new = move ? mt : m_run[j];
-        const float alpha = __builtin_amdgcn_exp2f((m_run[j] - m_new) * c1);
-        m_run[j] = m_new;
-        mcneg[j] = vmax(m_new, -1.0e20f) * -c1;  // all keys masked so far: exponent -> -huge, p = 0 exactly
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lacc[j][r] = vmul(lacc[j][r], alpha);
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[j][dt][r] = vmul(o[j][dt][r], alpha);
-      }
-      const float mcn = mcneg[j];
-#pragma unroll
-      for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s[j][sub][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][sub][r], c1, mcn));
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const f4 a = s[j][2 * u], bb = s[j][2 * u + 1];
-        if constexpr (IN == IN_BF16) pb[j][u] = u4{pack2_bf16(a[0], a[1]), pack2_bf16(a[2], a[3]), pack2_bf16(bb[0], bb[1]), pack2_bf16(bb[2], bb[3])};
-        else pb[j][u] = u4{pack2_f16(a[0], a[1]), pack2_f16(a[2], a[3]), pack2_f16(bb[0], bb[1]), pack2_f16(bb[2], bb[3])};
-      }
-    }
-    // ---- O^T += V^T P^T and l += 1^T P^T; every V^T fragment is read once and used MQ times
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-#pragma unroll
-      for (int j = 0; j < MQ; ++j) lacc[j] = mfma16<IN>(ones, pb[j][u], lacc[j]);
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const unsigned char* a0 = vaddr[dt] + soff + u * 32 * ROWB;
-        const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0));
-        const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + 16 * ROWB));
-        const u2 l2 = __builtin_bit_cast(u2, lo), h2 = __builtin_bit_cast(u2, hi);
-        const u4 va = u4{l2.x, l2.y, h2.x, h2.y};
-#pragma unroll
-        for (int j = 0; j < MQ; ++j) o[j][dt] = mfma16<IN>(va, pb[j][u], o[j][dt]);
-      }
-    }
-    if (i < 14) OEH_STAMP(5 + 2 * i);
+    if (i < 13) OEH_STAMP(5 + 2 * i);
   }
   OEH_STAMP(2);
 
@@ -310,10 +352,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   unsigned char* ebase = lds + (n_kt % R) * STAGEB + wave * (16 * MQ * ROWB);
 #pragma unroll
   for (int j = 0; j < MQ; ++j) {
-    const int qrow = q0w + 16 * j + c;
-    const float m_true = has_pad ? m_run[j] : m_run[j] * sc;
+    const int qrow = rb[j] + c;
     float den = lacc[j][0];
-    if (P.base != 0) den = den + exp_acc(m_true * -1.0f);  // softmax_1: + 1*exp(-m)  (vutils/softmax_1.py:18-20)
+    if (P.base != 0) den = den + __builtin_amdgcn_exp2f(mcneg[j]);  // softmax_1: + 1*exp(-reference)  (vutils/softmax_1.py:18-20)
     float rowscale = 1.0f / den;
     if (P.gate != nullptr && qrow < Sq) rowscale = rowscale * P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
 #pragma unroll
@@ -333,26 +374,29 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   {
     unsigned short* obase = reinterpret_cast<unsigned short*>(P.o) + (long)b * P.os_b + (long)h * P.os_h;
     const int lr = lane / CPR, lc = lane % CPR;
+    static_assert(16 % RPP == 0, "a store pass stays inside one query block");
 #pragma unroll
     for (int pass = 0; pass < (16 * MQ) / RPP; ++pass) {
-      const int row = pass * RPP + lr;
+      const int row = pass * RPP + lr;                            // row of the wave's staging area
+      const int grow = rb[(pass * RPP) / 16] + (pass * RPP) % 16 + lr;  // its query row
       const u4 w = *reinterpret_cast<const u4*>(ebase + row * ROWB + ((lc ^ (row & XM)) << 4));
-      if (q0w + row < Sq) *reinterpret_cast<u4*>(obase + (long)(q0w + row) * P.os_s + lc * 8) = w;
+      if (grow < Sq) *reinterpret_cast<u4*>(obase + (long)grow * P.os_s + lc * 8) = w;
     }
   }
   OEH_STAMP(3);
+  if (stamp != nullptr && lane == 0) stamp[31] = __builtin_amdgcn_s_memrealtime();
 }
 #undef OEH_STAMP
 
 template <int D, int MQ>
 static int launch_flash_d_mq(const AttnParams& P, int in, hipStream_t st) {
   const unsigned grid = (unsigned)(P.nQT * P.nBHpad);
-  if (in == IN_BF16) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN_BF16, MQ>), dim3(grid), dim3(256), (size_t)P.dbg_lds_pad, st, P);
-  else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN_F16, MQ>), dim3(grid), dim3(256), (size_t)P.dbg_lds_pad, st, P);
+  if (in == IN_BF16) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN_BF16, MQ>), dim3(grid), dim3(256), 0, st, P);
+  else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN_F16, MQ>), dim3(grid), dim3(256), 0, st, P);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-// P.nQT must be ceil(Sq / (64*MQ)); MQ is chosen by the host (oeh_api.hip: flash_mq)
+// P.nQT (workgroups per head), P.pair and P.nSlab are set by the host for the chosen MQ (oeh_api.hip: flash geometry)
 template <int D>
 static int launch_flash_d(const AttnParams& P, int in, int mq, hipStream_t st) {
   if (mq == 1) return launch_flash_d_mq<D, 1>(P, in, st);

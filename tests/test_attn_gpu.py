@@ -290,3 +290,45 @@ def test_full_size_properties(ops):
     for (b, h) in ((0, 0), (15, 11)):
         want = O.attn_core(_np32(q[b:b + 1, h:h + 1]), _np32(k[b:b + 1, h:h + 1]), _np32(v[b:b + 1, h:h + 1]), causal=True, clamp_min=True)
         _check(out[b:b + 1, h:h + 1], want, msg=f"slice {(b, h)}")
+
+
+@pytest.mark.parametrize("mq", [1, 2])
+def test_one_pass_kernel_geometries(ops, mq):
+    """The one-pass kernel (flash16) at both workgroup shapes, forced through the library's diagnostic hook: causal
+    slab pairing with even / odd / ragged slab counts, a key/value cache offset, rows longer than the full-row
+    kernel's 512-key limit, left- and right-padded key masks (softmax_1), bf16, D in {32, 128}."""
+    from outeffhop_amd import _lib
+
+    lib = _lib.load()
+    fmin = float(np.finfo(np.float32).min)
+    lib.oeh_debug_set_variant(256, mq)  # one-pass also for short rows; mq query blocks per wave
+    try:
+        cases = [  # (B, H, Sq, Sk, D, causal, softmax, pad?, dtype)
+            (1, 2, 512, 512, 64, True, "softmax1", False, torch.float16),
+            (1, 2, 320, 320, 64, True, "vanilla", False, torch.float16),   # 5 slabs: middle workgroup has one block
+            (2, 1, 200, 200, 64, True, "softmax1", False, torch.float16),  # ragged last slab
+            (1, 2, 192, 448, 64, True, "softmax1", False, torch.float16),  # kv-cache offset
+            (1, 1, 70, 900, 64, False, "vanilla", False, torch.float16),   # Sk > 512, cross attention
+            (1, 2, 130, 130, 32, True, "softmax1", False, torch.bfloat16),
+            (1, 1, 150, 150, 128, True, "vanilla", False, torch.float16),
+            (3, 2, 260, 260, 64, False, "softmax1", True, torch.float16),
+        ]
+        for n, (B, H, Sq, Sk, D, causal, sm, pad, dt) in enumerate(cases):
+            assert ops.attn_variant(B, H, Sq, Sk, D, dt).startswith(f"flash16/MQ{mq}/")
+            q = _rand((B, H, Sq, D), 900 + n, dtype=dt)
+            k, v = _rand((B, H, Sk, D), 920 + n, dtype=dt), _rand((B, H, Sk, D), 940 + n, dtype=dt)
+            padm = None
+            if pad:
+                padm = np.zeros((B, Sk), dtype=np.float32)
+                padm[0, 200:] = fmin   # right padding
+                padm[1, :70] = fmin    # left padding: the first 64-key tile is fully masked
+                padm[2, :] = fmin      # everything masked: softmax_1 row must be exactly 0
+            want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=D ** -0.5, causal=causal, clamp_min=causal, pad_mask=padm, **SPECS[sm])
+            got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=_spec(ops, sm), scale=D ** -0.5, causal=causal, clamp_min=causal,
+                               key_pad_mask=None if padm is None else torch.from_numpy(padm).cuda(), mask_min=fmin)
+            tol = F16_TOL if dt == torch.float16 else dict(atol=2e-2, rtol=2e-2)
+            _check(got, want, tol=tol, msg=f"case {n} mq={mq}")
+            if pad:
+                assert float(got[2].abs().max()) == 0.0
+    finally:
+        lib.oeh_debug_set_variant(0, 0)

@@ -2,9 +2,9 @@
 """Kernel micro-benchmark (GPU box): mean launch time of oeh_attn_fwd for a list of shapes / options,
 rotating over enough buffer sets to exceed the 256 MiB Infinity Cache.  Usage:
     python tools/microbench.py "B=16,H=12,S=512,D=64,causal=1" "B=32,H=12,S=128,D=64,pad=1" ...
-keys: B H S D causal pad clip int8 dtype(f16|bf16|f32) full iters gate base
-      off (bit mask of kernel variants to disable: 2 = one-pass, 4 = full-row; 256 = one-pass also for Sk <= 128)
-      ldspad (KiB of extra dynamic LDS per one-pass workgroup: lowers occupancy)  mq (force one-pass query blocks per wave)
+keys: B H S D causal pad clip int8 dtype(f16|bf16|f32) full iters reps gate base
+      off (bit mask of kernel variants to disable: 2 = one-pass, 4 = full-row; 256 = one-pass also for Sk <= 128;
+      512 = no causal slab pairing)  mq (force one-pass query blocks per wave)
 """
 import ctypes as C
 import sys
@@ -18,12 +18,12 @@ from outeffhop_amd import _lib, ops
 
 
 def run(spec):
-    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, ldspad=0)
+    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, reps=1)
     for item in spec.split(","):
         k, v = item.split("=")
         kv[k] = v if k == "dtype" else int(v)
     B, H, S, D = kv["B"], kv["H"], kv["S"], kv["D"]
-    _lib.load().oeh_debug_set_variant(kv["off"] | (kv["ldspad"] << 16), kv["mq"])
+    _lib.load().oeh_debug_set_variant(kv["off"], kv["mq"])
     dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[kv["dtype"]]
     eb = 4 if dt == torch.float32 else 2
     per_set = 4 * B * H * S * D * eb
@@ -60,16 +60,19 @@ def run(spec):
     for i in range(10):
         calls[i % nsets](stream)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = kv["iters"]
-    e0.record()
-    for i in range(n):
-        calls[i % nsets](stream)
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / n
+    samples = []
+    for _ in range(max(1, kv["reps"])):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(n):
+            calls[i % nsets](stream)
+        e1.record()
+        torch.cuda.synchronize()
+        samples.append(e0.elapsed_time(e1) * 1e3 / n)
+    us = float(np.median(samples))  # reps > 1: median of the repeats (boxes and clocks wander by a few %)
     alg = per_set
-    var = ops.attn_variant(B, H, S, S, D, dt, fq=bool(kv["int8"]))
+    var = ops.attn_variant(B, H, S, S, D, dt, fq=bool(kv["int8"]), clip=bool(kv["clip"]))
     print(f"{spec:60s} {us:8.2f} us  {alg / us / 1e3:8.1f} GB/s alg  frac {alg / us / 1e3 / 8000:.3f}  "
           f"{4 * B * H * S * S * D / us / 1e6:7.1f} TF(dense)  sets={nsets}  [{var}]", flush=True)
 

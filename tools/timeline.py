@@ -11,8 +11,8 @@ import torch
 
 from outeffhop_amd import _lib, ops
 
-B, H, S, D = 16, 12, 512, 64
 causal = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+B, H, S, D = (int(sys.argv[2]) if len(sys.argv) > 2 else 16), 12, 512, 64
 lib = _lib.load()
 lib.oeh_debug_set_stamps.argtypes = [C.c_void_p]
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -22,7 +22,7 @@ v = torch.randn(B, S, H * D, device="cuda", generator=g).half().view(B, S, H, D)
 kw = dict(causal=bool(causal), clamp_min=bool(causal), mask_min=float(np.finfo(np.float32).min))
 for _ in range(3):
     ops.attn_fwd(q, k, v, **kw)
-nwg = 768
+nwg = 4 * B * H
 buf = torch.zeros(nwg * 4 * 32, dtype=torch.int64, device="cuda")
 lib.oeh_debug_set_stamps(C.c_void_p(buf.data_ptr()))
 ops.attn_fwd(q, k, v, **kw)
@@ -31,7 +31,7 @@ lib.oeh_debug_set_stamps(C.c_void_p(0))
 st = buf.cpu().numpy().reshape(nwg, 4, 32).astype(np.int64)
 names = ["start", "prologue", "loopdone", "end"] + [f"{a}{i}" for i in range(14) for a in ("bar", "cmp")]
 order = [0, 1] + list(range(4, 32)) + [2, 3]
-for wg in (0, 100, 300, 500, 767):   # block ids: heaviest q tiles first
+for wg in (0, nwg // 3, nwg - 1):   # block ids: heaviest q tiles first
     w0 = st[wg, :, 0].min()
     print(f"--- workgroup {wg}: s_memtime ticks since its first wave started")
     for w in range(4):
@@ -39,8 +39,15 @@ for wg in (0, 100, 300, 500, 767):   # block ids: heaviest q tiles first
         print(f" wave {w}: " + " ".join(f"{names[i]}={int(row[i] - w0)}" for i in order if row[i]))
 dur = st[:, :, 3].max(axis=1) - st[:, :, 0].min(axis=1)
 print("per-WG duration ticks: min/median/max", int(dur.min()), int(np.median(dur)), int(dur.max()))
-t0 = st[:, :, 0].min()
-print("kernel span ticks (first start .. last end):", int(st[:, :, 3].max() - t0))
+# s_memrealtime (100 MHz) at start / end of every wave: real-time picture of the launch
+rs, re = st[:, :, 30].min(axis=1), st[:, :, 31].max(axis=1)
+r0 = rs.min()
+print(f"real time: kernel span {(re.max() - r0) * 10} ns; WG start offsets min/median/max {(rs.min() - r0) * 10}/{int(np.median(rs - r0)) * 10}/{(rs.max() - r0) * 10} ns")
+clk = dur / np.maximum(re - rs, 1) / 10.0  # ticks per ns = GHz
+print(f"in-kernel clock (ticks / real time) median {np.median(clk):.2f} GHz")
 for qt in range(4):
-    sel = slice((3 - qt) * 192, (4 - qt) * 192)
-    print(f" q tile {qt}: median WG duration {int(np.median(dur[sel]))} ticks, median start {int(np.median(st[sel, :, 0].min(axis=1) - t0))}")
+    sel = slice((3 - qt) * B * H, (4 - qt) * B * H)
+    print(f" q tile {qt}: median WG duration {int(np.median(dur[sel]))} ticks = {int(np.median((re - rs)[sel])) * 10} ns, "
+          f"median start +{int(np.median(rs[sel] - r0)) * 10} ns, median end +{int(np.median(re[sel] - r0)) * 10} ns, last end +{int((re[sel] - r0).max()) * 10} ns")
+pro = (st[:, :, 1] - st[:, :, 0]).max(axis=1)
+print("prologue ticks (start -> Q landed) min/median/max:", int(pro.min()), int(np.median(pro)), int(pro.max()))
