@@ -76,19 +76,20 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   const int causal = P.causal;
 
   // ---- query blocks of this wave: rb[j] = first row of block j, nkb[j] = 64-key tiles it needs (nkb[0] <= nkb[MQ-1])
-  int rb[MQ], nkb[MQ];
-  int last_row_wg;                      // last query row of the workgroup (bounds the tiles it streams)
+  // block j of wave w = rows 64*slab[j] + 16*w .. +15: the workgroup's Q is MQ 64-row slabs, each one K-shaped LDS tile
+  int slab[MQ], rb[MQ], nkb[MQ];
   if (MQ == 2 && P.pair) {
-    const int lo = qt_rev, hi = P.nSlab - 1 - qt_rev;
-    rb[0] = (lo == hi) ? -1 : 64 * lo + 16 * wave;  // odd slab count: the middle workgroup has one block only
-    rb[MQ - 1] = 64 * hi + 16 * wave;
-    last_row_wg = 64 * hi + 63;
+    slab[0] = qt_rev;
+    slab[MQ - 1] = P.nSlab - 1 - qt_rev;
   } else {
     const int qt = P.nQT - 1 - qt_rev;  // heaviest causal tiles first
 #pragma unroll
-    for (int j = 0; j < MQ; ++j) rb[j] = qt * QROWS + wave * (16 * MQ) + 16 * j;
-    last_row_wg = qt * QROWS + QROWS - 1;
+    for (int j = 0; j < MQ; ++j) slab[j] = qt * MQ + j;
   }
+  const int last_row_wg = 64 * slab[MQ - 1] + 63;  // last query row of the workgroup (bounds the tiles it streams)
+#pragma unroll
+  for (int j = 0; j < MQ; ++j) rb[j] = 64 * slab[j] + 16 * wave;
+  if (MQ == 2 && slab[0] == slab[MQ - 1]) rb[0] = -1;  // odd slab count: the middle workgroup has one block only
   const int n_kt = ((causal ? min(Sk, max(0, last_row_wg + 1 + off)) : Sk) + 63) >> 6;  // tiles the workgroup streams
   int tm0[MQ];                          // first tile that holds a masked key for the block's first row
 #pragma unroll
@@ -144,29 +145,37 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
     ++nx_tile;
     nx_slot = (nx_slot == R - 1) ? 0 : nx_slot + 1;
   };
-  issue_next();
-  if (1 < n_kt) issue_next();
-
-  // ---- Q^T operands of this wave's query blocks.  Q goes out AFTER the first two stages (one exposed memory
-  // latency, not two) and is consumed here, before the loop: the compiler's own wait for these loads must not land
-  // inside the DMA stream, where it would drain the ring.
-  u4 qf[MQ][KS];
+  // ---- Q rides the same LDS-DMA stream, FIRST, into the stage the ring does not use yet (slab j as a K-shaped tile at
+  // j*TILEB of stage R-1).  The bytes a workgroup needs before its first MFMA are then Q + K tile 0; with Q as ordinary
+  // register loads behind the first two stages (returns are in issue order) they were Q + 2 K tiles + 2 V tiles, and the
+  // measured start-up is paced by bytes per CU (~20 B/cycle), not by one memory latency.
+  {
+    const unsigned short* qbase = reinterpret_cast<const unsigned short*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h;
+    const unsigned qslot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((R - 1) * STAGEB + wave * G * 1024));
 #pragma unroll
-  for (int j = 0; j < MQ; ++j) {
-    const int qrow = rb[j] + c;
-    const long qoff = (long)b * P.qs_b + (long)h * P.qs_h + (long)qrow * P.qs_s;
+    for (int t = 0; t < MQ; ++t) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      qf[j][ks] = u4{0, 0, 0, 0};
-      if (qrow < Sq) qf[j][ks] = load8_as16<IN>(P.q, qoff + ks * 32 + 8 * g);
+      for (int j = 0; j < G; ++j) {
+        const int row = piece_row(j);
+        int qrow = 64 * slab[t] + row;
+        qrow = qrow < Sq ? qrow : Sq - 1;  // rows past Sq: finite data, never stored
+        glds16(qbase + (long)qrow * P.qs_s + (pch ^ swz_k<D>(row)) * 8, qslot + t * TILEB + j * 1024);
+      }
     }
   }
-#pragma unroll
-  for (int j = 0; j < MQ; ++j)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      asm volatile("" : "+v"(qf[j][ks].x), "+v"(qf[j][ks].y), "+v"(qf[j][ks].z), "+v"(qf[j][ks].w));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  issue_next();
+  if (1 < n_kt) issue_next();
+  // Q landed (all but the 2 x 2G younger transfers of stages 0 and 1), for every wave
+  if (1 < n_kt) {
+    if constexpr (G == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (G == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  } else {
+    if constexpr (G == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (G == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  }
+  barrier_mem();
   OEH_STAMP(1);
 
   // lane-constant parts of the LDS fragment addresses
@@ -177,6 +186,15 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   const unsigned char* vaddr[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) vaddr[dt] = lds + TILEB + vrow * ROWB + ((dt ^ swz_v<D>(vrow)) << 5) + ((c & 3) << 3);
+
+  // Q^T operands from the Q stage; read complete before the first loop barrier, after which the stage is refilled
+  u4 qf[MQ][KS];
+#pragma unroll
+  for (int j = 0; j < MQ; ++j)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      qf[j][ks] = *reinterpret_cast<const u4*>(kaddr[ks] + (R - 1) * STAGEB + j * TILEB + wave * 16 * ROWB);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   const bool has_pad = P.pad != nullptr;
   const float sc = P.scale;
@@ -330,8 +348,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     barrier_mem();
-    if (i < 13) OEH_STAMP(4 + 2 * i);
+    if (i < 8) OEH_STAMP(4 + 3 * i);
     if (i + 2 < n_kt) issue_next();  // into the stage every wave finished reading one iteration ago
+    if (i < 8) OEH_STAMP(5 + 3 * i);
     const int soff = slot_i * STAGEB;
     slot_i = (slot_i == R - 1) ? 0 : slot_i + 1;
     if (i >= nkb[MQ - 1]) continue;  // this wave's rows end before this tile (causal): nothing to compute
@@ -341,7 +360,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
     } else {
       tile(std::integral_constant<int, 0>{}, i, soff);
     }
-    if (i < 13) OEH_STAMP(5 + 2 * i);
+    if (i < 8) OEH_STAMP(6 + 3 * i);
   }
   OEH_STAMP(2);
 

@@ -11,9 +11,10 @@ import torch
 
 from outeffhop_amd import _lib, ops
 
-causal = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-B, H, S, D = (int(sys.argv[2]) if len(sys.argv) > 2 else 16), 12, 512, 64
 lib = _lib.load()
+causal = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+B, H, S, D = (int(sys.argv[2]) if len(sys.argv) > 2 else 16), 12, (int(sys.argv[3]) if len(sys.argv) > 3 else 512), 64
+lib.oeh_debug_set_variant(256 | (int(sys.argv[4]) if len(sys.argv) > 4 else 0), 2)
 lib.oeh_debug_set_stamps.argtypes = [C.c_void_p]
 g = torch.Generator(device="cuda").manual_seed(0)
 q = (torch.randn(B, S, H * D, device="cuda", generator=g) * D ** -0.5).half().view(B, S, H, D).permute(0, 2, 1, 3)
@@ -22,15 +23,16 @@ v = torch.randn(B, S, H * D, device="cuda", generator=g).half().view(B, S, H, D)
 kw = dict(causal=bool(causal), clamp_min=bool(causal), mask_min=float(np.finfo(np.float32).min))
 for _ in range(3):
     ops.attn_fwd(q, k, v, **kw)
-nwg = 4 * B * H
+nqt = (S + 127) // 128
+nwg = nqt * B * H
 buf = torch.zeros(nwg * 4 * 32, dtype=torch.int64, device="cuda")
 lib.oeh_debug_set_stamps(C.c_void_p(buf.data_ptr()))
 ops.attn_fwd(q, k, v, **kw)
 torch.cuda.synchronize()
 lib.oeh_debug_set_stamps(C.c_void_p(0))
 st = buf.cpu().numpy().reshape(nwg, 4, 32).astype(np.int64)
-names = ["start", "prologue", "loopdone", "end"] + [f"{a}{i}" for i in range(14) for a in ("bar", "cmp")]
-order = [0, 1] + list(range(4, 32)) + [2, 3]
+names = ["start", "prologue", "loopdone", "end"] + [f"{a}{i}" for i in range(8) for a in ("bar", "iss", "cmp")]
+order = [0, 1] + list(range(4, 28)) + [2, 3]
 for wg in (0, nwg // 3, nwg - 1):   # block ids: heaviest q tiles first
     w0 = st[wg, :, 0].min()
     print(f"--- workgroup {wg}: s_memtime ticks since its first wave started")
@@ -45,8 +47,8 @@ r0 = rs.min()
 print(f"real time: kernel span {(re.max() - r0) * 10} ns; WG start offsets min/median/max {(rs.min() - r0) * 10}/{int(np.median(rs - r0)) * 10}/{(rs.max() - r0) * 10} ns")
 clk = dur / np.maximum(re - rs, 1) / 10.0  # ticks per ns = GHz
 print(f"in-kernel clock (ticks / real time) median {np.median(clk):.2f} GHz")
-for qt in range(4):
-    sel = slice((3 - qt) * B * H, (4 - qt) * B * H)
+for qt in range(nqt):
+    sel = slice((nqt - 1 - qt) * B * H, (nqt - qt) * B * H)
     print(f" q tile {qt}: median WG duration {int(np.median(dur[sel]))} ticks = {int(np.median((re - rs)[sel])) * 10} ns, "
           f"median start +{int(np.median(rs[sel] - r0)) * 10} ns, median end +{int(np.median(re[sel] - r0)) * 10} ns, last end +{int((re[sel] - r0).max()) * 10} ns")
 pro = (st[:, :, 1] - st[:, :, 0]).max(axis=1)
