@@ -95,7 +95,6 @@ bool fast_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
 }
 
 int g_force_flash = 0;                   // tools/microbench.py only
-int g_no_pair = 0;                       // tools/microbench.py only
 
 // The one-pass kernel (oeh_attn_flash.inl) additionally needs the plain softmax_n (no clip) and, with key padding,
 // softmax_1 (a fully padded row is 0 there; under vanilla softmax it is uniform over all keys, which a one-pass
@@ -203,11 +202,6 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
     if (desc->scale_div != 0.0f) { P.scale = 1.0f / desc->scale_div; P.scale_div = 0.0f; }  // exact: power of two
     const int mq = flash_mq(desc);
     P.nQT = (desc->Sq + 64 * mq - 1) / (64 * mq);
-    if (mq == 2 && desc->causal && !g_no_pair) {  // causal balancing (oeh_attn_flash.inl): slabs a and nSlab-1-a per workgroup
-      P.pair = 1;
-      P.nSlab = (desc->Sq + 63) / 64;
-      P.nQT = (P.nSlab + 1) / 2;
-    }
     switch (desc->D) {
       case 32: return oeh::launch_attn_flash_d32(P, desc->dtype, mq, st);
       case 64: return oeh::launch_attn_flash_d64(P, desc->dtype, mq, st);
@@ -277,7 +271,7 @@ int oeh_minmax(const void* x, int64_t n, int32_t dtype, float* out2, void* strea
 // Diagnostic hook (not part of the ABI in include/oeh.h): device buffer of 16 u64 per wave that the resident kernel
 // fills with s_memtime stamps when non-null.  Used by tools/timeline.py only.
 void oeh_debug_set_variant(int off_mask, int flash_mq_force) {
-  g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_no_pair = (off_mask >> 9) & 1; g_flash_mq = flash_mq_force;
+  g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force;
 }
 void oeh_debug_set_stamps(void* device_buffer) { g_stamps = static_cast<unsigned long long*>(device_buffer); }
 

@@ -17,10 +17,6 @@
 //     uses, and frees 16 v_add per block and tile - the loop is VALU-issue bound, not MFMA bound);
 //   * lazy reference: it moves only when a row's tile maximum exceeds it by 2^8, so the O/l rescale (20 multiplies per
 //     block) almost never runs after the first tiles;
-//   * causal BALANCING (P.pair): query rows are cut into 64-row slabs and workgroup a of a head takes slab a AND slab
-//     N-1-a, 16 rows of each per wave.  Every workgroup then has the same number of (block x tile) products, all
-//     co-resident workgroups stay busy to the end (a lone wave per SIMD runs the loop 2.5x slower per tile than three
-//     sharing it), and the kernel no longer ends on the heavy last-rows workgroups.
 // Same swapped products (S^T = K Q^T, O^T = V^T P^T on v_mfma_f32_16x16x32), LDS images, swizzles and LDS-DMA ring
 // as the full-row kernel.  Masks: none | analytic causal | key padding (softmax_1 only: a fully masked row must be 0).
 #pragma once
@@ -78,28 +74,18 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   // ---- query blocks of this wave: rb[j] = first row of block j, nkb[j] = 64-key tiles it needs (nkb[0] <= nkb[MQ-1])
   // block j of wave w = rows 64*slab[j] + 16*w .. +15: the workgroup's Q is MQ 64-row slabs, each one K-shaped LDS tile
   int slab[MQ], rb[MQ], nkb[MQ];
-  if (MQ == 2 && P.pair) {
-    slab[0] = qt_rev;
-    slab[MQ - 1] = P.nSlab - 1 - qt_rev;
-  } else {
-    const int qt = P.nQT - 1 - qt_rev;  // heaviest causal tiles first
+  const int qt = P.nQT - 1 - qt_rev;    // heaviest causal tiles first
 #pragma unroll
-    for (int j = 0; j < MQ; ++j) slab[j] = qt * MQ + j;
+  for (int j = 0; j < MQ; ++j) {
+    slab[j] = qt * MQ + j;
+    rb[j] = 64 * slab[j] + 16 * wave;
   }
   const int last_row_wg = 64 * slab[MQ - 1] + 63;  // last query row of the workgroup (bounds the tiles it streams)
-#pragma unroll
-  for (int j = 0; j < MQ; ++j) rb[j] = 64 * slab[j] + 16 * wave;
-  if (MQ == 2 && slab[0] == slab[MQ - 1]) rb[0] = -1;  // odd slab count: the middle workgroup has one block only
   const int n_kt = ((causal ? min(Sk, max(0, last_row_wg + 1 + off)) : Sk) + 63) >> 6;  // tiles the workgroup streams
   int tm0[MQ];                          // first tile that holds a masked key for the block's first row
 #pragma unroll
   for (int j = 0; j < MQ; ++j) {
-    if (rb[j] < 0) {
-      rb[j] = (Sq + 15) & ~15;          // disabled block: rows >= Sq are neither loaded nor stored
-      nkb[j] = 0;
-    } else {
-      nkb[j] = ((causal ? min(Sk, max(0, rb[j] + 16 + off)) : Sk) + 63) >> 6;
-    }
+    nkb[j] = ((causal ? min(Sk, max(0, rb[j] + 16 + off)) : Sk) + 63) >> 6;
     tm0[j] = ((causal ? min(rb[j] + off, Sk - 1) : Sk - 1) + 1) >> 6;
   }
 
@@ -415,7 +401,7 @@ static int launch_flash_d_mq(const AttnParams& P, int in, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-// P.nQT (workgroups per head), P.pair and P.nSlab are set by the host for the chosen MQ (oeh_api.hip: flash geometry)
+// P.nQT = ceil(Sq / (64*MQ)) workgroups per head; MQ is chosen by the host (oeh_api.hip: flash_mq)
 template <int D>
 static int launch_flash_d(const AttnParams& P, int in, int mq, hipStream_t st) {
   if (mq == 1) return launch_flash_d_mq<D, 1>(P, in, st);

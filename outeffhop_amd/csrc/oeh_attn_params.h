@@ -33,7 +33,6 @@ struct AttnParams {
   // launch geometry
   int nQT;                    // q tiles (64 rows) per (b,h)
   int nBH, nBHpad;            // B*H and B*H rounded up to a multiple of 8 (XCD affinity of a head's q tiles)
-  int pair, nSlab;            // one-pass kernel, causal balancing: workgroup a takes 64-row slabs a and nSlab-1-a
   int skip_ok;                // causal tiles above the diagonal may be skipped (see oeh_api.hip)
   unsigned long long* stamps; // diagnostic builds only: per-wave s_memtime stamps (null in production)
 };

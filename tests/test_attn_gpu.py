@@ -295,7 +295,7 @@ def test_full_size_properties(ops):
 @pytest.mark.parametrize("mq", [1, 2])
 def test_one_pass_kernel_geometries(ops, mq):
     """The one-pass kernel (flash16) at both workgroup shapes, forced through the library's diagnostic hook: causal
-    slab pairing with even / odd / ragged slab counts, a key/value cache offset, rows longer than the full-row
+    rows with even / odd / ragged 64-row slab counts, a key/value cache offset, rows longer than the full-row
     kernel's 512-key limit, left- and right-padded key masks (softmax_1), bf16, D in {32, 128}."""
     from outeffhop_amd import _lib
 
@@ -305,7 +305,7 @@ def test_one_pass_kernel_geometries(ops, mq):
     try:
         cases = [  # (B, H, Sq, Sk, D, causal, softmax, pad?, dtype)
             (1, 2, 512, 512, 64, True, "softmax1", False, torch.float16),
-            (1, 2, 320, 320, 64, True, "vanilla", False, torch.float16),   # 5 slabs: middle workgroup has one block
+            (1, 2, 320, 320, 64, True, "vanilla", False, torch.float16),   # 5 slabs: the last workgroup has one block
             (2, 1, 200, 200, 64, True, "softmax1", False, torch.float16),  # ragged last slab
             (1, 2, 192, 448, 64, True, "softmax1", False, torch.float16),  # kv-cache offset
             (1, 1, 70, 900, 64, False, "vanilla", False, torch.float16),   # Sk > 512, cross attention
