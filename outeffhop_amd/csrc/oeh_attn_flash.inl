@@ -272,13 +272,13 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
       mt = __builtin_fmaxf(__builtin_fmaxf(mt, s[j][2][3]), s[j][3][0]);
       mt = __builtin_fmaxf(__builtin_fmaxf(mt, s[j][3][1]), s[j][3][2]);
       mt = __builtin_fmaxf(mt, s[j][3][3]);
-      mt = row_allreduce_max(mt);
-      // Move the reference: always on the first tile (to that tile's maximum, unless every key of it is masked), later
-      // only for rows whose maximum exceeds it by 2^8.  Decided per ROW, so that a row's result depends on its own keys
-      // only (bitwise causality); the wave-uniform branch merely skips the code when no row of the block moves.
-      const bool move = mt > thr;
-      if (__builtin_amdgcn_ballot_w64(move) != 0) {
-        const float delta = move ? mt : 0.0f;
+      // Move the reference: always on the first tile (to that tile's row maximum, unless every key of it is masked),
+      // later only for rows whose maximum exceeds it by 2^8.  The common case is decided on the LANE maxima (no cross-lane
+      // step); the row maximum is formed only when some row moves.  Decided per ROW, so that a row's result depends on
+      // its own keys only (bitwise causality); the wave-uniform branch merely skips the code when no row moves.
+      if (__builtin_amdgcn_ballot_w64(mt > thr) != 0) {
+        mt = row_allreduce_max(mt);
+        const float delta = (mt > thr) ? mt : 0.0f;
         mcneg[j] -= delta;
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub)
