@@ -199,6 +199,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed clock ramp before the W warm-up steps: a GPU coming out of idle needs tens of ms of work to reach its
+    # sustained clocks, and W steps of a 10 us kernel are 2 ms (seen as a 3x slow BERT-sized run right after process start).
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.25:
+        step()
+        torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
