@@ -37,7 +37,7 @@ __device__ __forceinline__ float row_allreduce_max(float x) {
 template <int D, int MQ>
 constexpr int flash_occupancy() { return D >= 128 ? 2 : (MQ >= 4 ? 2 : 3); }
 
-template <int D, int IN, int MQ>
+template <int D, int IN, int MQ, bool PAD>
 __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flash_kernel(const AttnParams P) {
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
   static_assert(MQ == 1 || MQ == 2, "one or two query blocks per wave");
@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
       qf[j][ks] = *reinterpret_cast<const u4*>(kaddr[ks] + (R - 1) * STAGEB + j * TILEB + wave * 16 * ROWB);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-  const bool has_pad = P.pad != nullptr;
+  constexpr bool has_pad = PAD;         // a kernel variant, not a branch: merging the two paths inside the loop costs a
+                                        // register-to-register copy of the whole score tile on the path without padding
   const float sc = P.scale;
   const float c1 = has_pad ? kLog2e : sc * kLog2e;   // pad mode keeps scaled+masked scores, otherwise raw dot products
   const u4 ones = (IN == IN_BF16) ? u4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
       }
     }
     // exponent arguments t = (s - reference) * log2e  [key padding: BERT order scale*s + pad first]
-    if (has_pad) {
+    if constexpr (has_pad) {
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
         const int kb = 64 * i + 16 * sub + 4 * g;
@@ -396,8 +397,14 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
 template <int D, int MQ>
 static int launch_flash_d_mq(const AttnParams& P, int in, hipStream_t st) {
   const unsigned grid = (unsigned)(P.nQT * P.nBHpad);
-  if (in == IN_BF16) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN_BF16, MQ>), dim3(grid), dim3(256), 0, st, P);
-  else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN_F16, MQ>), dim3(grid), dim3(256), 0, st, P);
+  const bool pad = P.pad != nullptr;
+  if (in == IN_BF16) {
+    if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN_BF16, MQ, true>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN_BF16, MQ, false>), dim3(grid), dim3(256), 0, st, P);
+  } else {
+    if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN_F16, MQ, true>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN_F16, MQ, false>), dim3(grid), dim3(256), 0, st, P);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
