@@ -332,3 +332,53 @@ def test_one_pass_kernel_geometries(ops, mq):
                 assert float(got[2].abs().max()) == 0.0
     finally:
         lib.oeh_debug_set_variant(0, 0)
+
+
+def test_randomised_kernel_sweep(ops):
+    """Seeded random configurations through each 16-bit MFMA kernel that is eligible for them (the library's diagnostic
+    hook disables variants: one-pass, full-row, general), against the oracle.  Shapes are ragged on purpose (Sq, Sk not
+    multiples of 16/64, Sq != Sk with a causal offset), inputs are strided head views, gates and both softmax bases."""
+    from outeffhop_amd import _lib
+
+    lib = _lib.load()
+    fmin = float(np.finfo(np.float32).min)
+    rng = np.random.default_rng(20240607)
+    seen = set()
+    try:
+        for n in range(36):
+            D = int(rng.choice([32, 64, 64, 128]))
+            H = int(rng.integers(1, 4))
+            B = int(rng.integers(1, 4))
+            Sk = int(rng.integers(17, 400))
+            causal = bool(rng.integers(0, 2))
+            Sq = int(rng.integers(max(1, Sk - 150), Sk + 1)) if causal else int(rng.integers(1, 300))
+            sm = ["softmax1", "vanilla"][int(rng.integers(0, 2))]
+            pad = (not causal) and sm == "softmax1" and bool(rng.integers(0, 2))
+            gated = bool(rng.integers(0, 2))
+            dt = [torch.float16, torch.bfloat16][int(rng.integers(0, 4) == 0)]
+            # (B,S,H*D) projections viewed as (B,H,S,D): the strided layout the modules pass
+            q = _rand((B, Sq, H * D), 3000 + n, dtype=dt).view(B, Sq, H, D).permute(0, 2, 1, 3)
+            k = _rand((B, Sk, H * D), 3100 + n, dtype=dt).view(B, Sk, H, D).permute(0, 2, 1, 3)
+            v = _rand((B, Sk, H * D), 3200 + n, dtype=dt).view(B, Sk, H, D).permute(0, 2, 1, 3)
+            padm = None
+            if pad:
+                padm = np.zeros((B, Sk), dtype=np.float32)
+                for b in range(B):
+                    padm[b, int(rng.integers(1, Sk + 1)):] = fmin
+            gate = torch.rand((B, H, Sq, 1), generator=torch.Generator().manual_seed(3300 + n)) if gated else None
+            want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=D ** -0.5, causal=causal, clamp_min=causal, pad_mask=padm,
+                               gate=None if gate is None else gate.numpy(), **SPECS[sm])
+            tol = F16_TOL if dt == torch.float16 else dict(atol=2e-2, rtol=2e-2)
+            for off_mask in (256, 2, 2 | 4):   # one-pass forced; one-pass off (full-row if eligible); both off (general)
+                if off_mask != 256 and Sk > 512:
+                    continue
+                lib.oeh_debug_set_variant(off_mask, 0)
+                var = ops.attn_variant(B, H, Sq, Sk, D, dt)
+                seen.add(var.split("/")[0])
+                got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=_spec(ops, sm), scale=D ** -0.5, causal=causal,
+                                   clamp_min=causal, key_pad_mask=None if padm is None else torch.from_numpy(padm).cuda(),
+                                   gate=None if gate is None else gate.cuda(), mask_min=fmin)
+                _check(got, want, tol=tol, msg=f"cfg {n} {(B, H, Sq, Sk, D, causal, sm, pad, gated, dt)} via {var}")
+    finally:
+        lib.oeh_debug_set_variant(0, 0)
+    assert {"flash16", "fast16", "mfma16"} <= seen

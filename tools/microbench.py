@@ -2,7 +2,7 @@
 """Kernel micro-benchmark (GPU box): mean launch time of oeh_attn_fwd for a list of shapes / options,
 rotating over enough buffer sets to exceed the 256 MiB Infinity Cache.  Usage:
     python tools/microbench.py "B=16,H=12,S=512,D=64,causal=1" "B=32,H=12,S=128,D=64,pad=1" ...
-keys: B H S D causal pad clip int8 dtype(f16|bf16|f32) full iters reps gate base
+keys: B H S D causal pad clip int8 dtype(f16|bf16|f32) full iters reps gate base graph(=launches per captured graph)
       off (bit mask of kernel variants to disable: 2 = one-pass, 4 = full-row; 256 = one-pass also for Sk <= 128)  mq (force one-pass query blocks per wave)
 """
 import ctypes as C
@@ -17,7 +17,7 @@ from outeffhop_amd import _lib, ops
 
 
 def run(spec):
-    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, reps=1)
+    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, reps=1, graph=0)
     for item in spec.split(","):
         k, v = item.split("=")
         kv[k] = v if k == "dtype" else int(v)
@@ -60,12 +60,24 @@ def run(spec):
         calls[i % nsets](stream)
     torch.cuda.synchronize()
     n = kv["iters"]
+    graph = None
+    if kv["graph"]:  # replay a captured graph of `graph` launches instead of launching one by one
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for i in range(kv["graph"]):
+                calls[i % nsets](cs)
+        n = max(1, n // kv["graph"]) * kv["graph"]
     samples = []
     for _ in range(max(1, kv["reps"])):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for i in range(n):
-            calls[i % nsets](stream)
+        if graph is not None:
+            for i in range(n // kv["graph"]):
+                graph.replay()
+        else:
+            for i in range(n):
+                calls[i % nsets](stream)
         e1.record()
         torch.cuda.synchronize()
         samples.append(e0.elapsed_time(e1) * 1e3 / n)
