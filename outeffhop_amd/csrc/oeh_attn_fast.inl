@@ -337,10 +337,18 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
 
   OEH_STAMP(21);
   // =========================== epilogue ===========================
-  if (!qvalid) return;
+  // O^T is scaled in registers, staged through the (idle) K ring - every wave has left the K phase once any wave is
+  // past the V-phase barriers - and stored as whole rows, 16 B per lane, write-through (oeh_common.h: store_wt16).
+  // Each wave owns the 16 rows of its query block in K slot 0: no workgroup barrier.
+  // (addresses are derived from an opaque copy of the lane id so that they are formed HERE, not hoisted above the loops
+  // where the NT=32 variant has no register to spare)
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int ce = lane_e & 15, ge = lane_e >> 4;
   float rowscale = CLIP ? 1.0f : inv;
-  if (P.gate != nullptr) rowscale = rowscale * P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
-  unsigned short* op = reinterpret_cast<unsigned short*>(P.o) + (long)b * P.os_b + (long)h * P.os_h + (long)qrow * P.os_s;
+  if (P.gate != nullptr && qvalid) rowscale = rowscale * P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
+  constexpr int XM = (CPR < 8 ? CPR : 8) - 1;
+  unsigned char* ebase = lds + wave * (16 * ROWB);
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) {
     u2 w;
@@ -351,7 +359,22 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
       w.x = pack2_f16(o[dt][0] * rowscale, o[dt][1] * rowscale);
       w.y = pack2_f16(o[dt][2] * rowscale, o[dt][3] * rowscale);
     }
-    *reinterpret_cast<u2*>(op + 16 * dt + 4 * g) = w;
+    *reinterpret_cast<u2*>(ebase + ce * ROWB + ((((2 * dt + (ge >> 1)) ^ (ce & XM)) << 4) | ((ge & 1) << 3))) = w;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes, before it reads them back
+  {
+    unsigned short* obase = reinterpret_cast<unsigned short*>(P.o) + (long)b * P.os_b + (long)h * P.os_h;
+    const int lr = lane_e / CPR, lc = lane_e % CPR;
+    static_assert(16 % RPP == 0 || RPP % 16 == 0, "store passes tile the 16-row block");
+#pragma unroll
+    for (int pass = 0; pass < (16 + RPP - 1) / RPP; ++pass) {
+      const int row = pass * RPP + lr;
+      if (row < 16) {
+        const u4 w = *reinterpret_cast<const u4*>(ebase + row * ROWB + ((lc ^ (row & XM)) << 4));
+        const int grow = q0 + row;
+        if (grow < P.Sq) store_wt16(obase + (long)grow * P.os_s + lc * 8, w);
+      }
+    }
   }
   OEH_STAMP(22);
 }

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
       const int row = pass * RPP + lr;                            // row of the wave's staging area
       const int grow = rb[(pass * RPP) / 16] + (pass * RPP) % 16 + lr;  // its query row
       const u4 w = *reinterpret_cast<const u4*>(ebase + row * ROWB + ((lc ^ (row & XM)) << 4));
-      if (grow < Sq) *reinterpret_cast<u4*>(obase + (long)grow * P.os_s + lc * 8) = w;
+      if (grow < Sq) store_wt16(obase + (long)grow * P.os_s + lc * 8, w);
     }
   }
   OEH_STAMP(3);

@@ -347,9 +347,9 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
         w.x = pack2_f16(ov[0], ov[1]);
         w.y = pack2_f16(ov[2], ov[3]);
       }
-      *reinterpret_cast<u2*>(reinterpret_cast<unsigned short*>(P.o) + ooff + d0) = w;
+      store_wt8(reinterpret_cast<unsigned short*>(P.o) + ooff + d0, w);
     } else {
-      *reinterpret_cast<f4*>(reinterpret_cast<float*>(P.o) + ooff + d0) = f4{ov[0], ov[1], ov[2], ov[3]};
+      store_wt16(reinterpret_cast<float*>(P.o) + ooff + d0, u4{f32_bits(ov[0]), f32_bits(ov[1]), f32_bits(ov[2]), f32_bits(ov[3])});
     }
     if constexpr (FQ) {
       if (P.fq_c.en && P.fq_c.dump != nullptr) dump4(P.fq_c.dump + (((long)b * P.H + h) * P.Sq + qrow) * D + d0, dump_word, 4);

@@ -133,6 +133,19 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
       : "v"(gsrc), "s"(lds_addr)
       : "memory");
 }
+// Output stores are WRITE-THROUGH (sc0 sc1).  A plain store leaves the line dirty in the XCD's L2; the whole output
+// (12.6 MB per OPT-125m launch, 1.6 MB per XCD: it all fits) then goes to memory in the end-of-kernel release, after
+// the last wave, where nothing overlaps it: measured 18.97 -> 16.2 us per launch on the headline workload (`nt` alone:
+// no change).  Written through, the bytes leave while other workgroups still compute.
+// The trailing s_nop is part of the instruction: a store of more than 64 bits reads its data registers over several
+// cycles and the next VALU write to them needs a wait state that the compiler inserts for its own stores but not after
+// inline asm (seen: every fp32-output row corrupted when the scheduler put the next v_cndmask right behind the store).
+__device__ __forceinline__ void store_wt16(void* dst, u4 w) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
+}
+__device__ __forceinline__ void store_wt8(void* dst, u2 w) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(w) : "memory");
+}
 // Workgroup barrier that is ALSO a compiler barrier for memory operations.  __builtin_amdgcn_s_barrier() is
 // "no memory, has side effects" to LLVM, so with the LDS-DMA hidden in inline asm the compiler may hoist LDS reads
 // of a freshly landed tile above it (seen as wholesale wrong results after an unrelated scheduling change).
