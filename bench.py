@@ -218,6 +218,16 @@ def main():
     t1 = time.perf_counter()
     wall = t1 - t0
     dev_ms = ev0.elapsed_time(ev1)
+    # spread of the per-launch time: 40 separately timed steps after the timed region (reported, never part of `value`)
+    spread = []
+    for _ in range(40):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        step()
+        e1.record()
+        torch.cuda.synchronize()
+        spread.append(e0.elapsed_time(e1) * 1e3 / L)
+    spread.sort()
     if dist is not None:
         tw = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -258,7 +268,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel_us": kern_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
+                "traffic": traffic, "kernel_us": kern_s * 1e6,
+                "kernel_us_p10_p50_p90": [round(spread[4], 2), round(spread[20], 2), round(spread[36], 2)],
+                "algorithmic_bytes_per_launch": alg_bytes,
                 "flops_per_launch": 4 * B * H * S * S * d, "tflops": 4 * B * H * S * S * d / kern_s / 1e12,
             },
         }

@@ -268,8 +268,11 @@ int oeh_minmax(const void* x, int64_t n, int32_t dtype, float* out2, void* strea
   return oeh::launch_minmax(x, n, dtype, out2, reinterpret_cast<hipStream_t>(stream));
 }
 
-// Diagnostic hook (not part of the ABI in include/oeh.h): device buffer of 16 u64 per wave that the resident kernel
-// fills with s_memtime stamps when non-null.  Used by tools/timeline.py only.
+// Diagnostic hooks (NOT part of the ABI in include/oeh.h; process-global, not thread-safe; tools/ and tests only):
+//  oeh_debug_set_variant: bit (1 << Variant) of off_mask disables a kernel variant, bit 8 lets the one-pass kernel take
+//    rows of <= 128 keys too, flash_mq_force != 0 fixes its query blocks per wave (A/B timing, forced-variant tests);
+//  oeh_debug_set_stamps: device buffer of 32 u64 per wave that the one-pass kernel fills with s_memtime /
+//    s_memrealtime stamps when non-null (tools/timeline.py).
 void oeh_debug_set_variant(int off_mask, int flash_mq_force) {
   g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force;
 }

@@ -50,7 +50,6 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   constexpr int KS = D / 32;
   constexpr int DT = D / 16;
   constexpr int R = 3;                  // stages
-  constexpr int QROWS = 64 * MQ;        // query rows per workgroup
   constexpr float NEG = -1.0e30f;       // floor of a padded score (finite: NEG * log2e does not overflow)
   constexpr float NEGT = -1.0e30f;      // exponent argument of a masked key: exp2 -> 0 exactly
   constexpr float kThr = 8.0f;          // lazy reference: P stays <= 2^8 (exact range for f16 / bf16 operands)
@@ -98,36 +97,37 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   OEH_STAMP(0);
   if (stamp != nullptr && lane == 0) stamp[30] = __builtin_amdgcn_s_memrealtime();
 
-  // ---- LDS-DMA stream of (K tile, V tile) stages, strictly in order, position carried incrementally
-  const unsigned short* kbase = reinterpret_cast<const unsigned short*>(P.k) + (long)b * P.ks_b + (long)h * P.ks_h;
-  const unsigned short* vbase = reinterpret_cast<const unsigned short*>(P.v) + (long)b * P.vs_b + (long)h * P.vs_h;
+  // ---- LDS-DMA stream of (K tile, V tile) stages, strictly in order: the scalar base pointers advance by 64 rows per
+  // stage, the per-lane byte offsets (row of the piece, swizzled 16-B chunk) never change
+  const unsigned char* kcur = reinterpret_cast<const unsigned char*>(P.k) + 2 * ((long)b * P.ks_b + (long)h * P.ks_h);
+  const unsigned char* vcur = reinterpret_cast<const unsigned char*>(P.v) + 2 * ((long)b * P.vs_b + (long)h * P.vs_h);
   const int prow = lane / CPR, pch = lane % CPR;
   const unsigned lds_base = lds_offset(lds);
   auto piece_row = [&](int j) { return (wave * G + j) * RPP + prow; };
-  long nx_koff[G], nx_voff[G];
+  unsigned koff[G], voff[G];
 #pragma unroll
   for (int j = 0; j < G; ++j) {
     const int row = piece_row(j);
-    nx_koff[j] = (long)row * P.ks_s + (pch ^ swz_k<D>(row)) * 8;
-    nx_voff[j] = (long)row * P.vs_s + ((((pch >> 1) ^ swz_v<D>(row)) << 1) | (pch & 1)) * 8;
+    koff[j] = 2u * (unsigned)(row * P.ks_s + (pch ^ swz_k<D>(row)) * 8);
+    voff[j] = 2u * (unsigned)(row * P.vs_s + ((((pch >> 1) ^ swz_v<D>(row)) << 1) | (pch & 1)) * 8);
   }
-  const long kstep = 64 * P.ks_s, vstep = 64 * P.vs_s;
+  const long kstep = 128 * P.ks_s, vstep = 128 * P.vs_s;  // bytes per 64 rows
   int nx_tile = 0, nx_slot = 0;
   auto issue_next = [&]() {
     const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(nx_slot * STAGEB + wave * G * 1024));
     const bool tail = nx_tile * 64 + 64 > Sk;  // rows past Sk are redirected to row Sk-1 (finite data, masked later)
 #pragma unroll
     for (int j = 0; j < G; ++j) {
-      long ko = nx_koff[j], vo = nx_voff[j];
+      unsigned ko = koff[j], vo = voff[j];
       if (tail) {
         const int over = nx_tile * 64 + piece_row(j) - (Sk - 1);
-        if (over > 0) { ko -= (long)over * P.ks_s; vo -= (long)over * P.vs_s; }
+        if (over > 0) { ko -= 2u * (unsigned)(over * P.ks_s); vo -= 2u * (unsigned)(over * P.vs_s); }
       }
-      glds16(kbase + ko, slot + j * 1024);
-      glds16(vbase + vo, slot + TILEB + j * 1024);
-      nx_koff[j] += kstep;
-      nx_voff[j] += vstep;
+      glds16_s(kcur, ko, slot + j * 1024);
+      glds16_s(vcur, vo, slot + TILEB + j * 1024);
     }
+    kcur += kstep;
+    vcur += vstep;
     ++nx_tile;
     nx_slot = (nx_slot == R - 1) ? 0 : nx_slot + 1;
   };
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   // register loads behind the first two stages (returns are in issue order) they were Q + 2 K tiles + 2 V tiles, and the
   // measured start-up is paced by bytes per CU (~20 B/cycle), not by one memory latency.
   {
-    const unsigned short* qbase = reinterpret_cast<const unsigned short*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h;
+    const unsigned char* qbase = reinterpret_cast<const unsigned char*>(P.q) + 2 * ((long)b * P.qs_b + (long)h * P.qs_h);
     const unsigned qslot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((R - 1) * STAGEB + wave * G * 1024));
 #pragma unroll
     for (int t = 0; t < MQ; ++t) {
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
         const int row = piece_row(j);
         int qrow = 64 * slab[t] + row;
         qrow = qrow < Sq ? qrow : Sq - 1;  // rows past Sq: finite data, never stored
-        glds16(qbase + (long)qrow * P.qs_s + (pch ^ swz_k<D>(row)) * 8, qslot + t * TILEB + j * 1024);
+        glds16_s(qbase, 2u * (unsigned)(qrow * P.qs_s + (pch ^ swz_k<D>(row)) * 8), qslot + t * TILEB + j * 1024);
       }
     }
   }
@@ -215,7 +215,6 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
 #pragma unroll
       for (int j = J0; j < MQ; ++j) {
         f4 acc = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = mfma16<IN>(kf[ks], qf[j][ks], acc);
         s[j][sub] = acc;
       }
@@ -354,11 +353,16 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   // ---- epilogue: denominators and gate, O^T staged through a free LDS stage so that global stores are whole rows
   // (per-lane stores of the MFMA layout would touch 16 rows x 32 B per instruction).  Stage n_kt % R is free: its
   // last reader was tile n_kt - 3 and no DMA is in flight.  Each wave owns 16*MQ rows of it: no workgroup barrier.
+  // (lane-derived addresses come from an opaque copy of the lane id: formed here, not kept live across the loop where
+  // the MQ=2 variant has no register to spare)
   constexpr int XM = (CPR < 8 ? CPR : 8) - 1;
   unsigned char* ebase = lds + (n_kt % R) * STAGEB + wave * (16 * MQ * ROWB);
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int ce = lane_e & 15, ge = lane_e >> 4;
 #pragma unroll
   for (int j = 0; j < MQ; ++j) {
-    const int qrow = rb[j] + c;
+    const int qrow = rb[j] + ce;
     float den = lacc[j][0];
     if (P.base != 0) den = den + __builtin_amdgcn_exp2f(mcneg[j]);  // softmax_1: + 1*exp(-reference)  (vutils/softmax_1.py:18-20)
     float rowscale = 1.0f / den;
@@ -373,13 +377,13 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
         w.x = pack2_f16(o[j][dt][0] * rowscale, o[j][dt][1] * rowscale);
         w.y = pack2_f16(o[j][dt][2] * rowscale, o[j][dt][3] * rowscale);
       }
-      *reinterpret_cast<u2*>(ebase + (16 * j + c) * ROWB + ((((2 * dt + (g >> 1)) ^ (c & XM)) << 4) | ((g & 1) << 3))) = w;
+      *reinterpret_cast<u2*>(ebase + (16 * j + ce) * ROWB + ((((2 * dt + (ge >> 1)) ^ (ce & XM)) << 4) | ((ge & 1) << 3))) = w;
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes, before it reads them back
   {
     unsigned short* obase = reinterpret_cast<unsigned short*>(P.o) + (long)b * P.os_b + (long)h * P.os_h;
-    const int lr = lane / CPR, lc = lane % CPR;
+    const int lr = lane_e / CPR, lc = lane_e % CPR;
     static_assert(16 % RPP == 0, "a store pass stays inside one query block");
 #pragma unroll
     for (int pass = 0; pass < (16 * MQ) / RPP; ++pass) {
