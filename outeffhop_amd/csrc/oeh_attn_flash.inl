@@ -116,16 +116,20 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   auto issue_next = [&]() {
     const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(nx_slot * STAGEB + wave * G * 1024));
     const bool tail = nx_tile * 64 + 64 > Sk;  // rows past Sk are redirected to row Sk-1 (finite data, masked later)
+    unsigned ko[G], vo[G];
 #pragma unroll
     for (int j = 0; j < G; ++j) {
-      unsigned ko = koff[j], vo = voff[j];
+      ko[j] = koff[j];
+      vo[j] = voff[j];
       if (tail) {
         const int over = nx_tile * 64 + piece_row(j) - (Sk - 1);
-        if (over > 0) { ko -= 2u * (unsigned)(over * P.ks_s); vo -= 2u * (unsigned)(over * P.vs_s); }
+        if (over > 0) { ko[j] -= 2u * (unsigned)(over * P.ks_s); vo[j] -= 2u * (unsigned)(over * P.vs_s); }
       }
-      glds16_s(kcur, ko, slot + j * 1024);
-      glds16_s(vcur, vo, slot + TILEB + j * 1024);
     }
+#pragma unroll
+    for (int j = 0; j < G; ++j) glds16_s(kcur, ko[j], slot + j * 1024);          // the K tile first: tile 0 starts on Q + K
+#pragma unroll
+    for (int j = 0; j < G; ++j) glds16_s(vcur, vo[j], slot + TILEB + j * 1024);
     kcur += kstep;
     vcur += vstep;
     ++nx_tile;
@@ -151,16 +155,22 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   }
   issue_next();
   if (1 < n_kt) issue_next();
-  // Q landed (all but the 2 x 2G younger transfers of stages 0 and 1), for every wave
-  if (1 < n_kt) {
-    if constexpr (G == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (G == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  // Q and K tile 0 landed, for every wave: all but the G (V tile 0) + 2G (stage 1) younger transfers
+  auto wait_vm = [&](auto nc) {  // s_waitcnt vmcnt(N * G), N compile-time
+    constexpr int N = decltype(nc)::value * G;
+    static_assert(N <= 16, "vmcnt immediates used below");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  } else {
-    if constexpr (G == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (G == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  }
+  };
+  if (1 < n_kt) wait_vm(std::integral_constant<int, 3>{});
+  else wait_vm(std::integral_constant<int, 1>{});
   barrier_mem();
   OEH_STAMP(1);
 
@@ -203,8 +213,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   }
 
   // ---- one 64-key tile for blocks J0..MQ-1 of this wave (J0 = 1: block 0's rows end before this tile)
-  auto tile = [&](auto j0c, const int i, const int soff) {
+  auto tile = [&](auto j0c, auto firstc, const int i, const int soff) {
     constexpr int J0 = decltype(j0c)::value;
+    constexpr bool FIRST = decltype(firstc)::value;  // tile 0: V tile 0 is awaited between the two products
     // S^T = K Q^T; every K fragment is read once and used by all active blocks
     f4 s[MQ][4];
 #pragma unroll
@@ -305,6 +316,14 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
         else pb[j][u] = u4{pack2_f16(a[0], a[1]), pack2_f16(a[2], a[3]), pack2_f16(bb[0], bb[1]), pack2_f16(bb[2], bb[3])};
       }
     }
+    if constexpr (FIRST) {
+      // V tile 0 landed for every wave (stage 1 may still be in flight); every wave has its Q operands, so the Q stage
+      // can now be refilled with stage 2
+      if (1 < n_kt) wait_vm(std::integral_constant<int, 2>{});
+      else wait_vm(std::integral_constant<int, 0>{});
+      barrier_mem();
+      if (2 < n_kt) issue_next();
+    }
     // O^T += V^T P^T and l += 1^T P^T; every V^T fragment is read once and used by all active blocks
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -323,16 +342,15 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
     }
   };
 
-  int slot_i = 0;
-  for (int i = 0; i < n_kt; ++i) {
+  using J0_0 = std::integral_constant<int, 0>;
+  using J0_1 = std::integral_constant<int, 1>;
+  tile(J0_0{}, std::true_type{}, 0, 0);  // every block sees key 0: tile 0 is computed by every wave, for all its blocks
+  OEH_STAMP(6);
+  int slot_i = 1;
+  for (int i = 1; i < n_kt; ++i) {
     // ---- stage i landed for every wave
-    if (i + 1 < n_kt) {
-      if constexpr (G == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else if constexpr (G == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (i + 1 < n_kt) wait_vm(std::integral_constant<int, 2>{});
+    else wait_vm(std::integral_constant<int, 0>{});
     barrier_mem();
     if (i < 8) OEH_STAMP(4 + 3 * i);
     if (i + 2 < n_kt) issue_next();  // into the stage every wave finished reading one iteration ago
@@ -340,11 +358,10 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
     const int soff = slot_i * STAGEB;
     slot_i = (slot_i == R - 1) ? 0 : slot_i + 1;
     if (i >= nkb[MQ - 1]) continue;  // this wave's rows end before this tile (causal): nothing to compute
-    if constexpr (MQ == 2) {
-      if (i >= nkb[0]) tile(std::integral_constant<int, 1>{}, i, soff);
-      else tile(std::integral_constant<int, 0>{}, i, soff);
+    if (MQ == 2 && i >= nkb[0]) {
+      if constexpr (MQ == 2) tile(J0_1{}, std::false_type{}, i, soff);
     } else {
-      tile(std::integral_constant<int, 0>{}, i, soff);
+      tile(J0_0{}, std::false_type{}, i, soff);
     }
     if (i < 8) OEH_STAMP(6 + 3 * i);
   }
