@@ -95,7 +95,10 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
     if (stamp != nullptr && lane == 0) stamp[(slot)] = __builtin_amdgcn_s_memtime();   \
   } while (0)
   OEH_STAMP(0);
-  if (stamp != nullptr && lane == 0) stamp[30] = __builtin_amdgcn_s_memrealtime();
+  if (stamp != nullptr && lane == 0) {
+    stamp[30] = __builtin_amdgcn_s_memrealtime();
+    stamp[29] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+  }
 
   // ---- LDS-DMA stream of (K tile, V tile) stages, strictly in order: the scalar base pointers advance by 64 rows per
   // stage, the per-lane byte offsets (row of the piece, swizzled 16-B chunk) never change

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
         w.x = pack2_f16(ov[0], ov[1]);
         w.y = pack2_f16(ov[2], ov[3]);
       }
-      store_wt8(reinterpret_cast<unsigned short*>(P.o) + ooff + d0, w);
+      *reinterpret_cast<u2*>(reinterpret_cast<unsigned short*>(P.o) + ooff + d0) = w;  // 8-B pieces: write-through would cost 2.7x per byte
     } else {
       store_wt16(reinterpret_cast<float*>(P.o) + ooff + d0, u4{f32_bits(ov[0]), f32_bits(ov[1]), f32_bits(ov[2]), f32_bits(ov[3])});
     }

@@ -158,9 +158,6 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
 __device__ __forceinline__ void store_wt16(void* dst, u4 w) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
 }
-__device__ __forceinline__ void store_wt8(void* dst, u2 w) {
-  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(w) : "memory");
-}
 // Workgroup barrier that is ALSO a compiler barrier for memory operations.  __builtin_amdgcn_s_barrier() is
 // "no memory, has side effects" to LLVM, so with the LDS-DMA hidden in inline asm the compiler may hoist LDS reads
 // of a freshly landed tile above it (seen as wholesale wrong results after an unrelated scheduling change).

@@ -53,3 +53,23 @@ for qt in range(nqt):
           f"median start +{int(np.median(rs[sel] - r0)) * 10} ns, median end +{int(np.median(re[sel] - r0)) * 10} ns, last end +{int((re[sel] - r0).max()) * 10} ns")
 pro = (st[:, :, 1] - st[:, :, 0]).max(axis=1)
 print("prologue ticks (start -> Q landed) min/median/max:", int(pro.min()), int(np.median(pro)), int(pro.max()))
+
+# placement: which CU each workgroup ran on (HW_REG_XCC_ID, HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13])
+hw = st[:, 0, 29]
+xcc = (hw >> 32) & 0xF
+cu = (hw >> 8) & 0xF
+sh = (hw >> 12) & 1
+se = (hw >> 13) & 7
+key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+ntile = np.minimum((S + 63) // 64, 2 * (nqt - np.arange(nwg) // (B * H)))  if causal else np.full(nwg, (S + 63) // 64)
+per_cu = {}
+for w in range(nwg):
+    per_cu.setdefault(int(key[w]), []).append(w)
+loads = np.array([sum(int(ntile[w]) for w in ws) for ws in per_cu.values()])
+cnt = np.array([len(ws) for ws in per_cu.values()])
+ends = np.array([max(int(re[w] - r0) for w in ws) for ws in per_cu.values()])
+print(f"CUs used {len(per_cu)}; workgroups per CU min/max {cnt.min()}/{cnt.max()}; 64-key tiles per CU min/mean/max {loads.min()}/{loads.mean():.1f}/{loads.max()}")
+for lv in sorted(set(loads.tolist())):
+    sel = loads == lv
+    print(f"  CUs with {lv:3d} tiles: {int(sel.sum()):3d}, last workgroup ends at median +{int(np.median(ends[sel])) * 10} ns")
+print("example CU -> block ids:", list(per_cu.items())[:4])
