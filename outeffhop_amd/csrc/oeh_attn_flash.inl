@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
         const int row = piece_row(j);
         int qrow = 64 * slab[t] + row;
         qrow = qrow < Sq ? qrow : Sq - 1;  // rows past Sq: finite data, never stored
-        glds16_s(qbase, 2u * (unsigned)(qrow * P.qs_s + (pch ^ swz_k<D>(row)) * 8), qslot + t * TILEB + j * 1024);
+        glds16_s_nt(qbase, 2u * (unsigned)(qrow * P.qs_s + (pch ^ swz_k<D>(row)) * 8), qslot + t * TILEB + j * 1024);
       }
     }
   }

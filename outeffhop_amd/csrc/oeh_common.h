@@ -148,6 +148,18 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
       : "v"(voff), "s"(sbase), "s"(lds_addr)
       : "memory");
 }
+__device__ __forceinline__ void glds16_s_nt(const void* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 nt\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_addr)
+      : "memory");
+}
 // Output stores are WRITE-THROUGH (sc0 sc1).  A plain store leaves the line dirty in the XCD's L2; the whole output
 // (12.6 MB per OPT-125m launch, 1.6 MB per XCD: it all fits) then goes to memory in the end-of-kernel release, after
 // the last wave, where nothing overlaps it: measured 18.97 -> 16.2 us per launch on the headline workload (`nt` alone:
