@@ -43,6 +43,7 @@ FqP make_fq(const oeh_fq* f) {
     r.rscale = 1.0f / f->scale;
     r.zp = f->zero_point;
     r.qmax = f->qmax;
+    r.guard = 0.5f - 1.2e-6f * (f->qmax + f->zero_point + 2.0f);
     r.dump = f->dump_idx;
   }
   return r;

@@ -176,40 +176,69 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
   }
 
   // =========================== phase 2: elementwise chain + row statistics ===========================
-  // lane (c,g) owns query row `qrow`, keys 16t+4g+r
+  // lane (c,g) owns query row `qrow`, keys 16t+4g+r.  Every optional step is guarded by a wave-uniform test evaluated
+  // once per 16-key tile (the option itself, or "this tile can hold such a key"), so that the per-element work is the
+  // arithmetic of the steps that are on - the order of the steps is the reference's.
   const float mask_min = P.mask_min;
   const int klim = qrow + off;  // last key a causal row may see
+  const bool use_div = P.scale_div != 0.0f;
+  const bool has_pad = P.pad != nullptr, has_full = P.full != nullptr;
+  const bool fq_s_on = FQ && P.fq_s.en, fq_p_on = FQ && P.fq_p.en;
+  const bool dump_s = fq_s_on && P.fq_s.dump != nullptr, dump_p = fq_p_on && P.fq_p.dump != nullptr;
+  const int t_causal = P.causal ? max(0, q0 + off + 1) >> 4 : NT;  // first tile with a key the wave's first row must not see
+  const int t_tail = P.Sk >> 4;                                     // first tile with a key >= Sk
   float m = -__builtin_inff();
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     if (t < nt_wave) {
-      const f4 padv = *reinterpret_cast<const f4*>(&lds_pad[16 * t + 4 * g]);
-      unsigned int dump_word = 0;
+      const int key0 = 16 * t + 4 * g;
+      f4 x = s[t];
+      if (use_div) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = 16 * t + 4 * g + r;
-        float x = s[t][r];
-        x = (P.scale_div != 0.0f) ? x / P.scale_div : x * P.scale;
-        if constexpr (FQ) {
-          if (P.fq_s.en) {
-            const float idx = fq_index(x, P.fq_s);
-            dump_word |= ((unsigned int)idx) << (8 * r);
-            x = fq_dequant(idx, P.fq_s);
-          }
-        }
-        if (P.pad != nullptr) x = x + padv[r];
-        if (P.full != nullptr && qvalid && key < P.Sk)
-          x = x + load_mask(P.full, P.full_f16, (long)b * P.full_sb + (long)qrow * P.full_sq + key);
-        if (P.causal && key > klim) x = x + mask_min;
-        if (P.clamp_min) x = __builtin_fmaxf(x, mask_min);
-        if (key >= P.Sk) x = -__builtin_inff();
-        s[t][r] = x;
-        m = __builtin_fmaxf(m, x);
+        for (int r = 0; r < 4; ++r) x[r] = x[r] / P.scale_div;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = x[r] * P.scale;
       }
       if constexpr (FQ) {
-        if (P.fq_s.en && P.fq_s.dump != nullptr && qvalid)
-          dump4(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + 16 * t + 4 * g, dump_word, P.Sk - (16 * t + 4 * g));
+        if (fq_s_on) {
+          f4 idx;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) idx[r] = fq_index_fast(x[r], P.fq_s);
+          if (dump_s && qvalid) {
+            const unsigned int w = (unsigned int)idx[0] | ((unsigned int)idx[1] << 8) | ((unsigned int)idx[2] << 16) | ((unsigned int)idx[3] << 24);
+            dump4(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + key0, w, P.Sk - key0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = fq_dequant(idx[r], P.fq_s);
+        }
       }
+      if (has_pad) {
+        const f4 padv = *reinterpret_cast<const f4*>(&lds_pad[key0]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = x[r] + padv[r];
+      }
+      if (has_full) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (qvalid && key0 + r < P.Sk) x[r] = x[r] + load_mask(P.full, P.full_f16, (long)b * P.full_sb + (long)qrow * P.full_sq + key0 + r);
+      }
+      if (t >= t_causal) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (key0 + r > klim) x[r] = x[r] + mask_min;
+      }
+      if (P.clamp_min) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = __builtin_fmaxf(x[r], mask_min);
+      }
+      if (t >= t_tail) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (key0 + r >= P.Sk) x[r] = -__builtin_inff();
+      }
+      s[t] = x;
+      m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(x[0], x[1])), __builtin_fmaxf(x[2], x[3]));
     }
   }
   m = __builtin_fmaxf(m, __shfl_xor(m, 16));
@@ -240,25 +269,35 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
   for (int t = 0; t < NT; ++t) {
     ph[t] = u2{0u, 0u};
     if (t < nt_wave) {
-      float pv[4];
-      unsigned int dump_word = 0;
+      const int key0 = 16 * t + 4 * g;
+      f4 pv;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float p = s[t][r] * inv;
-        if (P.clip) {
-          p = p * P.clip_w;
+      for (int r = 0; r < 4; ++r) pv[r] = s[t][r] * inv;
+      if (P.clip) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = pv[r] * P.clip_w;
           p = p + P.clip_g;
-          p = __builtin_fminf(__builtin_fmaxf(p, 0.0f), 1.0f);
+          pv[r] = __builtin_fminf(__builtin_fmaxf(p, 0.0f), 1.0f);
         }
-        if constexpr (FQ) {
-          if (P.fq_p.en) {
-            const float idx = fq_index(p, P.fq_p);
-            dump_word |= ((unsigned int)idx) << (8 * r);
-            p = idx - P.fq_p.zp;  // integer valued: exact in f16/bf16; scale applied after the product
+      }
+      if constexpr (FQ) {
+        if (fq_p_on) {
+          f4 idx;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) idx[r] = fq_index_fast(pv[r], P.fq_p);
+          if (dump_p && qvalid) {
+            const unsigned int w = (unsigned int)idx[0] | ((unsigned int)idx[1] << 8) | ((unsigned int)idx[2] << 16) | ((unsigned int)idx[3] << 24);
+            dump4(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + key0, w, P.Sk - key0);
           }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pv[r] = idx[r] - P.fq_p.zp;  // integer valued: exact in f16/bf16; scale applied after the product
         }
-        if (16 * t + 4 * g + r >= P.Sk) p = 0.0f;
-        pv[r] = p;
+      }
+      if (t >= t_tail) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (key0 + r >= P.Sk) pv[r] = 0.0f;
       }
       if constexpr (IN == IN_BF16) {
         ph[t].x = pack2_bf16(pv[0], pv[1]);
@@ -266,10 +305,6 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
       } else {
         ph[t].x = pack2_f16(pv[0], pv[1]);
         ph[t].y = pack2_f16(pv[2], pv[3]);
-      }
-      if constexpr (FQ) {
-        if (P.fq_p.en && P.fq_p.dump != nullptr && qvalid)
-          dump4(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + 16 * t + 4 * g, dump_word, P.Sk - (16 * t + 4 * g));
       }
     }
   }
@@ -322,7 +357,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
       if constexpr (FQ) {
         if (P.fq_p.en) x = P.fq_p.scale * x;
         if (P.fq_c.en && P.ctx_before_gate) {
-          const float idx = fq_index(x, P.fq_c);
+          const float idx = fq_index_fast(x, P.fq_c);
           dump_word |= ((unsigned int)idx) << (8 * r);
           x = fq_dequant(idx, P.fq_c);
         }
@@ -330,7 +365,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
       if (P.gate != nullptr) x = x * gatev;
       if constexpr (FQ) {
         if (P.fq_c.en && !P.ctx_before_gate) {
-          const float idx = fq_index(x, P.fq_c);
+          const float idx = fq_index_fast(x, P.fq_c);
           dump_word |= ((unsigned int)idx) << (8 * r);
           x = fq_dequant(idx, P.fq_c);
         }

@@ -26,6 +26,7 @@ constexpr float kLog2eLo = 0x1.4ae0bep-26f;  // log2 e - kLog2eHi
 struct FqP {
   int en;
   float scale, rscale, zp, qmax;
+  float guard;  // see fq_index_fast
   unsigned char* dump;
 };
 
@@ -41,6 +42,18 @@ __device__ __forceinline__ float fq_rint_div(float x, float scale, float rscale)
 __device__ __forceinline__ float fq_index(float x, const FqP& f) {
   float r = fq_rint_div(x, f.scale, f.rscale) + f.zp;
   return __builtin_fminf(__builtin_fmaxf(r, 0.0f), f.qmax);
+}
+// The same index two instructions cheaper per element.  Where the index is not clamped anyway the quotient is bounded
+// by the grid (|q| <= qmax + zp + 1), so the half-integer guard band is a per-quantiser constant: f.guard =
+// 0.5 - 1.2e-6 * (qmax + zp + 2), set by the host (oeh_api.hip: make_fq).  One subtract and one compare per element;
+// the division runs for ~(1 - 2*guard) of the elements (6e-4 for an 8-bit grid).
+__device__ __forceinline__ float fq_index_fast(float x, const FqP& f) {
+  const float q = x * f.rscale;
+  float r = __builtin_rintf(q);
+  if (__builtin_expect(__builtin_fabsf(q - r) > f.guard, 0)) {
+    if (__builtin_fabsf(q) <= f.qmax + f.zp + 2.0f) r = __builtin_rintf(x / f.scale);
+  }
+  return __builtin_fminf(__builtin_fmaxf(r + f.zp, 0.0f), f.qmax);
 }
 __device__ __forceinline__ float fq_dequant(float idx, const FqP& f) { return f.scale * (idx - f.zp); }
 
