@@ -105,6 +105,47 @@ def cpu_baseline(w, seconds):
                        f"{cores} logical CPUs), B={Bs} of {w['B']} H={H} S={S} d={d}, {n} layer passes in {dt:.1f} s")
 
 
+def int8_check():
+    """The second half of BASELINE.json's metric: INT8 max-abs-err of the fused HIP path vs the reference arithmetic (CPU
+    oracle), on a bounded OPT-shaped sample (B=1, H=2, S=256, d=64; softmax1, causal, three 8-bit quantisers calibrated at
+    percentile 99.999 like validate_clm.py:450-454).  Part of the cpu_baseline leg: the oracle is the checker only."""
+    import numpy as np
+    import torch
+
+    from oracle import oeh_oracle as O
+    from outeffhop_amd import ops
+
+    B, H, S, D = 1, 2, 256, 64
+    g = torch.Generator().manual_seed(2004)
+    q = (torch.randn(B, H, S, D, generator=g) * D ** -0.5).half()
+    k = torch.randn(B, H, S, D, generator=g).half()
+    v = torch.randn(B, H, S, D, generator=g).half()
+    f32 = lambda t: t.float().numpy()  # noqa: E731
+    common = dict(base=1, causal=True, clamp_min=True)
+    ctx_fp, fp = O.attn_core(f32(q), f32(k), f32(v), want=("scores", "probs"), **common)
+    d_s = O.quant_range_to_params(*np.percentile(fp["scores"], (0.001, 99.999)))
+    d_p = O.quant_range_to_params(*np.percentile(fp["probs"], (0.001, 99.999)))
+    d_c = O.quant_range_to_params(*np.percentile(ctx_fp, (0.001, 99.999)))
+    want, ex = O.attn_core(f32(q), f32(k), f32(v), fq_scores=d_s, fq_probs=d_p, fq_ctx=d_c, ctx_quant_before_gate=True,
+                           want=("scores_idx", "probs_idx", "ctx_idx"), **common)
+    dumps = {n: torch.zeros(shape, dtype=torch.uint8, device="cuda") for n, shape in
+             (("scores", (B, H, S, S)), ("probs", (B, H, S, S)), ("ctx", (B, H, S, D)))}
+    FQ = ops.FakeQuantSpec.from_delta
+    fq = ops.AttnFakeQuant(FQ(*d_s, dump=dumps["scores"]), FQ(*d_p, dump=dumps["probs"]), FQ(*d_c, dump=dumps["ctx"]), ctx_before_gate=True)
+    got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=ops.SoftmaxSpec(1, False, 0.0, 1.0), causal=True, clamp_min=True,
+                       mask_min=float(np.finfo(np.float32).min), fq=fq)
+    torch.cuda.synchronize()
+    tri = np.tril(np.ones((S, S), dtype=bool))[None, None]
+    flips, total = 0, 0
+    for n in ("scores", "probs", "ctx"):
+        a_, b_ = dumps[n].cpu().numpy().astype(np.int32), ex[f"{n}_idx"].astype(np.int32)
+        sel = np.broadcast_to(tri, a_.shape) if n != "ctx" else np.ones_like(a_, dtype=bool)
+        flips += int((a_[sel] != b_[sel]).sum())
+        total += int(sel.sum())
+    return {"max_abs_err": float(np.abs(got.float().cpu().numpy() - want).max()), "quantiser_index_mismatch_rate": flips / total,
+            "sample": f"B={B} H={H} S={S} d={D} fp16 causal softmax1, 8-bit scores/probs/context quantisers, vs oracle/oeh_oracle.py"}
+
+
 def main():
     a = parse()
     import numpy as np
@@ -277,6 +318,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(w, a.cpu_seconds)
             rec["config"]["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
+            rec["cpu_baseline"]["int8_vs_reference"] = int8_check()
         print(json.dumps(rec), flush=True)
     if dist is not None:
         dist.barrier()
