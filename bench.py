@@ -40,7 +40,8 @@ WORKLOADS = {
     "bert_softmax1": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=False, gate=False,
                           desc="BERT-base attention core B=32 H=12 S=128 d=64 fp16 key-padding mask softmax1"),
     "bert_gated": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=False, gate=True,
-                       desc="BERT-base gated attention core (per-token gate) B=32/GPU H=12 S=128 d=64 fp16"),
+                       desc="BERT-base gated attention core B=32/GPU H=12 S=128 d=64 fp16: per-token gate from per-head MLPs "
+                            "64->16->1 on the layer input (oeh_gate_fwd) + the fused core with the gate epilogue"),
 }
 
 
@@ -194,7 +195,15 @@ def main():
         for b_, n_ in enumerate(lens.tolist()):
             pad[b_, n_:] = fmin
         pad = pad.to(dev)
-    gate = torch.rand(B, H, S, 1, generator=g).to(dev) if w["gate"] else None
+    gate = None
+    gate_in = None
+    if w["gate"]:  # conditional_per_token gate, --attn_gate_mlp (submit_outlier_bert.sh:257-259): computed INSIDE the timed step
+        gate = torch.empty(B, H, S, 1, dtype=torch.float32, device=dev)
+        gw1 = (torch.randn(H, 16, d, generator=g) * 0.02).to(dev)
+        gb1 = torch.zeros(H, 16, device=dev)
+        gw2 = (torch.randn(H, 16, generator=g) * 0.02).to(dev)
+        gb2 = torch.full((H,), float(np.log(0.25 / 0.75)), device=dev)  # bias init logit(attn_gate_init = 0.25)
+        gate_in = [torch.randn(B, S, H * d, generator=g).half().to(dev) for _ in range(L)]  # the layers' hidden states
     fq = None
     if w["int8"]:
         FQ = ops.FakeQuantSpec
@@ -227,9 +236,18 @@ def main():
     calls = [make_call(*s) for s in sets]
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     fwd = lib.oeh_attn_fwd
+    gate_calls = None
+    if gate_in is not None:
+        vp = C.c_void_p
+        gate_calls = [(vp(hd.data_ptr()), _lib.OEH_F16, B, S, H, d, hd.stride(0), hd.stride(1), vp(gw1.data_ptr()), vp(gb1.data_ptr()),
+                       vp(gw2.data_ptr()), vp(gb2.data_ptr()), 16, 0, 1.0, vp(gate.data_ptr())) for hd in gate_in]
 
     def step():
-        for args, _ in calls:
+        for li, (args, _) in enumerate(calls):
+            if gate_calls is not None:
+                rc = lib.oeh_gate_fwd(*gate_calls[li], stream)
+                if rc != 0:
+                    raise RuntimeError(f"oeh_gate_fwd -> {rc}")
             rc = fwd(*args, stream)
             if rc != 0:
                 raise RuntimeError(f"oeh_attn_fwd -> {rc}")
@@ -279,7 +297,7 @@ def main():
         layer_tokens = world * B * S * L * a.steps
         kern_s = dev_ms * 1e-3 / launches
         elt = 2
-        alg_bytes = 4 * B * H * S * d * elt + (B * S * 4 if pad is not None else 0) + (B * H * S * 4 if gate is not None else 0)
+        alg_bytes = 4 * B * H * S * d * elt + (B * S * 4 if pad is not None else 0) + (B * S * H * d * elt if gate is not None else 0)  # + gate input (hidden states)
         achieved = alg_bytes / kern_s / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -304,7 +322,7 @@ def main():
             "config": {
                 "workload": w["desc"], "variant": ops.attn_variant(B, H, S, S, d, fq=w["int8"], clip=bool(w["sm"][1])),
                 "batch_per_gpu": B, "seq_len": S, "heads": H, "head_dim": d, "layers_per_step": L,
-                "launches_per_step": L, "model_tokens_per_s": world * B * S * a.steps / wall,
+                "launches_per_step": L * (2 if gate is not None else 1), "model_tokens_per_s": world * B * S * a.steps / wall,
                 "parallelism": f"batch-shard x{world}, no collective in the timed region",
             },
             "roofline": {

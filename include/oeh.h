@@ -149,8 +149,9 @@ int oeh_minmax(const void* x, int64_t n, int32_t dtype, float* out2, void* strea
 int oeh_abi_version(void);
 const char* oeh_build_info(void);       /* "gfx950 hipcc <version> ..." */
 const char* oeh_strerror(int code);
-/* name of the kernel variant oeh_attn_fwd would launch for `desc` ("mfma16/NT32/D64/f16", "generic", ...)
- * or NULL if unsupported; host only. */
+/* name of the kernel variant oeh_attn_fwd would launch for `desc` ("flash16/MQ2/D64/f16" one-pass kernel,
+ * "fast16/NT32/D64/f16/clip" full-row kernel, "mfma16/NT32/D64/f16/fq" general kernel, "generic") or NULL if
+ * unsupported; host only.  The returned string lives in thread-local storage until the next call on this thread. */
 const char* oeh_attn_variant(const oeh_attn_desc* desc, const oeh_fq_desc* fq);
 
 #ifdef __cplusplus
