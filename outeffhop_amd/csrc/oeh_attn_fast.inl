@@ -40,7 +40,7 @@ __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
 
 // waves per SIMD the register allocator must leave room for: 3 at NT=32 (<= 168 VGPRs), LDS allows 3 workgroups (50 KB each)
 template <int NT, int D>
-constexpr int fast_occupancy() { return D >= 128 ? 2 : (NT >= 32 ? 3 : (NT >= 16 ? 3 : 4)); }
+constexpr int fast_occupancy() { return D >= 128 ? 1 : 3; }  // what the LDS rings allow (6 tiles of 64 x 2D bytes)
 
 template <int NT, int D, int IN, bool CLIP>
 __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_kernel(const AttnParams P) {

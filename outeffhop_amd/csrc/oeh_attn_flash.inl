@@ -35,7 +35,7 @@ __device__ __forceinline__ float row_allreduce_max(float x) {
 }
 
 template <int D, int MQ>
-constexpr int flash_occupancy() { return D >= 128 ? 2 : (MQ >= 4 ? 2 : 3); }
+constexpr int flash_occupancy() { return D >= 128 ? 1 : 3; }
 
 template <int D, int IN, int MQ, bool PAD>
 __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flash_kernel(const AttnParams P) {
