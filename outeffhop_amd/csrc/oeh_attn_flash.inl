@@ -55,6 +55,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   constexpr float kThr = 8.0f;          // lazy reference: P stays <= 2^8 (exact range for f16 / bf16 operands)
 
   __shared__ __attribute__((aligned(16))) unsigned char lds[R * STAGEB];
+  constexpr int PADROW = 1024;          // keys of the padding row kept in LDS (PAD variant)
+  __shared__ __attribute__((aligned(16))) float lds_padrow[PAD ? PADROW : 4];
+  __shared__ int lds_last[4];
 
   const int bid = blockIdx.x;
   const int qt_rev = bid / P.nBHpad;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
     rb[j] = 64 * slab[j] + 16 * wave;
   }
   const int last_row_wg = 64 * slab[MQ - 1] + 63;  // last query row of the workgroup (bounds the tiles it streams)
-  const int n_kt = ((causal ? min(Sk, max(0, last_row_wg + 1 + off)) : Sk) + 63) >> 6;  // tiles the workgroup streams
+  int n_kt = ((causal ? min(Sk, max(0, last_row_wg + 1 + off)) : Sk) + 63) >> 6;  // tiles the workgroup streams
   int tm0[MQ];                          // first tile that holds a masked key for the block's first row
 #pragma unroll
   for (int j = 0; j < MQ; ++j) {
@@ -172,9 +175,29 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   };
+  // Key padding (PAD variant), while the first transfers fly: the row of additive values goes to LDS once (tiles read it
+  // from there; in-loop global loads would put compiler waits into the DMA stream), and trailing 64-key tiles in which
+  // EVERY key is masked are dropped from the stream - a masked key contributes exp(x - m) = 0 exactly, so this is the
+  // reference's result, and right-padded batches are the norm.  The two stages already issued are always consumed.
+  const bool pad_in_lds = PAD && Sk <= PADROW;
+  if constexpr (PAD) {
+    int last = -1;  // last key that is not masked
+    for (int key = tid; key < ((Sk + 63) & ~63); key += 256) {
+      const float pv = key < Sk ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + key) : 0.0f;
+      if (key < PADROW) lds_padrow[key] = pv;
+      if (key < Sk && pv > -1.0e30f) last = key;
+    }
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) last = max(last, __shfl_xor(last, sft));
+    if (lane == 0) lds_last[wave] = last;
+  }
   if (1 < n_kt) wait_vm(std::integral_constant<int, 3>{});
   else wait_vm(std::integral_constant<int, 1>{});
   barrier_mem();
+  if constexpr (PAD) {
+    const int last = max(max(lds_last[0], lds_last[1]), max(lds_last[2], lds_last[3]));
+    n_kt = min(n_kt, max((last >> 6) + 1, min(n_kt, 2)));
+  }
   OEH_STAMP(1);
 
   // lane-constant parts of the LDS fragment addresses
@@ -239,8 +262,12 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
       for (int sub = 0; sub < 4; ++sub) {
         const int kb = 64 * i + 16 * sub + 4 * g;
         f4 padv;
+        if (pad_in_lds) {
+          padv = *reinterpret_cast<const f4*>(&lds_padrow[kb]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) padv[r] = (kb + r < Sk) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + kb + r) : 0.0f;
+          for (int r = 0; r < 4; ++r) padv[r] = (kb + r < Sk) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + kb + r) : 0.0f;
+        }
 #pragma unroll
         for (int j = J0; j < MQ; ++j)
 #pragma unroll

@@ -382,3 +382,16 @@ def test_randomised_kernel_sweep(ops):
     finally:
         lib.oeh_debug_set_variant(0, 0)
     assert {"flash16", "fast16", "mfma16"} <= seen
+
+
+def test_one_pass_padding_trim_and_long_rows(ops):
+    """Key padding on the one-pass kernel: trailing fully padded 64-key tiles are dropped from the stream (exact: a masked key
+    contributes 0), the padding row is read from LDS up to 1024 keys and from global memory beyond."""
+    fmin = float(np.finfo(np.float32).min)
+    for n, (B, H, Sq, Sk, lens) in enumerate([(3, 2, 90, 700, (130, 700, 1)), (2, 1, 150, 1100, (1100, 333))]):
+        q, k, v = _rand((B, H, Sq, 64), 4000 + n), _rand((B, H, Sk, 64), 4010 + n), _rand((B, H, Sk, 64), 4020 + n)
+        padm = _pad_mask(B, Sk, list(lens), fmin)
+        assert ops.attn_variant(B, H, Sq, Sk, 64).startswith("flash16/")
+        want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=0.125, pad_mask=padm, **SPECS["softmax1"])
+        got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), scale=0.125, key_pad_mask=torch.from_numpy(padm).cuda(), mask_min=fmin)
+        _check(got, want, msg=f"case {n}")
