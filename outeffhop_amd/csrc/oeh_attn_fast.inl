@@ -133,29 +133,37 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
     if (stamp != nullptr && lane == 0) stamp[(slot)] = __builtin_amdgcn_s_memtime();                  \
   } while (0)
   OEH_STAMP(0);
-  // ---- Q^T operand
-  u4 qf[KS];
+  // ---- Q rides the LDS-DMA stream, first, as a K-shaped tile in the V ring's last slot (first used by V tile R-1, long
+  // after the operands below are in registers): the bytes in front of the first MFMA are Q + K tile 0, requested together,
+  // instead of a register load of Q that had to land before the first transfer could even be issued.
   {
-    const long qoff = (long)b * P.qs_b + (long)h * P.qs_h + (long)qrow * P.qs_s;
+    const unsigned short* qbase = reinterpret_cast<const unsigned short*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h;
+    const unsigned qslot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((2 * R - 1) * TILEB + wave * G * 1024));
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      qf[ks] = u4{0, 0, 0, 0};
-      if (qvalid) qf[ks] = load8_as16<IN>(P.q, qoff + ks * 32 + 8 * g);
+    for (int j = 0; j < G; ++j) {
+      const int row = piece_row(j);
+      int qr = qt * 64 + row;
+      qr = qr < P.Sq ? qr : P.Sq - 1;  // rows past Sq: finite data, never stored
+      glds16(qbase + (long)qr * P.qs_s + (pch ^ swz_k<D>(row)) * 8, qslot + j * 1024);
     }
   }
-  const bool has_pad = P.pad != nullptr;
-  if (has_pad) {
-    for (int i = tid; i < NT * 16; i += 256) lds_pad[i] = (i < P.Sk) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + i) : 0.0f;
-  }
-  // the compiler must wait for its own loads (Q, padding row) BEFORE the first LDS-DMA is issued: later it would
-  // have to use vmcnt(0) and drain the ring
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // stream prologue: two tiles in flight
   issue_next();
   if (1 < T) issue_next();
+  const bool has_pad = P.pad != nullptr;
+  if (has_pad) {  // (compiler-visible loads: its wait for them also covers the transfers above, which the next wait needs anyway)
+    for (int i = tid; i < NT * 16; i += 256) lds_pad[i] = (i < P.Sk) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + i) : 0.0f;
+  }
+  wait_tiles_in_flight<G>(min(2, T));  // Q landed; the one or two tiles behind it may still be in flight
+  barrier_mem();
   OEH_STAMP(1);
+  const unsigned char* kaddr[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kaddr[ks] = lds + c * ROWB + (((ks * 4 + g) ^ swz_k<D>(c)) << 4);  // swz_k(16*sub + c) == swz_k(c)
+  u4 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u4*>(kaddr[ks] + (2 * R - 1) * TILEB + wave * 16 * ROWB);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   // Instruction stream: the 64-key LDS tile is also the unit of control flow.  Every wave of the workgroup runs all
   // four 16-key sub-tiles of every tile it has waited for as straight-line code with compile-time LDS offsets and
@@ -165,9 +173,6 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
   // on tiles at or after the first masked key.
   // =========================== phase 1: S^T = K Q^T ===========================
   f4 s[NT];
-  const unsigned char* kaddr[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) kaddr[ks] = lds + c * ROWB + (((ks * 4 + g) ^ swz_k<D>(c)) << 4);  // swz_k(16*sub + c) == swz_k(c)
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     if (kt < n_kt) {
