@@ -17,6 +17,9 @@
 //     uses, and frees 16 v_add per block and tile - the loop is VALU-issue bound, not MFMA bound);
 //   * lazy reference: it moves only when a row's tile maximum exceeds it by 2^8, so the O/l rescale (20 multiplies per
 //     block) almost never runs after the first tiles;
+//   * Q arrives by LDS-DMA ahead of the first stages and tile 0 starts on Q + K tile 0 alone; O leaves as whole rows,
+//     write-through (oeh_common.h: store_wt16 - a plain store parks the output in L2 until the end-of-kernel release);
+//   * key padding (PAD variant): the padding row sits in LDS and trailing fully padded key tiles are not streamed.
 // Same swapped products (S^T = K Q^T, O^T = V^T P^T on v_mfma_f32_16x16x32), LDS images, swizzles and LDS-DMA ring
 // as the full-row kernel.  Masks: none | analytic causal | key padding (softmax_1 only: a fully masked row must be 0).
 #pragma once
