@@ -41,7 +41,7 @@ WORKLOADS = {
                           desc="BERT-base attention core B=32 H=12 S=128 d=64 fp16 key-padding mask softmax1"),
     "bert_gated": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=False, gate=True,
                        desc="BERT-base gated attention core B=32/GPU H=12 S=128 d=64 fp16: per-token gate from per-head MLPs "
-                            "64->16->1 on the layer input (oeh_gate_fwd) + the fused core with the gate epilogue"),
+                            "64->16->1 on the layer input, evaluated inside the attention kernel (gate_hidden ... of oeh_attn_desc)"),
 }
 
 
@@ -198,7 +198,7 @@ def main():
     gate = None
     gate_in = None
     if w["gate"]:  # conditional_per_token gate, --attn_gate_mlp (submit_outlier_bert.sh:257-259): computed INSIDE the timed step
-        gate = torch.empty(B, H, S, 1, dtype=torch.float32, device=dev)
+        gate = True
         gw1 = (torch.randn(H, 16, d, generator=g) * 0.02).to(dev)
         gb1 = torch.zeros(H, 16, device=dev)
         gw2 = (torch.randn(H, 16, generator=g) * 0.02).to(dev)
@@ -221,9 +221,13 @@ def main():
             dsc.scale, dsc.scale_div = 1.0, 8.0
             dsc.key_pad_mask, dsc.key_pad_dtype, dsc.key_pad_stride = pad.data_ptr(), _lib.OEH_F32, pad.stride(0)
         dsc.softmax_base, dsc.clip, dsc.gamma, dsc.eta, dsc.mask_min = base, int(clip), gamma, eta, fmin
-        if gate is not None:
-            dsc.gate = gate.data_ptr()
-            dsc.gate_stride[:] = [gate.stride(0), gate.stride(1), gate.stride(2)]
+        if gate_in is not None:  # per-layer predictor input: the gate is evaluated in the kernel
+            hd = gate_in[len(gate_descs)]
+            gate_descs.append(hd)
+            dsc.gate_hidden = hd.data_ptr()
+            dsc.gate_hidden_stride[:] = [hd.stride(0), hd.stride(1)]
+            dsc.gate_w1, dsc.gate_b1, dsc.gate_w2, dsc.gate_b2 = gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr()
+            dsc.gate_units, dsc.gate_scaling = 16, 1.0
         fqd = None
         if fq is not None:
             fqd = _lib.oeh_fq_desc()
@@ -233,21 +237,12 @@ def main():
                 C.c_void_p(o.data_ptr()), None if fqd is None else C.byref(fqd))
         return args, (dsc, fqd)
 
+    gate_descs = []
     calls = [make_call(*s) for s in sets]
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     fwd = lib.oeh_attn_fwd
-    gate_calls = None
-    if gate_in is not None:
-        vp = C.c_void_p
-        gate_calls = [(vp(hd.data_ptr()), _lib.OEH_F16, B, S, H, d, hd.stride(0), hd.stride(1), vp(gw1.data_ptr()), vp(gb1.data_ptr()),
-                       vp(gw2.data_ptr()), vp(gb2.data_ptr()), 16, 0, 1.0, vp(gate.data_ptr())) for hd in gate_in]
-
     def step():
-        for li, (args, _) in enumerate(calls):
-            if gate_calls is not None:
-                rc = lib.oeh_gate_fwd(*gate_calls[li], stream)
-                if rc != 0:
-                    raise RuntimeError(f"oeh_gate_fwd -> {rc}")
+        for args, _ in calls:
             rc = fwd(*args, stream)
             if rc != 0:
                 raise RuntimeError(f"oeh_attn_fwd -> {rc}")
@@ -322,7 +317,7 @@ def main():
             "config": {
                 "workload": w["desc"], "variant": ops.attn_variant(B, H, S, S, d, fq=w["int8"], clip=bool(w["sm"][1])),
                 "batch_per_gpu": B, "seq_len": S, "heads": H, "head_dim": d, "layers_per_step": L,
-                "launches_per_step": L * (2 if gate is not None else 1), "model_tokens_per_s": world * B * S * a.steps / wall,
+                "launches_per_step": L, "model_tokens_per_s": world * B * S * a.steps / wall,
                 "parallelism": f"batch-shard x{world}, no collective in the timed region",
             },
             "roofline": {

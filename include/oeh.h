@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OEH_ABI_VERSION 1
+#define OEH_ABI_VERSION 2
 
 /* error codes (negative errno style) */
 #define OEH_OK 0
@@ -109,6 +109,26 @@ typedef struct oeh_attn_desc {
    * (context *= gate * scaling, bert_attention.py:327; opt_attention.py:309).  NULL = no gate. */
   const float* gate;
   int64_t gate_stride[3];        /* elements: batch, head, query row */
+
+  /* OR the conditional per-token gate computed INSIDE the kernel from the layer input (bert_attention.py:301-327,
+   * opt_attention.py:283-309), used when gate == NULL and gate_hidden != NULL: per head h the predictor acts on
+   * gate_hidden[b, t, h*D:(h+1)*D] (same 16-bit dtype as q, D contiguous, rows 16-byte aligned); weights are fp32
+   * device arrays laid out as for oeh_gate_fwd (gate_units == 0: Linear(D,1): w1 (H,D), b1 (H); gate_units = m > 0:
+   * Linear(D,m), ReLU, Linear(m,1): w1 (H,m,D), b1 (H,m), w2 (H,m), b2 (H)); context *= sigmoid(logit) * gate_scaling.
+   * The first layer runs on the matrix cores with the weights rounded to the storage dtype and fp32 accumulation -
+   * what the reference's own Linear does in a 16-bit model - so values agree with oeh_gate_fwd (fp32 weights) to
+   * ~1e-4, not bit for bit.  gate_out (B,H,Sq) fp32, optional, receives sigmoid(logit) without the scaling (the
+   * modules' last_gate_all_probs bookkeeping).  Only the full-row 16-bit variant ("fast16/...") takes it:
+   * OEH_ENOTSUP otherwise (use oeh_gate_fwd + `gate`). */
+  const void* gate_hidden;
+  int64_t gate_hidden_stride[2]; /* elements: batch, token */
+  const float* gate_w1;
+  const float* gate_b1;
+  const float* gate_w2;
+  const float* gate_b2;
+  int32_t gate_units;
+  float gate_scaling;
+  float* gate_out;
 } oeh_attn_desc;
 
 /* QK^T -> scale -> [fq] -> mask -> softmax / softmax_1 -> [clip] -> [fq] -> PV -> [fq] -> gate -> [fq]

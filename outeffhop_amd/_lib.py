@@ -17,7 +17,7 @@ OEH_SOFTMAX_VANILLA, OEH_SOFTMAX_ONE = 0, 1
 
 
 class OehError(RuntimeError):
-    pass
+    code = 0  # the negative OEH_E* code when the error came from the library
 
 
 class oeh_fq(C.Structure):
@@ -45,6 +45,9 @@ class oeh_attn_desc(C.Structure):
         ("full_mask", C.c_void_p), ("full_mask_dtype", C.c_int32), ("full_mask_stride", C.c_int64 * 2),
         ("causal", C.c_int32), ("clamp_min", C.c_int32), ("mask_min", C.c_float),
         ("gate", C.c_void_p), ("gate_stride", C.c_int64 * 3),
+        ("gate_hidden", C.c_void_p), ("gate_hidden_stride", C.c_int64 * 2),
+        ("gate_w1", C.c_void_p), ("gate_b1", C.c_void_p), ("gate_w2", C.c_void_p), ("gate_b2", C.c_void_p),
+        ("gate_units", C.c_int32), ("gate_scaling", C.c_float), ("gate_out", C.c_void_p),
     ]
 
 
@@ -90,12 +93,14 @@ def load() -> C.CDLL:
     lib.oeh_strerror.restype = C.c_char_p
     lib.oeh_attn_variant.argtypes = [C.POINTER(oeh_attn_desc), C.POINTER(oeh_fq_desc)]
     lib.oeh_attn_variant.restype = C.c_char_p
-    if lib.oeh_abi_version() != 1:
-        raise OehError(f"liboeh_hip.so ABI {lib.oeh_abi_version()} != 1 (stale build?)")
+    if lib.oeh_abi_version() != 2:
+        raise OehError(f"liboeh_hip.so ABI {lib.oeh_abi_version()} != 2 (stale build?)")
     _lib = lib
     return lib
 
 
 def check(rc: int, what: str) -> None:
     if rc != 0:
-        raise OehError(f"{what} failed: {load().oeh_strerror(rc).decode()} ({rc})")
+        err = OehError(f"{what} failed: {load().oeh_strerror(rc).decode()} ({rc})")
+        err.code = rc
+        raise err

@@ -95,6 +95,26 @@ class GateState:
         return packed
 
     @staticmethod
+    def predictor(mod: nn.Module, hidden_states: torch.Tensor, num_heads: int, scaling: float):
+        """The conditional per-token gate as an `ops.GatePredictor` for evaluation INSIDE the attention kernel, or None
+        when the module's gate is of another kind (then `evaluate`).  Bookkeeping attributes are set from the
+        predictor's `out` tensor by `finish_predictor` after the launch."""
+        if mod.attn_gate_type != AttentionGateType.conditional_per_token or mod.attn_gate_linear_all_features:
+            return None
+        if hidden_states.dtype not in (torch.float16, torch.bfloat16) or hidden_states.dim() != 3 or hidden_states.stride(2) != 1:
+            return None
+        w1, b1, w2, b2 = GateState.packed_weights(mod)
+        B, T, _ = hidden_states.shape
+        out = torch.empty((B, num_heads, T), dtype=torch.float32, device=hidden_states.device)
+        return ops.GatePredictor(hidden_states, w1, b1, w2, b2, scaling=float(scaling), out=out)
+
+    @staticmethod
+    def finish_predictor(mod: nn.Module, gp, num_heads: int) -> None:
+        gate = gp.out.unsqueeze(3)
+        mod.last_gate_all_probs = gate
+        mod.last_gate_avg_prob = gate.mean(dim=0).view(num_heads, -1).mean(dim=1)
+
+    @staticmethod
     def evaluate(mod: nn.Module, hidden_states: torch.Tensor, num_heads: int) -> Optional[torch.Tensor]:
         """Gate probabilities, broadcastable to (B,H,T,1), fp32, WITHOUT the scaling factor; sets
         last_gate_avg_prob / last_gate_all_probs like bert_attention.py:299,329-331."""
@@ -160,8 +180,11 @@ def attention_core(
     q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, softmax_fn, scale: float = 1.0, scale_div: float = 0.0,
     attention_mask: Optional[torch.Tensor] = None, clamp_min: bool = False, detect_causal: bool = False,
     gate: Optional[torch.Tensor] = None, fq: Optional[AttnFakeQuant] = None, mask_min: Optional[float] = None,
+    gate_mlp=None,
 ) -> torch.Tensor:
-    """Fused path: logical (B,H,S,d) views in, (B,Sq,H*d) context out (head merge is free)."""
+    """Fused path: logical (B,H,S,d) views in, (B,Sq,H*d) context out (head merge is free).  `gate_mlp`
+    (ops.GatePredictor): the per-token gate is evaluated inside the attention kernel where the library supports that
+    (full-row 16-bit kernel, <= 16 hidden units), else by `ops.gate_fwd` first."""
     B, H, Sq, D = q.shape
     Sk = k.shape[2]
     spec = spec_of(softmax_fn)
@@ -174,8 +197,25 @@ def attention_core(
     if mask_min is None:
         mdt = attention_mask.dtype if attention_mask is not None and attention_mask.is_floating_point() else q.dtype
         mask_min = float(torch.finfo(mdt).min)
-    out = ops.attn_fwd(q, k, v, softmax=spec, scale=scale, scale_div=scale_div, key_pad_mask=pad, full_mask=full, causal=causal,
-                       clamp_min=clamp_min, mask_min=mask_min, gate=gate, fq=fq)
+    kw = dict(softmax=spec, scale=scale, scale_div=scale_div, key_pad_mask=pad, full_mask=full, causal=causal,
+              clamp_min=clamp_min, mask_min=mask_min, fq=fq)
+    out = None
+    if gate_mlp is not None:
+        units = 0 if gate_mlp.w1.dim() == 2 else gate_mlp.w1.shape[1]
+        if full is None and ops.fused_gate_ok(B, H, Sq, Sk, D, q.dtype, clip=bool(spec.clip), fq=fq is not None, units=units):
+            try:
+                out = ops.attn_fwd(q, k, v, gate_mlp=gate_mlp, **kw)
+            except _lib.OehError as e:  # a mask / option combination the full-row kernel does not take after all
+                if e.code != -95:
+                    raise
+        if out is None:
+            gp = gate_mlp
+            g = ops.gate_fwd(gp.hidden, H, gp.w1, gp.b1, gp.w2, gp.b2, scaling=1.0)
+            if gp.out is not None:
+                gp.out.copy_(g[..., 0])
+            gate = g * gp.scaling
+    if out is None:
+        out = ops.attn_fwd(q, k, v, gate=gate, **kw)
     return out.permute(0, 2, 1, 3).reshape(B, Sq, H * D)
 
 

@@ -112,13 +112,21 @@ class BertSelfAttentionWithExtras(nn.Module):
         use_cache = past_key_value is not None
         q, k, v, attention_mask = self._project(hidden_states, attention_mask, encoder_hidden_states, encoder_attention_mask, past_key_value)
         new_past = (k, v) if self.is_decoder else None
-        gate = GateState.evaluate(self, hidden_states, self.num_attention_heads)
-        if gate is not None and self.attn_gate_type != AttentionGateType.unconditional_per_head:
-            gate = gate * self.gate_scaling_factor  # context *= gate * scaling (bert_attention.py:327)
+        fusable = self._fusable(head_mask, output_attentions)
+        # conditional per-token gate: evaluated inside the attention kernel when the fused path runs
+        gp = GateState.predictor(self, hidden_states, self.num_attention_heads, self.gate_scaling_factor) if fusable else None
+        gate = None
+        if gp is None:
+            gate = GateState.evaluate(self, hidden_states, self.num_attention_heads)
+            if gate is not None and self.attn_gate_type != AttentionGateType.unconditional_per_head:
+                gate = gate * self.gate_scaling_factor  # context *= gate * scaling (bert_attention.py:327)
         div = math.sqrt(self.attention_head_size)
         probs = None
-        if self._fusable(head_mask, output_attentions):
-            context = attention_core(q, k, v, softmax_fn=self.softmax_fn, scale_div=div, attention_mask=attention_mask, gate=gate)
+        if fusable:
+            context = attention_core(q, k, v, softmax_fn=self.softmax_fn, scale_div=div, attention_mask=attention_mask, gate=gate,
+                                     gate_mlp=gp)
+            if gp is not None:
+                GateState.finish_predictor(self, gp, self.num_attention_heads)
         else:
             extra = None
             if self.position_embedding_type in ("relative_key", "relative_key_query"):

@@ -66,6 +66,10 @@ int validate(const oeh_attn_desc* d, const void* q, const void* k, const void* v
   if (d->softmax_base != OEH_SOFTMAX_VANILLA && d->softmax_base != OEH_SOFTMAX_ONE) return OEH_EINVAL;
   if (d->key_pad_mask != nullptr && d->key_pad_dtype != OEH_F16 && d->key_pad_dtype != OEH_F32) return OEH_EINVAL;
   if (d->full_mask != nullptr && d->full_mask_dtype != OEH_F16 && d->full_mask_dtype != OEH_F32) return OEH_EINVAL;
+  if (d->gate == nullptr && d->gate_hidden != nullptr) {
+    if (d->gate_w1 == nullptr || d->gate_b1 == nullptr || d->gate_units < 0) return OEH_EINVAL;
+    if (d->gate_units > 0 && (d->gate_w2 == nullptr || d->gate_b2 == nullptr)) return OEH_EINVAL;
+  }
   if (fq != nullptr) {
     const oeh_fq* fs[3] = {&fq->scores, &fq->probs, &fq->ctx};
     for (const oeh_fq* f : fs) {
@@ -156,6 +160,11 @@ void fill_params(AttnParams& P, const oeh_attn_desc* d, const void* q, const voi
   P.full_sb = d->full_mask_stride[0]; P.full_sq = d->full_mask_stride[1];
   P.causal = d->causal ? 1 : 0; P.clamp_min = d->clamp_min ? 1 : 0; P.mask_min = d->mask_min;
   P.gate = d->gate; P.gs_b = d->gate_stride[0]; P.gs_h = d->gate_stride[1]; P.gs_s = d->gate_stride[2];
+  if (d->gate == nullptr && d->gate_hidden != nullptr) {
+    P.gh = d->gate_hidden; P.ghs_b = d->gate_hidden_stride[0]; P.ghs_t = d->gate_hidden_stride[1];
+    P.gw1 = d->gate_w1; P.gb1 = d->gate_b1; P.gw2 = d->gate_w2; P.gb2 = d->gate_b2;
+    P.g_units = d->gate_units; P.g_scaling = d->gate_scaling; P.g_out = d->gate_out;
+  }
   if (fq != nullptr) {
     P.fq_s = make_fq(&fq->scores); P.fq_p = make_fq(&fq->probs); P.fq_c = make_fq(&fq->ctx);
     P.ctx_before_gate = fq->ctx_quant_before_gate ? 1 : 0;
@@ -196,6 +205,10 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
   if (rc != OEH_OK) return rc;
   const Variant var = pick_variant(desc, q, k, v, o, fq);
   if (var == V_NONE) return OEH_ENOTSUP;
+  if (desc->gate == nullptr && desc->gate_hidden != nullptr) {  // fused gate predictor: full-row 16-bit variant, 16-B aligned rows
+    if (var != V_FAST || desc->gate_units > 16) return OEH_ENOTSUP;  // one 16-unit MFMA tile of hidden units
+    if (((reinterpret_cast<uintptr_t>(desc->gate_hidden) | (uintptr_t)(desc->gate_hidden_stride[0] * 2) | (uintptr_t)(desc->gate_hidden_stride[1] * 2)) & 15) != 0) return OEH_EALIGN;
+  }
   AttnParams P;
   fill_params(P, desc, q, k, v, o, fq);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

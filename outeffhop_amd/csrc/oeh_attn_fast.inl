@@ -42,7 +42,13 @@ __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
 template <int NT, int D>
 constexpr int fast_occupancy() { return D >= 128 ? 1 : 3; }  // what the LDS rings allow (6 tiles of 64 x 2D bytes)
 
-template <int NT, int D, int IN, bool CLIP>
+// GATE: the conditional per-token gate (include/oeh.h: gate_hidden ...) is computed in the kernel.  The layer-input rows
+// of the workgroup arrive as one more K-shaped LDS-DMA tile; the first predictor layer is ONE small product on the matrix
+// cores per wave, logits^T = W1 X^T, in the same swapped orientation as the scores (token on the lane, hidden units over
+// registers), with the weights rounded to the storage dtype - what the reference's Linear does in a 16-bit model; the
+// second layer, the sigmoid and the scaling are a few VALU operations per lane and one register carries the result to the
+// epilogue.  A separate variant: the others carry none of it.
+template <int NT, int D, int IN, bool CLIP, bool GATE>
 __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_kernel(const AttnParams P) {
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
   constexpr int KT = NT / 4;
@@ -147,9 +153,45 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
       glds16(qbase + (long)qr * P.qs_s + (pch ^ swz_k<D>(row)) * 8, qslot + j * 1024);
     }
   }
+  // GATE: this workgroup's 64 rows of the layer input, head h's slice, as a K-shaped tile in K ring slot R-1 (first used by
+  // K tile R-1, issued after the gate has been formed); and the lane's share of the predictor weights (hidden unit c,
+  // inputs 8g.. of each 32-wide k-step; first-layer bias and second-layer weights of units 4g..4g+3), requested in the
+  // same round as everything else
+  f4 gw[KS][2];
+  f4 gb1v = f4{0.f, 0.f, 0.f, 0.f}, gw2v = f4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (GATE) {
+    const unsigned short* xbase = reinterpret_cast<const unsigned short*>(P.gh) + (long)b * P.ghs_b + (long)h * D;
+    const unsigned xslot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((R - 1) * TILEB + wave * G * 1024));
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int row = piece_row(j);
+      int xr = qt * 64 + row;
+      xr = xr < P.Sq ? xr : P.Sq - 1;
+      glds16(xbase + (long)xr * P.ghs_t + (pch ^ swz_k<D>(row)) * 8, xslot + j * 1024);
+    }
+  }
   // stream prologue: two tiles in flight
   issue_next();
   if (1 < T) issue_next();
+  if constexpr (GATE) {
+    const int mm = P.g_units > 0 ? P.g_units : 1;  // <= 16 (host)
+    const bool uv = c < mm;
+    const float* wr = P.gw1 + ((long)h * mm + (uv ? c : 0)) * D + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      gw[ks][0] = *reinterpret_cast<const f4*>(wr + 32 * ks);
+      gw[ks][1] = *reinterpret_cast<const f4*>(wr + 32 * ks + 4);
+      if (!uv) gw[ks][0] = gw[ks][1] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int u = 4 * g + r;
+      if (u < mm) {
+        gb1v[r] = P.gb1[(long)h * mm + u];
+        gw2v[r] = P.g_units > 0 ? P.gw2[(long)h * mm + u] : 1.0f;
+      }
+    }
+  }
   const bool has_pad = P.pad != nullptr;
   if (has_pad) {  // (compiler-visible loads: its wait for them also covers the transfers above, which the next wait needs anyway)
     for (int i = tid; i < NT * 16; i += 256) lds_pad[i] = (i < P.Sk) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + i) : 0.0f;
@@ -163,6 +205,35 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
   u4 qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u4*>(kaddr[ks] + (2 * R - 1) * TILEB + wave * 16 * ROWB);
+  float gate_row = 1.0f;  // GATE: sigmoid(logit) * scaling of this lane's query row
+  if constexpr (GATE) {
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u4 xf = *reinterpret_cast<const u4*>(kaddr[ks] + (R - 1) * TILEB + wave * 16 * ROWB);
+      u4 wf;
+      if constexpr (IN == IN_BF16) wf = u4{pack2_bf16(gw[ks][0][0], gw[ks][0][1]), pack2_bf16(gw[ks][0][2], gw[ks][0][3]), pack2_bf16(gw[ks][1][0], gw[ks][1][1]), pack2_bf16(gw[ks][1][2], gw[ks][1][3])};
+      else wf = u4{pack2_f16(gw[ks][0][0], gw[ks][0][1]), pack2_f16(gw[ks][0][2], gw[ks][0][3]), pack2_f16(gw[ks][1][0], gw[ks][1][1]), pack2_f16(gw[ks][1][2], gw[ks][1][3])};
+      acc = mfma16<IN>(wf, xf, acc);  // rows = hidden units 4g+r, column = token c
+    }
+    float a = 0.0f;
+    if (P.g_units > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a = __builtin_fmaf(__builtin_fmaxf(acc[r] + gb1v[r], 0.0f), gw2v[r], a);  // padded units: w2 = 0
+    } else {
+      a = (g == 0) ? acc[0] + gb1v[0] : 0.0f;  // Linear(D,1): unit 0 only
+    }
+    {  // sum over the 4 lanes (c, c+16, c+32, c+48) of the row
+      auto s1 = __builtin_amdgcn_permlane16_swap(f32_bits(a), f32_bits(a), false, false);
+      a = bits_f32(s1[0]) + bits_f32(s1[1]);
+      auto s2 = __builtin_amdgcn_permlane32_swap(f32_bits(a), f32_bits(a), false, false);
+      a = bits_f32(s2[0]) + bits_f32(s2[1]);
+    }
+    if (P.g_units > 0) a = a + P.gb2[h];
+    a = 1.0f / (1.0f + exp_acc(-a));
+    gate_row = a * P.g_scaling;
+    if (P.g_out != nullptr && g == 0 && qvalid) P.g_out[((long)b * P.H + h) * P.Sq + qrow] = a;
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   // Instruction stream: the 64-key LDS tile is also the unit of control flow.  Every wave of the workgroup runs all
@@ -352,6 +423,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
   const int ce = lane_e & 15, ge = lane_e >> 4;
   float rowscale = CLIP ? 1.0f : inv;
   if (P.gate != nullptr && qvalid) rowscale = rowscale * P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
+  if constexpr (GATE) rowscale = rowscale * gate_row;
   constexpr int XM = (CPR < 8 ? CPR : 8) - 1;
   unsigned char* ebase = lds + wave * (16 * ROWB);
 #pragma unroll
@@ -385,16 +457,23 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
 }
 #undef OEH_STAMP
 
+template <int NT, int D, int IN>
+static void launch_fast_nt_d_in(const AttnParams& P, unsigned grid, hipStream_t st) {
+  const bool gate = P.gh != nullptr;
+  if (P.clip) {
+    if (gate) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, true>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false>), dim3(grid), dim3(256), 0, st, P);
+  } else {
+    if (gate) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, true>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false>), dim3(grid), dim3(256), 0, st, P);
+  }
+}
+
 template <int NT, int D>
 static int launch_fast_nt_d(const AttnParams& P, int in, hipStream_t st) {
   const unsigned grid = (unsigned)(P.nQT * P.nBHpad);
-  if (P.clip) {
-    if (in == IN_BF16) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN_BF16, true>), dim3(grid), dim3(256), 0, st, P);
-    else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN_F16, true>), dim3(grid), dim3(256), 0, st, P);
-  } else {
-    if (in == IN_BF16) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN_BF16, false>), dim3(grid), dim3(256), 0, st, P);
-    else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN_F16, false>), dim3(grid), dim3(256), 0, st, P);
-  }
+  if (in == IN_BF16) launch_fast_nt_d_in<NT, D, IN_BF16>(P, grid, st);
+  else launch_fast_nt_d_in<NT, D, IN_F16>(P, grid, st);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -28,6 +28,13 @@ struct AttnParams {
   float mask_min;
   const float* gate;          // null = none
   long gs_b, gs_h, gs_s;
+  // fused gate predictor (null gh = none): layer input rows, per-head weights, optional copy of the gate (include/oeh.h)
+  const void* gh;
+  long ghs_b, ghs_t;
+  const float *gw1, *gb1, *gw2, *gb2;
+  int g_units;
+  float g_scaling;
+  float* g_out;
   FqP fq_s, fq_p, fq_c;
   int ctx_before_gate;
   // launch geometry

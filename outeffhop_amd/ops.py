@@ -96,6 +96,7 @@ def attn_fwd(
     gate: Optional[torch.Tensor] = None,
     fq: Optional[AttnFakeQuant] = None,
     out: Optional[torch.Tensor] = None,
+    gate_mlp: Optional["GatePredictor"] = None,
     _prepared: Optional[list] = None,
 ) -> torch.Tensor:
     """Fused attention core.  q,k,v are logical (B,H,S,D) views (any batch/head/seq strides, unit head-dim
@@ -153,6 +154,28 @@ def attn_fwd(
         keep.append(g)
         d.gate = g.data_ptr()
         d.gate_stride[:] = [g.stride(0), g.stride(1), g.stride(2)]
+    if gate_mlp is not None:
+        if gate is not None:
+            raise ValueError("pass either `gate` (values) or `gate_mlp` (predictor evaluated in the kernel), not both")
+        gm = gate_mlp
+        hid = gm.hidden
+        _need_gpu(hid, gm.w1, gm.b1, gm.w2, gm.b2, gm.out)
+        if hid.shape != (B, Sq, H * D) or hid.dtype != q.dtype or hid.stride(2) != 1:
+            raise ValueError(f"gate_mlp.hidden must be (B,Sq,H*D) = {(B, Sq, H * D)} in the dtype of q with a contiguous last dim")
+        f32c = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()  # noqa: E731
+        w1, b1, w2, b2 = f32c(gm.w1), f32c(gm.b1), f32c(gm.w2), f32c(gm.b2)
+        keep.extend([hid, w1, b1, w2, b2, gm.out])
+        d.gate_hidden = hid.data_ptr()
+        d.gate_hidden_stride[:] = [hid.stride(0), hid.stride(1)]
+        d.gate_w1, d.gate_b1 = w1.data_ptr(), b1.data_ptr()
+        d.gate_units = 0 if w1.dim() == 2 else w1.shape[1]
+        if d.gate_units > 0:
+            d.gate_w2, d.gate_b2 = w2.data_ptr(), b2.data_ptr()
+        d.gate_scaling = float(gm.scaling)
+        if gm.out is not None:
+            if gm.out.shape != (B, H, Sq) or gm.out.dtype != torch.float32 or not gm.out.is_contiguous():
+                raise ValueError("gate_mlp.out must be a contiguous fp32 (B,H,Sq) tensor")
+            d.gate_out = gm.out.data_ptr()
     fqd = None
     if fq is not None and (fq.scores or fq.probs or fq.ctx):
         fqd = oeh_fq_desc()
@@ -168,6 +191,28 @@ def attn_fwd(
     rc = lib.oeh_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), None if fqd is None else C.byref(fqd), _stream())
     _lib.check(rc, "oeh_attn_fwd")
     return out
+
+
+@dataclass
+class GatePredictor:
+    """The conditional per-token gate evaluated INSIDE the attention kernel (include/oeh.h: gate_hidden ...): the layer
+    input `hidden` (B,Sq,H*D) and the per-head predictor weights laid out as for `gate_fwd`; `out` (B,H,Sq) fp32, optional,
+    receives the gate probabilities (without `scaling`).  Only the full-row 16-bit kernel takes it (`fused_gate_ok`)."""
+    hidden: torch.Tensor
+    w1: torch.Tensor
+    b1: torch.Tensor
+    w2: Optional[torch.Tensor] = None
+    b2: Optional[torch.Tensor] = None
+    scaling: float = 1.0
+    out: Optional[torch.Tensor] = None
+
+
+def fused_gate_ok(B, H, Sq, Sk, D, dtype, clip: bool = False, fq: bool = False, units: int = 0) -> bool:
+    """True when `attn_fwd(..., gate_mlp=...)` is supported for this problem (else: `gate_fwd` + `gate=`)."""
+    if dtype not in (torch.float16, torch.bfloat16) or fq or int(units) > 16:
+        return False
+    v = attn_variant(B, H, Sq, Sk, D, dtype, clip=clip)
+    return v is not None and v.startswith("fast16/")
 
 
 class PreparedAttn:

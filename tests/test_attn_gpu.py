@@ -395,3 +395,42 @@ def test_one_pass_padding_trim_and_long_rows(ops):
         want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=0.125, pad_mask=padm, **SPECS["softmax1"])
         got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), scale=0.125, key_pad_mask=torch.from_numpy(padm).cuda(), mask_min=fmin)
         _check(got, want, msg=f"case {n}")
+
+
+@pytest.mark.parametrize("units,dtype", [(16, torch.float16), (0, torch.float16), (7, torch.bfloat16), (64, torch.float16)])
+def test_gate_predictor_fused_in_kernel(ops, units, dtype):
+    """The conditional per-token gate evaluated inside the full-row kernel (include/oeh.h: gate_hidden ...): first layer on
+    the matrix cores with weights rounded to the storage dtype, so it agrees with oeh_gate_fwd (fp32 weights) to ~1e-4 in
+    the gate and to the usual output tolerance; > 16 hidden units are refused (callers fall back to gate_fwd)."""
+    B, H, S, D = 3, 4, 100, 64
+    fmin = float(np.finfo(np.float32).min)
+    q, k, v = _rand((B, S, H * D), 5001, dtype=dtype), _rand((B, S, H * D), 5002, dtype=dtype), _rand((B, S, H * D), 5003, dtype=dtype)
+    view = lambda t: t.cuda().view(B, S, H, D).permute(0, 2, 1, 3)  # noqa: E731
+    hidden = _rand((B, S, H * D), 5004, dtype=dtype).cuda()
+    g = torch.Generator().manual_seed(5005)
+    mm = max(units, 1)
+    w1 = (torch.randn((H, mm, D) if units else (H, D), generator=g) * 0.2).cuda()
+    b1 = (torch.randn((H, mm) if units else (H,), generator=g) * 0.2).cuda()
+    w2 = (torch.randn((H, mm), generator=g) * 0.5).cuda() if units else None
+    b2 = torch.randn((H,), generator=g).cuda() if units else None
+    pad = torch.from_numpy(_pad_mask(B, S, [100, 63, 1], fmin)).cuda()
+    gp = ops.GatePredictor(hidden, w1, b1, w2, b2, scaling=4.0, out=torch.empty((B, H, S), dtype=torch.float32, device="cuda"))
+    if units > 16:
+        from outeffhop_amd._lib import OehError
+        assert not ops.fused_gate_ok(B, H, S, S, D, dtype, units=units)
+        with pytest.raises(OehError) as ei:
+            ops.attn_fwd(view(q), view(k), view(v), scale_div=8.0, gate_mlp=gp)
+        assert ei.value.code == -95
+        return
+    assert ops.fused_gate_ok(B, H, S, S, D, dtype, units=units)
+    sep_gate = ops.gate_fwd(hidden, H, w1, b1, w2, b2, scaling=1.0)
+    want = ops.attn_fwd(view(q), view(k), view(v), scale_div=8.0, key_pad_mask=pad, mask_min=fmin, gate=sep_gate * 4.0)
+    got = ops.attn_fwd(view(q), view(k), view(v), scale_div=8.0, key_pad_mask=pad, mask_min=fmin, gate_mlp=gp)
+    gtol = 2e-3 if dtype == torch.float16 else 1.5e-2  # weights rounded to 11 / 8 significant bits
+    assert float((gp.out - sep_gate[..., 0]).abs().max()) < gtol
+    tol = F16_TOL if dtype == torch.float16 else dict(atol=2e-2, rtol=2e-2)
+    _check(got, _np32(want), tol=dict(atol=4 * tol["atol"], rtol=4 * tol["rtol"]), msg="fused vs separate gate")  # gate_scaling = 4
+    # and against the oracle with the gate the kernel reported
+    want_o = O.attn_core(_np32(view(q)), _np32(view(k)), _np32(view(v)), scale=8.0, scale_is_divisor=True, pad_mask=_pad_mask(B, S, [100, 63, 1], fmin),
+                         gate=(gp.out.cpu().numpy() * 4.0)[..., None], **SPECS["softmax1"])
+    _check(got, want_o, tol=dict(atol=4 * tol["atol"], rtol=tol["rtol"]), msg="fused gate vs oracle")
