@@ -40,7 +40,10 @@ __device__ __forceinline__ float row_allreduce_max(float x) {
 template <int D, int MQ>
 constexpr int flash_occupancy() { return D >= 128 ? 1 : 3; }
 
-template <int D, int IN, int MQ, bool PAD>
+// GATE: the conditional per-token gate is computed in the kernel exactly as in the full-row kernel (oeh_attn_fast.inl:
+// layer-input rows as K-shaped LDS-DMA tiles, first predictor layer on the matrix cores).  The input rows borrow stage 1
+// at start-up, so stage 1 of the K/V stream is issued later (with stage 2, once the gate has been formed).
+template <int D, int IN, int MQ, bool PAD, bool GATE>
 __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flash_kernel(const AttnParams P) {
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
   static_assert(MQ == 1 || MQ == 2, "one or two query blocks per wave");
@@ -162,8 +165,43 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
       }
     }
   }
+  f4 gw[MQ][KS][2];                      // GATE: the lane's share of the predictor weights, per block (same for both: one head)
+  f4 gb1v = f4{0.f, 0.f, 0.f, 0.f}, gw2v = f4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (GATE) {  // the workgroup's layer-input rows, head h's slice, slab t as a K-shaped tile at t*TILEB of stage 1
+    const unsigned char* xbase = reinterpret_cast<const unsigned char*>(P.gh) + 2 * ((long)b * P.ghs_b + (long)h * D);
+    const unsigned xslot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(1 * STAGEB + wave * G * 1024));
+#pragma unroll
+    for (int t = 0; t < MQ; ++t) {
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int row = piece_row(j);
+        int xr = 64 * slab[t] + row;
+        xr = xr < Sq ? xr : Sq - 1;
+        glds16_s_nt(xbase, 2u * (unsigned)(xr * P.ghs_t + (pch ^ swz_k<D>(row)) * 8), xslot + t * TILEB + j * 1024);
+      }
+    }
+  }
   issue_next();
-  if (1 < n_kt) issue_next();
+  if (!GATE && 1 < n_kt) issue_next();
+  if constexpr (GATE) {  // weights: hidden unit c, inputs 8g.. of each 32-wide k-step; b1 / w2 of units 4g..4g+3
+    const int mm = P.g_units > 0 ? P.g_units : 1;  // <= 16 (host)
+    const bool uv = c < mm;
+    const float* wr = P.gw1 + ((long)h * mm + (uv ? c : 0)) * D + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      gw[0][ks][0] = *reinterpret_cast<const f4*>(wr + 32 * ks);
+      gw[0][ks][1] = *reinterpret_cast<const f4*>(wr + 32 * ks + 4);
+      if (!uv) gw[0][ks][0] = gw[0][ks][1] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int u = 4 * g + r;
+      if (u < mm) {
+        gb1v[r] = P.gb1[(long)h * mm + u];
+        gw2v[r] = P.g_units > 0 ? P.gw2[(long)h * mm + u] : 1.0f;
+      }
+    }
+  }
   // Q and K tile 0 landed, for every wave: all but the G (V tile 0) + 2G (stage 1) younger transfers
   auto wait_vm = [&](auto nc) {  // s_waitcnt vmcnt(N * G), N compile-time
     constexpr int N = decltype(nc)::value * G;
@@ -194,8 +232,8 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
     for (int sft = 1; sft < 64; sft <<= 1) last = max(last, __shfl_xor(last, sft));
     if (lane == 0) lds_last[wave] = last;
   }
-  if (1 < n_kt) wait_vm(std::integral_constant<int, 3>{});
-  else wait_vm(std::integral_constant<int, 1>{});
+  if (!GATE && 1 < n_kt) wait_vm(std::integral_constant<int, 3>{});
+  else wait_vm(std::integral_constant<int, 1>{});  // (GATE: stage 1 is not in flight yet - its slot holds the input rows)
   barrier_mem();
   if constexpr (PAD) {
     const int last = max(max(lds_last[0], lds_last[1]), max(lds_last[2], lds_last[3]));
@@ -219,6 +257,45 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
       qf[j][ks] = *reinterpret_cast<const u4*>(kaddr[ks] + (R - 1) * STAGEB + j * TILEB + wave * 16 * ROWB);
+  float gate_row[MQ];  // GATE: sigmoid(logit) * scaling of this lane's query row in block j
+#pragma unroll
+  for (int j = 0; j < MQ; ++j) gate_row[j] = 1.0f;
+  if constexpr (GATE) {
+    u4 wf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const f4 w0 = gw[0][ks][0], w1 = gw[0][ks][1];
+      if constexpr (IN == IN_BF16) wf[ks] = u4{pack2_bf16(w0[0], w0[1]), pack2_bf16(w0[2], w0[3]), pack2_bf16(w1[0], w1[1]), pack2_bf16(w1[2], w1[3])};
+      else wf[ks] = u4{pack2_f16(w0[0], w0[1]), pack2_f16(w0[2], w0[3]), pack2_f16(w1[0], w1[1]), pack2_f16(w1[2], w1[3])};
+    }
+#pragma unroll
+    for (int j = 0; j < MQ; ++j) {
+      f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const u4 xf = *reinterpret_cast<const u4*>(kaddr[ks] + 1 * STAGEB + j * TILEB + wave * 16 * ROWB);
+        acc = mfma16<IN>(wf[ks], xf, acc);  // rows = hidden units 4g+r, column = token c
+      }
+      float a = 0.0f;
+      if (P.g_units > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a = __builtin_fmaf(__builtin_fmaxf(acc[r] + gb1v[r], 0.0f), gw2v[r], a);  // padded units: w2 = 0
+      } else {
+        a = (g == 0) ? acc[0] + gb1v[0] : 0.0f;  // Linear(D,1): unit 0 only
+      }
+      {  // sum over the 4 lanes (c, c+16, c+32, c+48) of the row
+        auto s1 = __builtin_amdgcn_permlane16_swap(f32_bits(a), f32_bits(a), false, false);
+        a = bits_f32(s1[0]) + bits_f32(s1[1]);
+        auto s2 = __builtin_amdgcn_permlane32_swap(f32_bits(a), f32_bits(a), false, false);
+        a = bits_f32(s2[0]) + bits_f32(s2[1]);
+      }
+      if (P.g_units > 0) a = a + P.gb2[h];
+      a = 1.0f / (1.0f + exp_acc(-a));
+      gate_row[j] = a * P.g_scaling;
+      const int qrow = rb[j] + c;
+      if (P.g_out != nullptr && g == 0 && qrow < Sq) P.g_out[((long)b * P.H + h) * Sq + qrow] = a;
+    }
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   constexpr bool has_pad = PAD;         // a kernel variant, not a branch: merging the two paths inside the loop costs a
@@ -352,9 +429,10 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
     if constexpr (FIRST) {
       // V tile 0 landed for every wave (stage 1 may still be in flight); every wave has its Q operands, so the Q stage
       // can now be refilled with stage 2
-      if (1 < n_kt) wait_vm(std::integral_constant<int, 2>{});
+      if (!GATE && 1 < n_kt) wait_vm(std::integral_constant<int, 2>{});
       else wait_vm(std::integral_constant<int, 0>{});
       barrier_mem();
+      if (GATE && 1 < n_kt) issue_next();  // stage 1, held back while its slot carried the gate's input rows
       if (2 < n_kt) issue_next();
     }
     // O^T += V^T P^T and l += 1^T P^T; every V^T fragment is read once and used by all active blocks
@@ -417,6 +495,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
     if (P.base != 0) den = den + __builtin_amdgcn_exp2f(mcneg[j]);  // softmax_1: + 1*exp(-reference)  (vutils/softmax_1.py:18-20)
     float rowscale = 1.0f / den;
     if (P.gate != nullptr && qrow < Sq) rowscale = rowscale * P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
+    if constexpr (GATE) rowscale = rowscale * gate_row[j];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       u2 w;
@@ -448,17 +527,23 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
 }
 #undef OEH_STAMP
 
+template <int D, int MQ, int IN>
+static void launch_flash_d_mq_in(const AttnParams& P, unsigned grid, hipStream_t st) {
+  const bool pad = P.pad != nullptr, gate = P.gh != nullptr;
+  if (pad) {
+    if (gate) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, true>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false>), dim3(grid), dim3(256), 0, st, P);
+  } else {
+    if (gate) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, true>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false>), dim3(grid), dim3(256), 0, st, P);
+  }
+}
+
 template <int D, int MQ>
 static int launch_flash_d_mq(const AttnParams& P, int in, hipStream_t st) {
   const unsigned grid = (unsigned)(P.nQT * P.nBHpad);
-  const bool pad = P.pad != nullptr;
-  if (in == IN_BF16) {
-    if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN_BF16, MQ, true>), dim3(grid), dim3(256), 0, st, P);
-    else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN_BF16, MQ, false>), dim3(grid), dim3(256), 0, st, P);
-  } else {
-    if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN_F16, MQ, true>), dim3(grid), dim3(256), 0, st, P);
-    else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN_F16, MQ, false>), dim3(grid), dim3(256), 0, st, P);
-  }
+  if (in == IN_BF16) launch_flash_d_mq_in<D, MQ, IN_BF16>(P, grid, st);
+  else launch_flash_d_mq_in<D, MQ, IN_F16>(P, grid, st);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -197,7 +197,7 @@ def attn_fwd(
 class GatePredictor:
     """The conditional per-token gate evaluated INSIDE the attention kernel (include/oeh.h: gate_hidden ...): the layer
     input `hidden` (B,Sq,H*D) and the per-head predictor weights laid out as for `gate_fwd`; `out` (B,H,Sq) fp32, optional,
-    receives the gate probabilities (without `scaling`).  Only the full-row 16-bit kernel takes it (`fused_gate_ok`)."""
+    receives the gate probabilities (without `scaling`).  The 16-bit MFMA kernels (full-row and one-pass) take it (`fused_gate_ok`)."""
     hidden: torch.Tensor
     w1: torch.Tensor
     b1: torch.Tensor
@@ -212,7 +212,7 @@ def fused_gate_ok(B, H, Sq, Sk, D, dtype, clip: bool = False, fq: bool = False, 
     if dtype not in (torch.float16, torch.bfloat16) or fq or int(units) > 16:
         return False
     v = attn_variant(B, H, Sq, Sk, D, dtype, clip=clip)
-    return v is not None and v.startswith("fast16/")
+    return v is not None and (v.startswith("fast16/") or v.startswith("flash16/"))
 
 
 class PreparedAttn:

@@ -95,16 +95,25 @@ class OPTAttentionWithExtras(nn.Module):
             raise ValueError(f"Attention mask should be of size {(bsz, 1, tgt_len, src_len)}, but is {attention_mask.size()}")
         if layer_head_mask is not None and layer_head_mask.size() != (self.num_heads,):
             raise ValueError(f"Head mask for a single layer should be of size {(self.num_heads,)}, but is {layer_head_mask.size()}")
-        gate = GateState.evaluate(self, hidden_states, self.num_heads)
-        if gate is not None and self.attn_gate_type != AttentionGateType.unconditional_per_head:
-            gate = gate * self.gate_scaling_factor
         fusable = (spec_of(self.softmax_fn) is not None and layer_head_mask is None and not output_attentions
                    and not (self.training and self.dropout > 0.0)
                    and not has_hooks(self.attn_scores, self.attn_probs_before_dropout, self.attn_probs_after_dropout))
+        # conditional per-token gate: evaluated inside the attention kernel when the fused path runs (self-attention only:
+        # the predictor acts on the query-side layer input)
+        gp = None
+        if fusable and key_value_states is None and past_key_value is None:
+            gp = GateState.predictor(self, hidden_states, self.num_heads, self.gate_scaling_factor)
+        gate = None
+        if gp is None:
+            gate = GateState.evaluate(self, hidden_states, self.num_heads)
+            if gate is not None and self.attn_gate_type != AttentionGateType.unconditional_per_head:
+                gate = gate * self.gate_scaling_factor
         weights = None
         if fusable:
             merged = attention_core(q, k, v, softmax_fn=self.softmax_fn, scale=1.0, attention_mask=attention_mask,
-                                    clamp_min=attention_mask is not None, detect_causal=True, gate=gate)
+                                    clamp_min=attention_mask is not None, detect_causal=True, gate=gate, gate_mlp=gp)
+            if gp is not None:
+                GateState.finish_predictor(self, gp, self.num_heads)
         else:
             hm = None if layer_head_mask is None else layer_head_mask.view(1, -1, 1, 1)
             drop = (lambda p: nn.functional.dropout(p, p=self.dropout, training=self.training))

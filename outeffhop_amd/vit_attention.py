@@ -63,13 +63,18 @@ class ViTSelfAttentionWithExtras(nn.Module):
         H, d = self.num_attention_heads, self.attention_head_size
         q, k, v = self.qkv(x).reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4).unbind(0)  # (B,H,N,d) views, unit d stride
         q, k = self.q_norm(q), self.k_norm(k)
-        gate = GateState.evaluate(self, x, H)
-        if gate is not None and self.attn_gate_type != AttentionGateType.unconditional_per_head:
-            gate = gate * self.gate_scaling_factor
         fusable = (spec_of(self.softmax_fn) is not None and not (self.training and self.attn_drop.p > 0.0)
                    and not has_hooks(self.attn_scores, self.attn_probs_before_dropout, self.attn_probs_after_dropout))
+        gp = GateState.predictor(self, x, H, self.gate_scaling_factor) if fusable else None  # gate evaluated in the kernel
+        gate = None
+        if gp is None:
+            gate = GateState.evaluate(self, x, H)
+            if gate is not None and self.attn_gate_type != AttentionGateType.unconditional_per_head:
+                gate = gate * self.gate_scaling_factor
         if fusable:
-            merged = attention_core(q, k, v, softmax_fn=self.softmax_fn, scale=self.scale, gate=gate)
+            merged = attention_core(q, k, v, softmax_fn=self.softmax_fn, scale=self.scale, gate=gate, gate_mlp=gp)
+            if gp is not None:
+                GateState.finish_predictor(self, gp, H)
         else:
             ctx, _, _ = unfused_core(q, k, v, softmax_fn=self.softmax_fn, scale=self.scale, scores_tap=self.attn_scores,
                                      probs_tap=self.attn_probs_before_dropout, dropout=self.attn_drop,

@@ -434,3 +434,41 @@ def test_gate_predictor_fused_in_kernel(ops, units, dtype):
     want_o = O.attn_core(_np32(view(q)), _np32(view(k)), _np32(view(v)), scale=8.0, scale_is_divisor=True, pad_mask=_pad_mask(B, S, [100, 63, 1], fmin),
                          gate=(gp.out.cpu().numpy() * 4.0)[..., None], **SPECS["softmax1"])
     _check(got, want_o, tol=dict(atol=4 * tol["atol"], rtol=tol["rtol"]), msg="fused gate vs oracle")
+
+
+@pytest.mark.parametrize("mq", [1, 2])
+@pytest.mark.parametrize("units", [0, 12])
+def test_gate_predictor_fused_one_pass(ops, mq, units):
+    """The in-kernel gate predictor on the one-pass kernel (both workgroup shapes): causal rows longer than one tile, with
+    and without key padding, against gate_fwd + the `gate` argument and against the oracle."""
+    from outeffhop_amd import _lib
+
+    lib = _lib.load()
+    B, H, S, D = 2, 3, 300, 64
+    fmin = float(np.finfo(np.float32).min)
+    q = (_rand((B, S, H * D), 6001).float() * 0.125).half()
+    k, v, hidden = _rand((B, S, H * D), 6002), _rand((B, S, H * D), 6003), _rand((B, S, H * D), 6004).cuda()
+    view = lambda t: t.cuda().view(B, S, H, D).permute(0, 2, 1, 3)  # noqa: E731
+    g = torch.Generator().manual_seed(6005)
+    mm = max(units, 1)
+    w1 = (torch.randn((H, mm, D) if units else (H, D), generator=g) * 0.2).cuda()
+    b1 = (torch.randn((H, mm) if units else (H,), generator=g) * 0.2).cuda()
+    w2 = (torch.randn((H, mm), generator=g) * 0.5).cuda() if units else None
+    b2 = torch.randn((H,), generator=g).cuda() if units else None
+    sep_gate = ops.gate_fwd(hidden, H, w1, b1, w2, b2, scaling=1.0)
+    lib.oeh_debug_set_variant(0, mq)
+    try:
+        for pad in (None, torch.from_numpy(_pad_mask(B, S, [300, 170], fmin)).cuda()):
+            assert ops.attn_variant(B, H, S, S, D).startswith(f"flash16/MQ{mq}/")
+            gp = ops.GatePredictor(hidden, w1, b1, w2, b2, scaling=1.0, out=torch.empty((B, H, S), dtype=torch.float32, device="cuda"))
+            kw = dict(causal=True, clamp_min=True, key_pad_mask=pad, mask_min=fmin)
+            want = ops.attn_fwd(view(q), view(k), view(v), gate=sep_gate, **kw)
+            got = ops.attn_fwd(view(q), view(k), view(v), gate_mlp=gp, **kw)
+            assert float((gp.out - sep_gate[..., 0]).abs().max()) < 2e-3
+            _check(got, _np32(want), tol=dict(atol=2e-3, rtol=2e-3), msg=f"fused vs separate gate, pad={pad is not None}")
+            want_o = O.attn_core(_np32(view(q)), _np32(view(k)), _np32(view(v)), causal=True, clamp_min=True,
+                                 pad_mask=None if pad is None else _pad_mask(B, S, [300, 170], fmin), gate=gp.out.cpu().numpy()[..., None],
+                                 **SPECS["softmax1"])
+            _check(got, want_o, msg=f"fused gate vs oracle, pad={pad is not None}")
+    finally:
+        lib.oeh_debug_set_variant(0, 0)

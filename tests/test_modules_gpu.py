@@ -219,3 +219,45 @@ def test_int8_modules_calibrate_fix_eval(oa, fam):
             step = float(g[f"{pre}.q.out_proj.activation_quantizer.delta"])
             err = np.abs(got - ref)
             assert err.max() <= 3.05 * step and (err > 0.5 * step).mean() < 0.15, (pre, err.max(), step, (err > 0.5 * step).mean())
+
+
+def test_gated_modules_in_16bit_use_the_in_kernel_predictor(oa):
+    """fp16 modules with the conditional per-token gate: the predictor is evaluated inside the attention kernel (BERT:
+    full-row kernel, OPT causal S > 128: one-pass kernel); output and the last_gate_* bookkeeping agree with the fp32 module
+    (separate gate kernel + general kernel) to fp16 accuracy."""
+    from outeffhop_amd.attention import AttentionGateType as GT
+
+    torch.manual_seed(7)
+    fmin16 = torch.finfo(torch.float16).min
+    # BERT, B=2, S=100, per-head MLP gate
+    m32 = oa.BertSelfAttentionWithExtras(Cfg(), softmax_fn=oa.SOFTMAX_MAPPING["softmax1"], attn_gate_type=GT.conditional_per_token,
+                                         attn_gate_init=0.25, attn_gate_mlp=True).cuda().eval()
+    m16 = oa.BertSelfAttentionWithExtras(Cfg(), softmax_fn=oa.SOFTMAX_MAPPING["softmax1"], attn_gate_type=GT.conditional_per_token,
+                                         attn_gate_init=0.25, attn_gate_mlp=True)
+    m16.load_state_dict(m32.state_dict())
+    m16 = m16.cuda().half().eval()
+    E = Cfg().hidden_size
+    hidden = torch.randn(2, 100, E, device="cuda").half()
+    mask = torch.zeros(2, 1, 1, 100, device="cuda")
+    mask[1, :, :, 77:] = torch.finfo(torch.float32).min
+    with torch.no_grad():
+        want = m32(hidden.float(), attention_mask=mask)[0]
+        got = m16(hidden, attention_mask=mask.half().clamp(min=fmin16))[0]
+    assert got.dtype == torch.float16
+    _close(got, want.cpu().numpy(), "bert gated fp16", dict(atol=4e-3, rtol=4e-3))
+    _close(m16.last_gate_all_probs, m32.last_gate_all_probs.cpu().numpy(), "bert gate probs", dict(atol=2e-3, rtol=2e-3))
+    _close(m16.last_gate_avg_prob, m32.last_gate_avg_prob.cpu().numpy(), "bert gate avg", dict(atol=2e-3, rtol=2e-3))
+    # OPT, causal, S=200 (one-pass kernel), per-head Linear gate
+    o32 = oa.OPTAttentionWithExtras(128, 2, is_decoder=True, softmax_fn=oa.SOFTMAX_MAPPING["softmax1"], attn_gate_type=GT.conditional_per_token,
+                                    attn_gate_init=0.25).cuda().eval()
+    o16 = oa.OPTAttentionWithExtras(128, 2, is_decoder=True, softmax_fn=oa.SOFTMAX_MAPPING["softmax1"], attn_gate_type=GT.conditional_per_token,
+                                    attn_gate_init=0.25)
+    o16.load_state_dict(o32.state_dict())
+    o16 = o16.cuda().half().eval()
+    hs = torch.randn(2, 200, 128, device="cuda").half()
+    cm = torch.full((200, 200), torch.finfo(torch.float32).min, device="cuda").triu(1)[None, None].expand(2, 1, 200, 200).contiguous()
+    with torch.no_grad():
+        want = o32(hs.float(), attention_mask=cm)[0]
+        got = o16(hs, attention_mask=cm.half().clamp(min=fmin16))[0]
+    _close(got, want.cpu().numpy(), "opt gated fp16", dict(atol=6e-3, rtol=6e-3))
+    _close(o16.last_gate_all_probs, o32.last_gate_all_probs.cpu().numpy(), "opt gate probs", dict(atol=2e-3, rtol=2e-3))
