@@ -202,9 +202,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
       }
       if constexpr (FQ) {
         if (fq_s_on) {
-          f4 idx;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) idx[r] = fq_index_fast(x[r], P.fq_s);
+          const f4 idx = fq_index_fast4(x, P.fq_s);
           if (dump_s && qvalid) {
             const unsigned int w = (unsigned int)idx[0] | ((unsigned int)idx[1] << 8) | ((unsigned int)idx[2] << 16) | ((unsigned int)idx[3] << 24);
             dump4(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + key0, w, P.Sk - key0);
@@ -283,9 +281,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
       }
       if constexpr (FQ) {
         if (fq_p_on) {
-          f4 idx;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) idx[r] = fq_index_fast(pv[r], P.fq_p);
+          const f4 idx = fq_index_fast4(pv, P.fq_p);
           if (dump_p && qvalid) {
             const unsigned int w = (unsigned int)idx[0] | ((unsigned int)idx[1] << 8) | ((unsigned int)idx[2] << 16) | ((unsigned int)idx[3] << 24);
             dump4(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + key0, w, P.Sk - key0);

@@ -55,6 +55,31 @@ __device__ __forceinline__ float fq_index_fast(float x, const FqP& f) {
   }
   return __builtin_fminf(__builtin_fmaxf(r + f.zp, 0.0f), f.qmax);
 }
+// Four elements at once with ONE wave-uniform test for the rare exact-division case (a per-element `if` costs an
+// exec-mask save / branch / restore per element: the INT8 kernel had 725 of them).  Inside the rare block the division
+// is computed for all lanes and selected.
+__device__ __forceinline__ f4 fq_index_fast4(f4 x, const FqP& f) {
+  f4 q, r;
+  bool need = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    q[i] = x[i] * f.rscale;
+    r[i] = __builtin_rintf(q[i]);
+    need = need || (__builtin_fabsf(q[i] - r[i]) > f.guard);
+  }
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(need) != 0, 0)) {
+    const float bound = f.qmax + f.zp + 2.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float e = __builtin_rintf(x[i] / f.scale);
+      const bool use = __builtin_fabsf(q[i] - r[i]) > f.guard && __builtin_fabsf(q[i]) <= bound;
+      r[i] = use ? e : r[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __builtin_fminf(__builtin_fmaxf(r[i] + f.zp, 0.0f), f.qmax);
+  return r;
+}
 __device__ __forceinline__ float fq_dequant(float idx, const FqP& f) { return f.scale * (idx - f.zp); }
 
 // exp(y) to ~1 ulp: n = rint(y*log2e), f = y*log2e - n in two fma steps, 2^f by v_exp_f32, ldexp.
