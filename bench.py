@@ -282,6 +282,27 @@ def main():
         torch.cuda.synchronize()
         spread.append(e0.elapsed_time(e1) * 1e3 / L)
     spread.sort()
+    # the same step as one captured HIP graph (SURVEY 8d asks for the variant; reported, never part of `value`)
+    graph_us = None
+    try:
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for args, _ in calls:
+                if fwd(*args, cs) != 0:
+                    raise RuntimeError("capture")
+        for _ in range(3):
+            gr.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        graph_us = e0.elapsed_time(e1) * 1e3 / (30 * L)
+    except Exception:
+        graph_us = None
     if dist is not None:
         tw = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -324,6 +345,7 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "kernel_us": kern_s * 1e6,
                 "kernel_us_p10_p50_p90": [round(spread[4], 2), round(spread[20], 2), round(spread[36], 2)],
+                "kernel_us_hipgraph": None if graph_us is None else round(graph_us, 2),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "flops_per_launch": 4 * B * H * S * S * d, "tflops": 4 * B * H * S * S * d / kern_s / 1e12,
             },
