@@ -208,11 +208,15 @@ __device__ __forceinline__ void glds16_s_nt(const void* sbase, unsigned voff, un
 __device__ __forceinline__ void store_wt16(void* dst, u4 w) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
 }
-// Workgroup barrier that is ALSO a compiler barrier for memory operations.  __builtin_amdgcn_s_barrier() is
-// "no memory, has side effects" to LLVM, so with the LDS-DMA hidden in inline asm the compiler may hoist LDS reads
-// of a freshly landed tile above it (seen as wholesale wrong results after an unrelated scheduling change).
+// Workgroup barrier that is ALSO a compiler barrier for memory operations and waits for this wave's own LDS traffic.
+// __builtin_amdgcn_s_barrier() is "no memory, has side effects" to LLVM: with the LDS-DMA hidden in inline asm the compiler
+// may hoist LDS reads of a freshly landed tile above it (seen as wholesale wrong results after an unrelated scheduling
+// change), and - unlike __syncthreads(), which carries a fence - it emits NO `s_waitcnt lgkmcnt(0)` in front of the raw
+// s_barrier, so a ds_write issued just before it (padding row, scan results) could still be in flight when another wave
+// read the location after the barrier: 1 launch in ~1000 wrong on padded inputs under a concurrent stream (tools stress
+// run).  The explicit wait costs nothing in the tile loops: a wave's LDS reads are consumed before it arrives here.
 __device__ __forceinline__ void barrier_mem() {
-  asm volatile("" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }

@@ -472,3 +472,28 @@ def test_gate_predictor_fused_one_pass(ops, mq, units):
             _check(got, want_o, msg=f"fused gate vs oracle, pad={pad is not None}")
     finally:
         lib.oeh_debug_set_variant(0, 0)
+
+
+def test_repeated_launches_under_a_concurrent_stream_are_bitwise_equal(ops):
+    """Race detector (short form of tools/stress_determinism.py): the same padded launch 500 times while another stream runs
+    a different attention shape.  Before `barrier_mem` waited for the wave's own LDS writes about 1 launch in 1000 differed."""
+    fmin = float(np.finfo(np.float32).min)
+    B, H, S, D = 16, 12, 512, 64
+    g = torch.Generator(device="cuda").manual_seed(3)
+    mk = lambda: torch.randn(B, S, H * D, device="cuda", generator=g).half().view(B, S, H, D).permute(0, 2, 1, 3)  # noqa: E731
+    q, k, v = mk() * 0.3, mk(), mk()
+    pad = torch.zeros(B, S, device="cuda")
+    for b in range(B):
+        pad[b, int(S * (0.5 + 0.5 * b / B)):] = fmin
+    q2 = torch.randn(4, 8, 333, 64, device="cuda", generator=g).half()
+    s2 = torch.cuda.Stream()
+    for kw in (dict(scale_div=8.0, key_pad_mask=pad), dict(causal=True, clamp_min=True, key_pad_mask=pad), dict(causal=True, clamp_min=True)):
+        ref = ops.attn_fwd(q, k, v, mask_min=fmin, **kw).clone()
+        bad = 0
+        for it in range(500):
+            if it % 3 == 0:
+                with torch.cuda.stream(s2):
+                    ops.attn_fwd(q2, q2, q2, causal=True, clamp_min=True, mask_min=fmin)
+            bad += 0 if torch.equal(ops.attn_fwd(q, k, v, mask_min=fmin, **kw), ref) else 1
+        torch.cuda.synchronize()
+        assert bad == 0, f"{bad} of 500 launches differ ({sorted(kw)})"

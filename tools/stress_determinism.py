@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Determinism stress (GPU box): repeat one launch N times while a second stream runs another attention shape, and count
+launches whose output differs bitwise from the first.  Found the missing `s_waitcnt lgkmcnt(0)` in front of the raw
+s_barrier (oeh_common.h: barrier_mem): ~1 launch in 1000 wrong on padded inputs.  usage: stress_determinism.py N"""
+import sys, os
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from outeffhop_amd import ops
+fmin = float(np.finfo(np.float32).min)
+N = int(sys.argv[1])
+tot = 0
+def case(name, B,H,S,D, kwf):
+    global tot
+    for seed in range(2):
+        torch.manual_seed(seed)
+        q = (torch.randn(B,S,H*D, device="cuda")*0.3).half().view(B,S,H,D).permute(0,2,1,3)
+        k = torch.randn(B,S,H*D, device="cuda").half().view(B,S,H,D).permute(0,2,1,3)
+        v = torch.randn(B,S,H*D, device="cuda").half().view(B,S,H,D).permute(0,2,1,3)
+        pad = torch.zeros(B,S, device="cuda")
+        for b in range(B): pad[b, int(S*(0.5+0.5*b/B)):] = fmin
+        kw = kwf(pad)
+        s2 = torch.cuda.Stream(); q2 = torch.randn(4,8,333,64, device="cuda").half()
+        outs = [ops.attn_fwd(q,k,v, mask_min=fmin, **kw).clone() for _ in range(3)]
+        ref = outs[0]
+        bad = sum(0 if torch.equal(o, ref) else 1 for o in outs)
+        for it in range(N):
+            if it % 3 == 0:
+                with torch.cuda.stream(s2):
+                    ops.attn_fwd(q2,q2,q2, causal=True, clamp_min=True, mask_min=fmin)
+            if not torch.equal(ops.attn_fwd(q,k,v, mask_min=fmin, **kw), ref): bad += 1
+        print(f"{name:34s} seed {seed}: {bad} of {N} differ [{ops.attn_variant(B,H,S,S,D, clip=bool(kw.get('softmax') and kw['softmax'].clip))}]"); tot += bad
+case("one-pass pad S=512", 16,12,512,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad))
+case("one-pass causal+pad S=512", 16,12,512,64, lambda pad: dict(causal=True, clamp_min=True, key_pad_mask=pad))
+case("full-row pad S=128 (BERT)", 32,12,128,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad))
+case("full-row clip+pad S=512", 16,12,512,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad, softmax=ops.SoftmaxSpec(1, True, -0.025, 1.1)))
+case("one-pass causal S=512", 16,12,512,64, lambda pad: dict(causal=True, clamp_min=True))
+sys.exit(1 if tot else 0)
