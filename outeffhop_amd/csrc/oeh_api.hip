@@ -43,7 +43,10 @@ FqP make_fq(const oeh_fq* f) {
     r.rscale = 1.0f / f->scale;
     r.zp = f->zero_point;
     r.qmax = f->qmax;
-    r.guard = 0.5f - 1.2e-6f * (f->qmax + f->zero_point + 2.0f);
+    // |x*rscale - fl(x/scale)| <= 1.8e-7 * |quotient| (two roundings against one); the band below is > 2x that
+    r.guard = 0.5f - 4.0e-7f * (f->qmax + f->zero_point + 2.0f);
+    r.lo = -f->zero_point;
+    r.hi = f->qmax - f->zero_point;
     r.dump = f->dump_idx;
   }
   return r;
@@ -88,10 +91,11 @@ bool is_pow2(float x) {
   return x > 0.0f && std::isfinite(x) && std::frexp(x, &e) == 0.5f;
 }
 
-// The fast kernel (oeh_attn_fast.inl) covers 16-bit storage, masks in {none, key padding, causal}, a positive
-// multiplicative scale (a power-of-two divisor is the same multiply, exactly) and no fake-quant.
+// The fast kernel (oeh_attn_fast.inl) covers 16-bit storage, masks in {none, key padding, causal} and a positive
+// multiplicative scale (a power-of-two divisor is the same multiply, exactly); fake-quant is its FQ variant.
 bool fast_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
-  if (d->dtype == OEH_F32 || any_fq(fq) || d->full_mask != nullptr) return false;
+  if (d->dtype == OEH_F32 || d->full_mask != nullptr) return false;
+  if (any_fq(fq) && (d->gate == nullptr && d->gate_hidden != nullptr)) return false;  // no in-kernel predictor in the FQ variant
   if (d->scale_div != 0.0f ? !is_pow2(d->scale_div) : !(d->scale > 0.0f && std::isfinite(d->scale))) return false;
   if (d->clip && d->gamma > 0.0f) return false;
   if (d->causal && d->Sq > d->Sk) return false;
@@ -105,7 +109,7 @@ int g_force_flash = 0;                   // tools/microbench.py only
 // softmax_1 (a fully padded row is 0 there; under vanilla softmax it is uniform over all keys, which a one-pass
 // kernel that may skip tiles cannot reproduce).  No Sk limit.
 bool flash_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
-  if (!fast_eligible(d, fq) || d->clip) return false;
+  if (!fast_eligible(d, fq) || d->clip || any_fq(fq)) return false;
   if (d->key_pad_mask != nullptr && d->softmax_base != OEH_SOFTMAX_ONE) return false;
   // short rows (<= 128 keys) fit the full-row kernel's registers in one pass, which measures faster there
   // (BERT-base S=128: 10.0 vs 11.7 us per launch)
@@ -135,7 +139,7 @@ Variant pick_variant(const oeh_attn_desc* d, const void* q, const void* k, const
                                      aligned16(v, d->v_stride, eb) && aligned16(o, d->o_stride, eb));
   const bool d_ok = d->D == 32 || d->D == 64 || d->D == 128;
   if (d_ok && al && flash_eligible(d, fq) && !(g_variant_off & (1 << V_FLASH))) return V_FLASH;
-  if (shape_ok && al && fast_eligible(d, fq) && !(g_variant_off & (1 << V_FAST))) return V_FAST;
+  if (shape_ok && p_exact && al && fast_eligible(d, fq) && !(g_variant_off & (1 << V_FAST))) return V_FAST;
   if (shape_ok && p_exact && al) return V_MFMA;
   if ((size_t)(d->D + d->Sk) * 4 <= 64 * 1024) return V_GENERIC;
   return V_NONE;
@@ -190,7 +194,7 @@ const char* variant_name(Variant v, const oeh_attn_desc* d, bool fq) {
   const int nt = d->Sk <= 128 ? 8 : (d->Sk <= 256 ? 16 : 32);
   const char* dt = d->dtype == OEH_F16 ? "f16" : (d->dtype == OEH_BF16 ? "bf16" : "f32");
   if (v == V_FLASH) std::snprintf(buf, sizeof(buf), "flash16/MQ%d/D%d/%s", flash_mq(d), d->D, dt);
-  else if (v == V_FAST) std::snprintf(buf, sizeof(buf), "fast16/NT%d/D%d/%s%s", nt, d->D, dt, d->clip ? "/clip" : "");
+  else if (v == V_FAST) std::snprintf(buf, sizeof(buf), "fast16/NT%d/D%d/%s%s%s", nt, d->D, dt, d->clip ? "/clip" : "", fq ? "/fq" : "");
   else std::snprintf(buf, sizeof(buf), "mfma16/NT%d/D%d/%s%s", nt, d->D, dt, fq ? "/fq" : "");
   return buf;
 }

@@ -16,8 +16,8 @@
 //     resident when P@V starts.  Separate rings make every LDS slot offset a compile-time constant in the unrolled loops.  The XOR swizzle is applied on the per-lane SOURCE address (the LDS image of
 //     one wave-instruction is lane-linear), reads use the same swizzle: conflict-free (tools/lds_bank_sim.py).
 //     One raw s_barrier per tile, counted s_waitcnt vmcnt(N) (never 0 in the loop).
-// Everything else (fake-quant, (B,1,Sq,Sk) masks, fp32 storage, non-power-of-two score division, gamma > 0)
-// runs the general kernel.
+// Everything else ((B,1,Sq,Sk) masks, fp32 storage, non-power-of-two score division, gamma > 0) runs the general kernel;
+// the fused fake-quantisers are the FQ variant below.
 #pragma once
 #include "oeh_attn_mfma.inl"
 
@@ -48,8 +48,12 @@ constexpr int fast_occupancy() { return D >= 128 ? 1 : 3; }  // what the LDS rin
 // registers), with the weights rounded to the storage dtype - what the reference's Linear does in a 16-bit model; the
 // second layer, the sigmoid and the scaling are a few VALU operations per lane and one register carries the result to the
 // epilogue.  A separate variant: the others carry none of it.
-template <int NT, int D, int IN, bool CLIP, bool GATE>
+// FQ: the fused fake-quantisers (scores / probabilities / context).  The per-element chain is then the reference's op
+// order literally - scale, quantise, masks added (not substituted), x - m, 1-ulp exp, normalise, [clip], quantise - as in
+// the general kernel (oeh_attn_mfma.inl), on this kernel's data path; clipping is a run-time option of this variant.
+template <int NT, int D, int IN, bool CLIP, bool GATE, bool FQ = false>
 __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_kernel(const AttnParams P) {
+  static_assert(!FQ || (!CLIP && !GATE), "the fake-quant variant takes clipping at run time and has no in-kernel gate predictor");
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
   constexpr int KT = NT / 4;
   constexpr int ROWB = 2 * D;
@@ -271,6 +275,124 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
   const int klim = causal ? min(qrow + off, Sk - 1) : Sk - 1;            // last admissible key of this lane's row
   const int gm0 = ((causal ? min(q0 + off, Sk - 1) : Sk - 1) + 1) >> 6;  // first 64-key tile holding a masked key (wave-uniform)
   float m = -__builtin_inff();
+  float inv_fq = 1.0f;
+  if constexpr (FQ) {
+    const float mask_min = P.mask_min;
+    const int klimc = qrow + off;                                          // last key a causal row may see
+    const bool fq_s_on = P.fq_s.en, fq_p_on = P.fq_p.en;
+    const bool dump_s = fq_s_on && P.fq_s.dump != nullptr, dump_p = fq_p_on && P.fq_p.dump != nullptr;
+    const int kt_causal = causal ? (max(0, q0 + off + 1) >> 6) : KT;       // first 64-key tile with a key the wave's first row must not see
+    const int kt_tail = Sk >> 6;                                           // first 64-key tile with a key >= Sk
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      if (kt < n_kt) {
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          const int t = kt * 4 + sub;
+          const int key0 = 16 * t + 4 * g;
+          f4 x = s[t];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = x[r] * sc;
+          if (fq_s_on) {
+            const f4 rel = fq_rel4(x, P.fq_s);
+            if (dump_s && qvalid) {
+              const unsigned int w = (unsigned int)(rel[0] + P.fq_s.zp) | ((unsigned int)(rel[1] + P.fq_s.zp) << 8) |
+                                     ((unsigned int)(rel[2] + P.fq_s.zp) << 16) | ((unsigned int)(rel[3] + P.fq_s.zp) << 24);
+              dump4(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0, w, Sk - key0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = P.fq_s.scale * rel[r];
+          }
+          if (has_pad) {
+            const f4 padv = *reinterpret_cast<const f4*>(&lds_pad[key0]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = x[r] + padv[r];
+          }
+          if (kt >= kt_causal) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (key0 + r > klimc) x[r] = x[r] + mask_min;
+          }
+          if (P.clamp_min && (has_pad || kt >= kt_causal)) {  // elsewhere x is a finite product of 16-bit data: the clamp is dead
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = __builtin_fmaxf(x[r], mask_min);
+          }
+          if (kt >= kt_tail) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (key0 + r >= Sk) x[r] = -__builtin_inff();
+          }
+          s[t] = x;
+          m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(x[0], x[1])), __builtin_fmaxf(x[2], x[3]));
+        }
+      }
+    }
+    m = __builtin_fmaxf(m, __shfl_xor(m, 16));
+    m = __builtin_fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      if (kt < n_kt) {
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          const int t = kt * 4 + sub;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = exp_acc_nonpos(s[t][r] - m);
+            s[t][r] = e;
+            sum += e;
+          }
+        }
+      }
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    float den = sum;
+    if (P.base != 0) den = sum + exp_acc(m * -1.0f);  // softmax_1: + 1*exp(-max)  (softmax_1.py:18-20)
+    inv_fq = 1.0f / den;
+    // probabilities -> [clip] -> [fq] -> packed 16-bit P^T operand in the first two registers of the score tile
+    const bool clip_on = P.clip != 0;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      if (kt < n_kt) {
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          const int t = kt * 4 + sub;
+          const int key0 = 16 * t + 4 * g;
+          f4 pv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pv[r] = s[t][r] * inv_fq;
+          if (clip_on) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float p = pv[r] * P.clip_w;
+              p = p + P.clip_g;
+              pv[r] = __builtin_fminf(__builtin_fmaxf(p, 0.0f), 1.0f);
+            }
+          }
+          if (fq_p_on) {
+            pv = fq_rel4(pv, P.fq_p);  // integer valued (idx - zp): exact in f16/bf16; the scale is applied after the product
+            if (dump_p && qvalid) {
+              const unsigned int w = (unsigned int)(pv[0] + P.fq_p.zp) | ((unsigned int)(pv[1] + P.fq_p.zp) << 8) |
+                                     ((unsigned int)(pv[2] + P.fq_p.zp) << 16) | ((unsigned int)(pv[3] + P.fq_p.zp) << 24);
+              dump4(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0, w, Sk - key0);
+            }
+          }
+          if (kt >= kt_tail) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (key0 + r >= Sk) pv[r] = 0.0f;
+          }
+          const unsigned lo = (IN == IN_BF16) ? pack2_bf16(pv[0], pv[1]) : pack2_f16(pv[0], pv[1]);
+          const unsigned hi = (IN == IN_BF16) ? pack2_bf16(pv[2], pv[3]) : pack2_f16(pv[2], pv[3]);
+          s[t][0] = bits_f32(lo);
+          s[t][1] = bits_f32(hi);
+        }
+      }
+    }
+  }
+  float inv = inv_fq;
+  if constexpr (!FQ) {
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     if (kt < n_kt) {
@@ -349,7 +471,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
   sum += __shfl_xor(sum, 32);
   float den = sum;
   if (P.base != 0) den = sum + exp_acc(m_true * -1.0f);
-  const float inv = 1.0f / den;
+  inv = 1.0f / den;
 
   if constexpr (CLIP) {  // clip(p*(eta-gamma)+gamma, 0, 1); masked keys have p == 0 and stay 0 (this path requires gamma <= 0)
     const float clip_w = P.clip_w, clip_g = P.clip_g;
@@ -376,6 +498,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
     }
   }
 
+  }  // !FQ
   OEH_STAMP(12);
   // =========================== phase 3: O^T = V^T P^T ===========================
   f4 o[DT];
@@ -421,20 +544,46 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
   const int ce = lane_e & 15, ge = lane_e >> 4;
-  float rowscale = CLIP ? 1.0f : inv;
+  float rowscale = (CLIP || FQ) ? 1.0f : inv;
   if (P.gate != nullptr && qvalid) rowscale = rowscale * P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
   if constexpr (GATE) rowscale = rowscale * gate_row;
   constexpr int XM = (CPR < 8 ? CPR : 8) - 1;
   unsigned char* ebase = lds + wave * (16 * ROWB);
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) {
+    float ov[4];
+    if constexpr (FQ) {  // [scale of the quantised P] [fq] gate [fq]: the general kernel's epilogue chain
+      unsigned int dump_word = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = o[dt][r];
+        if (P.fq_p.en) x = P.fq_p.scale * x;
+        if (P.fq_c.en && P.ctx_before_gate) {
+          const float idx = fq_index_fast(x, P.fq_c);
+          dump_word |= ((unsigned int)idx) << (8 * r);
+          x = fq_dequant(idx, P.fq_c);
+        }
+        if (P.gate != nullptr) x = x * rowscale;
+        if (P.fq_c.en && !P.ctx_before_gate) {
+          const float idx = fq_index_fast(x, P.fq_c);
+          dump_word |= ((unsigned int)idx) << (8 * r);
+          x = fq_dequant(idx, P.fq_c);
+        }
+        ov[r] = x;
+      }
+      if (P.fq_c.en && P.fq_c.dump != nullptr && q0 + ce < P.Sq)
+        dump4(P.fq_c.dump + (((long)b * P.H + h) * P.Sq + q0 + ce) * D + 16 * dt + 4 * ge, dump_word, 4);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov[r] = o[dt][r] * rowscale;
+    }
     u2 w;
     if constexpr (IN == IN_BF16) {
-      w.x = pack2_bf16(o[dt][0] * rowscale, o[dt][1] * rowscale);
-      w.y = pack2_bf16(o[dt][2] * rowscale, o[dt][3] * rowscale);
+      w.x = pack2_bf16(ov[0], ov[1]);
+      w.y = pack2_bf16(ov[2], ov[3]);
     } else {
-      w.x = pack2_f16(o[dt][0] * rowscale, o[dt][1] * rowscale);
-      w.y = pack2_f16(o[dt][2] * rowscale, o[dt][3] * rowscale);
+      w.x = pack2_f16(ov[0], ov[1]);
+      w.y = pack2_f16(ov[2], ov[3]);
     }
     *reinterpret_cast<u2*>(ebase + ce * ROWB + ((((2 * dt + (ge >> 1)) ^ (ce & XM)) << 4) | ((ge & 1) << 3))) = w;
   }
@@ -460,6 +609,10 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
 template <int NT, int D, int IN>
 static void launch_fast_nt_d_in(const AttnParams& P, unsigned grid, hipStream_t st) {
   const bool gate = P.gh != nullptr;
+  if (P.fq_s.en || P.fq_p.en || P.fq_c.en) {
+    hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, true>), dim3(grid), dim3(256), 0, st, P);
+    return;
+  }
   if (P.clip) {
     if (gate) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, true>), dim3(grid), dim3(256), 0, st, P);
     else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false>), dim3(grid), dim3(256), 0, st, P);

@@ -27,6 +27,7 @@ struct FqP {
   int en;
   float scale, rscale, zp, qmax;
   float guard;  // see fq_index_fast
+  float lo, hi;  // -zp and qmax - zp: the grid relative to the zero point (fq_rel4)
   unsigned char* dump;
 };
 
@@ -45,8 +46,8 @@ __device__ __forceinline__ float fq_index(float x, const FqP& f) {
 }
 // The same index two instructions cheaper per element.  Where the index is not clamped anyway the quotient is bounded
 // by the grid (|q| <= qmax + zp + 1), so the half-integer guard band is a per-quantiser constant: f.guard =
-// 0.5 - 1.2e-6 * (qmax + zp + 2), set by the host (oeh_api.hip: make_fq).  One subtract and one compare per element;
-// the division runs for ~(1 - 2*guard) of the elements (6e-4 for an 8-bit grid).
+// 0.5 - 4e-7 * (qmax + zp + 2), set by the host (oeh_api.hip: make_fq).  One subtract and one compare per element;
+// the division runs for ~(1 - 2*guard) of the elements (3e-4 for an 8-bit grid).
 __device__ __forceinline__ float fq_index_fast(float x, const FqP& f) {
   const float q = x * f.rscale;
   float r = __builtin_rintf(q);
@@ -81,11 +82,45 @@ __device__ __forceinline__ f4 fq_index_fast4(f4 x, const FqP& f) {
   return r;
 }
 __device__ __forceinline__ float fq_dequant(float idx, const FqP& f) { return f.scale * (idx - f.zp); }
+// Index relative to the zero point, idx - zp = clamp(rint(x/scale), -zp, qmax - zp): the same integer as
+// clamp(rint(x/scale) + zp, 0, qmax) - zp (all operands are integers far below 2^24, or the clamp saturates either way)
+// for two instructions less per element; x_q = scale * rel, and rel itself is the integer the P operand carries.
+__device__ __forceinline__ f4 fq_rel4(f4 x, const FqP& f) {
+  f4 q, r;
+  bool need = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    q[i] = x[i] * f.rscale;
+    r[i] = __builtin_rintf(q[i]);
+    need = need || (__builtin_fabsf(q[i] - r[i]) > f.guard);
+  }
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(need) != 0, 0)) {
+    const float bound = f.qmax + f.zp + 2.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float e = __builtin_rintf(x[i] / f.scale);
+      const bool use = __builtin_fabsf(q[i] - r[i]) > f.guard && __builtin_fabsf(q[i]) <= bound;
+      r[i] = use ? e : r[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_fmed3f(r[i], f.lo, f.hi);
+  return r;
+}
 
 // exp(y) to ~1 ulp: n = rint(y*log2e), f = y*log2e - n in two fma steps, 2^f by v_exp_f32, ldexp.
 // Used wherever a value feeds a quantiser (index parity with an IEEE-accurate expf).
 __device__ __forceinline__ float exp_acc(float y) {
   y = __builtin_fminf(__builtin_fmaxf(y, -110.0f), 90.0f);
+  float t = y * kLog2eHi;
+  float n = __builtin_rintf(t);
+  float f = __builtin_fmaf(y, kLog2eHi, -n);
+  f = __builtin_fmaf(y, kLog2eLo, f);
+  return __builtin_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+// the same for y <= 0 (softmax arguments): the upper clamp is dead
+__device__ __forceinline__ float exp_acc_nonpos(float y) {
+  y = __builtin_fmaxf(y, -110.0f);
   float t = y * kLog2eHi;
   float n = __builtin_rintf(t);
   float f = __builtin_fmaf(y, kLog2eHi, -n);

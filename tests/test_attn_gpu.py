@@ -249,6 +249,19 @@ def test_int8_fused(ops, order, sm, S):
     fq2 = ops.AttnFakeQuant(FQ(*d_s), FQ(*d_p), FQ(*d_c), ctx_before_gate=before)
     got2 = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=fq2, **args)
     assert torch.equal(got, got2)
+    # 16-bit storage runs the full-row kernel's FQ variant; the general kernel's FQ chain must give the same bits and indices
+    from outeffhop_amd import _lib
+    assert ops.attn_variant(B, H, S, S, D, fq=True).startswith("fast16/") and ops.attn_variant(B, H, S, S, D, fq=True).endswith("/fq")
+    dumps2 = [torch.zeros_like(t) for t in (dump_s, dump_p, dump_c)]
+    fq3 = ops.AttnFakeQuant(FQ(*d_s, dump=dumps2[0]), FQ(*d_p, dump=dumps2[1]), FQ(*d_c, dump=dumps2[2]), ctx_before_gate=before)
+    _lib.load().oeh_debug_set_variant(4, 0)
+    try:
+        got3 = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=fq3, **args)
+    finally:
+        _lib.load().oeh_debug_set_variant(0, 0)
+    assert torch.equal(got, got3)
+    for a, b_ in zip((dump_s, dump_p, dump_c), dumps2):
+        assert torch.equal(a, b_)
 
 
 def test_bit_reproducible_and_batch_shard_invariant(ops):
@@ -497,3 +510,59 @@ def test_repeated_launches_under_a_concurrent_stream_are_bitwise_equal(ops):
             bad += 0 if torch.equal(ops.attn_fwd(q, k, v, mask_min=fmin, **kw), ref) else 1
         torch.cuda.synchronize()
         assert bad == 0, f"{bad} of 500 launches differ ({sorted(kw)})"
+
+
+def test_fq_kernels_agree_bitwise_on_ragged_shapes(ops):
+    """The full-row kernel's FQ variant against the general kernel's FQ chain (pinned to the reference by the golden INT8
+    fixtures): random ragged shapes, quantiser subsets, zero points, masks, clipping, both softmax bases - same bits, same
+    indices."""
+    from outeffhop_amd import _lib
+
+    lib = _lib.load()
+    fmin = float(np.finfo(np.float32).min)
+    rng = np.random.default_rng(977)
+    FQ = ops.FakeQuantSpec
+    for n in range(24):
+        D = int(rng.choice([32, 64, 64, 128]))
+        B, H = int(rng.integers(1, 3)), int(rng.integers(1, 4))
+        Sk = int(rng.integers(17, 513))
+        causal = bool(rng.integers(0, 2))
+        Sq = int(rng.integers(max(1, Sk - 150), Sk + 1)) if causal else int(rng.integers(1, 300))
+        sm = ["softmax1", "vanilla", "clippedsoftmax1(-.025:1)"][int(rng.integers(0, 3))]
+        dt = [torch.float16, torch.bfloat16][int(rng.integers(0, 4) == 0)]
+        q = _rand((B, Sq, H * D), 5000 + n, dtype=dt).view(B, Sq, H, D).permute(0, 2, 1, 3).cuda()
+        k = _rand((B, Sk, H * D), 5100 + n, dtype=dt).view(B, Sk, H, D).permute(0, 2, 1, 3).cuda()
+        v = _rand((B, Sk, H * D), 5200 + n, dtype=dt).view(B, Sk, H, D).permute(0, 2, 1, 3).cuda()
+        pad = None
+        if not causal and bool(rng.integers(0, 2)):
+            pad = torch.zeros(B, Sk)
+            for b in range(B):
+                pad[b, int(rng.integers(1, Sk + 1)):] = fmin
+            pad = pad.cuda()
+        gate = torch.rand((B, H, Sq, 1), generator=torch.Generator().manual_seed(5300 + n)).cuda() if rng.integers(0, 2) else None
+        on = [bool(rng.integers(0, 4)) for _ in range(3)]
+        if not any(on):
+            on[1] = True
+        grids = [(0.013 + 0.05 * float(rng.random()), float(rng.integers(0, 200))), (1.0 / 255.0, float(rng.integers(0, 3))),
+                 (0.004 + 0.02 * float(rng.random()), float(rng.integers(60, 190)))]
+        want_dump = bool(rng.integers(0, 2))
+        res = []
+        for off_mask in (0, 4):  # as picked (full-row FQ variant); full-row kernel disabled (general kernel)
+            dumps = [torch.zeros((B, H, Sq, Sk), dtype=torch.uint8, device="cuda"), torch.zeros((B, H, Sq, Sk), dtype=torch.uint8, device="cuda"),
+                     torch.zeros((B, H, Sq, D), dtype=torch.uint8, device="cuda")] if want_dump else [None] * 3
+            specs = [FQ(g_[0], g_[1], dump=d_) if o_ else None for g_, d_, o_ in zip(grids, dumps, on)]
+            lib.oeh_debug_set_variant(off_mask, 0)
+            try:
+                var = ops.attn_variant(B, H, Sq, Sk, D, dt, fq=True)
+                got = ops.attn_fwd(q, k, v, softmax=_spec(ops, sm), scale=D ** -0.5, causal=causal, clamp_min=causal, key_pad_mask=pad, gate=gate,
+                                   fq=ops.AttnFakeQuant(*specs, ctx_before_gate=bool(n & 1)), mask_min=fmin)
+            finally:
+                lib.oeh_debug_set_variant(0, 0)
+            res.append((var, got, dumps))
+        (var_a, got_a, dumps_a), (var_b, got_b, dumps_b) = res
+        assert var_a.startswith("fast16/") and var_b.startswith("mfma16/"), (var_a, var_b)
+        what = f"case {n}: {var_a} vs {var_b}, on={on} sm={sm} causal={causal} pad={pad is not None} gate={gate is not None}"
+        assert torch.equal(got_a, got_b), what
+        for i_, (da, db) in enumerate(zip(dumps_a, dumps_b)):
+            if da is not None and on[i_]:
+                assert torch.equal(da, db), what + f": index dump {i_} differs"
