@@ -43,8 +43,6 @@ FqP make_fq(const oeh_fq* f) {
     r.rscale = 1.0f / f->scale;
     r.zp = f->zero_point;
     r.qmax = f->qmax;
-    // |x*rscale - fl(x/scale)| <= 1.8e-7 * |quotient| (two roundings against one); the band below is > 2x that
-    r.guard = 0.5f - 4.0e-7f * (f->qmax + f->zero_point + 2.0f);
     r.lo = -f->zero_point;
     r.hi = f->qmax - f->zero_point;
     r.dump = f->dump_idx;

@@ -296,9 +296,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
           if (fq_s_on) {
             const f4 rel = fq_rel4(x, P.fq_s);
             if (dump_s && qvalid) {
-              const unsigned int w = (unsigned int)(rel[0] + P.fq_s.zp) | ((unsigned int)(rel[1] + P.fq_s.zp) << 8) |
-                                     ((unsigned int)(rel[2] + P.fq_s.zp) << 16) | ((unsigned int)(rel[3] + P.fq_s.zp) << 24);
-              dump4(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0, w, Sk - key0);
+              dump4(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0, fq_dump_word(rel, P.fq_s), Sk - key0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[r] = P.fq_s.scale * rel[r];
@@ -373,9 +371,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
           if (fq_p_on) {
             pv = fq_rel4(pv, P.fq_p);  // integer valued (idx - zp): exact in f16/bf16; the scale is applied after the product
             if (dump_p && qvalid) {
-              const unsigned int w = (unsigned int)(pv[0] + P.fq_p.zp) | ((unsigned int)(pv[1] + P.fq_p.zp) << 8) |
-                                     ((unsigned int)(pv[2] + P.fq_p.zp) << 16) | ((unsigned int)(pv[3] + P.fq_p.zp) << 24);
-              dump4(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0, w, Sk - key0);
+              dump4(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0, fq_dump_word(pv, P.fq_p), Sk - key0);
             }
           }
           if (kt >= kt_tail) {
@@ -559,13 +555,13 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
         float x = o[dt][r];
         if (P.fq_p.en) x = P.fq_p.scale * x;
         if (P.fq_c.en && P.ctx_before_gate) {
-          const float idx = fq_index_fast(x, P.fq_c);
+          const float idx = fq_index(x, P.fq_c);
           dump_word |= ((unsigned int)idx) << (8 * r);
           x = fq_dequant(idx, P.fq_c);
         }
         if (P.gate != nullptr) x = x * rowscale;
         if (P.fq_c.en && !P.ctx_before_gate) {
-          const float idx = fq_index_fast(x, P.fq_c);
+          const float idx = fq_index(x, P.fq_c);
           dump_word |= ((unsigned int)idx) << (8 * r);
           x = fq_dequant(idx, P.fq_c);
         }

@@ -202,13 +202,10 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
       }
       if constexpr (FQ) {
         if (fq_s_on) {
-          const f4 idx = fq_index_fast4(x, P.fq_s);
-          if (dump_s && qvalid) {
-            const unsigned int w = (unsigned int)idx[0] | ((unsigned int)idx[1] << 8) | ((unsigned int)idx[2] << 16) | ((unsigned int)idx[3] << 24);
-            dump4(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + key0, w, P.Sk - key0);
-          }
+          const f4 rel = fq_rel4(x, P.fq_s);
+          if (dump_s && qvalid) dump4(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + key0, fq_dump_word(rel, P.fq_s), P.Sk - key0);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) x[r] = fq_dequant(idx[r], P.fq_s);
+          for (int r = 0; r < 4; ++r) x[r] = P.fq_s.scale * rel[r];
         }
       }
       if (has_pad) {
@@ -281,13 +278,8 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
       }
       if constexpr (FQ) {
         if (fq_p_on) {
-          const f4 idx = fq_index_fast4(pv, P.fq_p);
-          if (dump_p && qvalid) {
-            const unsigned int w = (unsigned int)idx[0] | ((unsigned int)idx[1] << 8) | ((unsigned int)idx[2] << 16) | ((unsigned int)idx[3] << 24);
-            dump4(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + key0, w, P.Sk - key0);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pv[r] = idx[r] - P.fq_p.zp;  // integer valued: exact in f16/bf16; scale applied after the product
+          pv = fq_rel4(pv, P.fq_p);  // integer valued (idx - zp): exact in f16/bf16; scale applied after the product
+          if (dump_p && qvalid) dump4(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + key0, fq_dump_word(pv, P.fq_p), P.Sk - key0);
         }
       }
       if (t >= t_tail) {
@@ -353,7 +345,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
       if constexpr (FQ) {
         if (P.fq_p.en) x = P.fq_p.scale * x;
         if (P.fq_c.en && P.ctx_before_gate) {
-          const float idx = fq_index_fast(x, P.fq_c);
+          const float idx = fq_index(x, P.fq_c);
           dump_word |= ((unsigned int)idx) << (8 * r);
           x = fq_dequant(idx, P.fq_c);
         }
@@ -361,7 +353,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
       if (P.gate != nullptr) x = x * gatev;
       if constexpr (FQ) {
         if (P.fq_c.en && !P.ctx_before_gate) {
-          const float idx = fq_index_fast(x, P.fq_c);
+          const float idx = fq_index(x, P.fq_c);
           dump_word |= ((unsigned int)idx) << (8 * r);
           x = fq_dequant(idx, P.fq_c);
         }

@@ -25,87 +25,38 @@ constexpr float kLog2eLo = 0x1.4ae0bep-26f;  // log2 e - kLog2eHi
 // One fixed-range asymmetric fake-quantiser (uniform_quantizers.py:72-82,114-115,146).
 struct FqP {
   int en;
-  float scale, rscale, zp, qmax;
-  float guard;  // see fq_index_fast
-  float lo, hi;  // -zp and qmax - zp: the grid relative to the zero point (fq_rel4)
+  float scale, rscale, zp, qmax;  // rscale = RN(1/scale), formed by the host (oeh_api.hip: make_fq)
+  float lo, hi;                   // -zp and qmax - zp: the grid relative to the zero point
   unsigned char* dump;
 };
 
-// rint(x / scale) with the result of a TRUE IEEE division, at the cost of one multiply in the common
-// case: x*rscale is within 2^-23 relative of x/scale, so the two can only round differently when the
-// quotient sits within that distance of a half-integer; only then is the division carried out.
-__device__ __forceinline__ float fq_rint_div(float x, float scale, float rscale) {
-  float q = x * rscale;
-  float r = __builtin_rintf(q);
-  if (__builtin_expect(0.5f - __builtin_fabsf(q - r) <= __builtin_fabsf(q) * 6e-7f, 0)) r = __builtin_rintf(x / scale);
-  return r;
+// x / scale, correctly rounded, in three instructions: the product with the correctly rounded reciprocal is within
+// 1.5 ulp of the quotient, its residual r = x - q0*scale is then exact in one fma, and q0 + r*rscale rounds to RN(x/scale)
+// (Markstein's correction step).  The reference divides (uniform_quantizers.py:114), and rint() of a quotient that is one
+// ulp off flips the index next to a half-integer, so the quotient has to be the IEEE one: tools/div_check.hip compares
+// this sequence with the hardware division on every float within 4 ulp of every half-integer |h| <= 520 for 2^20 scales
+// (incl. all-ones mantissas) and on 8.6e9 random pairs - 0 differences in 2.8e10.  (The first version multiplied and fell
+// back to a real division inside a guard band around the half-integers: one more instruction per element, a wave-uniform
+// branch per four, and 1.1 k instructions of division code per kernel; INT8 OPT shape 46.3 -> 40 us without it.)
+__device__ __forceinline__ float fq_quot(float x, const FqP& f) {
+  const float q0 = x * f.rscale;
+  const float r = __builtin_fmaf(-q0, f.scale, x);
+  return __builtin_fmaf(r, f.rscale, q0);
 }
-__device__ __forceinline__ float fq_index(float x, const FqP& f) {
-  float r = fq_rint_div(x, f.scale, f.rscale) + f.zp;
-  return __builtin_fminf(__builtin_fmaxf(r, 0.0f), f.qmax);
-}
-// The same index two instructions cheaper per element.  Where the index is not clamped anyway the quotient is bounded
-// by the grid (|q| <= qmax + zp + 1), so the half-integer guard band is a per-quantiser constant: f.guard =
-// 0.5 - 4e-7 * (qmax + zp + 2), set by the host (oeh_api.hip: make_fq).  One subtract and one compare per element;
-// the division runs for ~(1 - 2*guard) of the elements (3e-4 for an 8-bit grid).
-__device__ __forceinline__ float fq_index_fast(float x, const FqP& f) {
-  const float q = x * f.rscale;
-  float r = __builtin_rintf(q);
-  if (__builtin_expect(__builtin_fabsf(q - r) > f.guard, 0)) {
-    if (__builtin_fabsf(q) <= f.qmax + f.zp + 2.0f) r = __builtin_rintf(x / f.scale);
-  }
-  return __builtin_fminf(__builtin_fmaxf(r + f.zp, 0.0f), f.qmax);
-}
-// Four elements at once with ONE wave-uniform test for the rare exact-division case (a per-element `if` costs an
-// exec-mask save / branch / restore per element: the INT8 kernel had 725 of them).  Inside the rare block the division
-// is computed for all lanes and selected.
-__device__ __forceinline__ f4 fq_index_fast4(f4 x, const FqP& f) {
-  f4 q, r;
-  bool need = false;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    q[i] = x[i] * f.rscale;
-    r[i] = __builtin_rintf(q[i]);
-    need = need || (__builtin_fabsf(q[i] - r[i]) > f.guard);
-  }
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(need) != 0, 0)) {
-    const float bound = f.qmax + f.zp + 2.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float e = __builtin_rintf(x[i] / f.scale);
-      const bool use = __builtin_fabsf(q[i] - r[i]) > f.guard && __builtin_fabsf(q[i]) <= bound;
-      r[i] = use ? e : r[i];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = __builtin_fminf(__builtin_fmaxf(r[i] + f.zp, 0.0f), f.qmax);
-  return r;
-}
-__device__ __forceinline__ float fq_dequant(float idx, const FqP& f) { return f.scale * (idx - f.zp); }
 // Index relative to the zero point, idx - zp = clamp(rint(x/scale), -zp, qmax - zp): the same integer as
 // clamp(rint(x/scale) + zp, 0, qmax) - zp (all operands are integers far below 2^24, or the clamp saturates either way)
 // for two instructions less per element; x_q = scale * rel, and rel itself is the integer the P operand carries.
+__device__ __forceinline__ float fq_rel(float x, const FqP& f) { return __builtin_amdgcn_fmed3f(__builtin_rintf(fq_quot(x, f)), f.lo, f.hi); }
 __device__ __forceinline__ f4 fq_rel4(f4 x, const FqP& f) {
-  f4 q, r;
-  bool need = false;
+  f4 r;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    q[i] = x[i] * f.rscale;
-    r[i] = __builtin_rintf(q[i]);
-    need = need || (__builtin_fabsf(q[i] - r[i]) > f.guard);
-  }
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(need) != 0, 0)) {
-    const float bound = f.qmax + f.zp + 2.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float e = __builtin_rintf(x[i] / f.scale);
-      const bool use = __builtin_fabsf(q[i] - r[i]) > f.guard && __builtin_fabsf(q[i]) <= bound;
-      r[i] = use ? e : r[i];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_fmed3f(r[i], f.lo, f.hi);
+  for (int i = 0; i < 4; ++i) r[i] = fq_rel(x[i], f);
   return r;
+}
+__device__ __forceinline__ float fq_index(float x, const FqP& f) { return fq_rel(x, f) + f.zp; }
+__device__ __forceinline__ float fq_dequant(float idx, const FqP& f) { return f.scale * (idx - f.zp); }
+__device__ __forceinline__ unsigned int fq_dump_word(f4 rel, const FqP& f) {  // four uint8 indices (test dumps)
+  return (unsigned int)(rel[0] + f.zp) | ((unsigned int)(rel[1] + f.zp) << 8) | ((unsigned int)(rel[2] + f.zp) << 16) | ((unsigned int)(rel[3] + f.zp) << 24);
 }
 
 // exp(y) to ~1 ulp: n = rint(y*log2e), f = y*log2e - n in two fma steps, 2^f by v_exp_f32, ldexp.
