@@ -93,7 +93,9 @@ bool is_pow2(float x) {
 // multiplicative scale (a power-of-two divisor is the same multiply, exactly); fake-quant is its FQ variant.
 bool fast_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
   if (d->dtype == OEH_F32 || d->full_mask != nullptr) return false;
-  if (any_fq(fq) && (d->gate == nullptr && d->gate_hidden != nullptr)) return false;  // no in-kernel predictor in the FQ variant
+  if (any_fq(fq)) {  // the FQ variant: scores and probabilities both quantised (the reference's configuration), no in-kernel predictor
+    if (!(fq->scores.enable && fq->probs.enable) || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
+  }
   if (d->scale_div != 0.0f ? !is_pow2(d->scale_div) : !(d->scale > 0.0f && std::isfinite(d->scale))) return false;
   if (d->clip && d->gamma > 0.0f) return false;
   if (d->causal && d->Sq > d->Sk) return false;

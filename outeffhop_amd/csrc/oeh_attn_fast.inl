@@ -50,10 +50,12 @@ constexpr int fast_occupancy() { return D >= 128 ? 1 : 3; }  // what the LDS rin
 // epilogue.  A separate variant: the others carry none of it.
 // FQ: the fused fake-quantisers (scores / probabilities / context).  The per-element chain is then the reference's op
 // order literally - scale, quantise, masks added (not substituted), x - m, 1-ulp exp, normalise, [clip], quantise - as in
-// the general kernel (oeh_attn_mfma.inl), on this kernel's data path; clipping is a run-time option of this variant.
+// the general kernel (oeh_attn_mfma.inl), on this kernel's data path.  The variant is compiled for the reference's
+// configuration, scores AND probabilities quantised (context optional): a run-time test per quantiser and per four elements
+// costs a branch and, at the join, register copies (1.5 VALU per element for the clip alone).  Other subsets: general kernel.
 template <int NT, int D, int IN, bool CLIP, bool GATE, bool FQ = false>
 __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_kernel(const AttnParams P) {
-  static_assert(!FQ || (!CLIP && !GATE), "the fake-quant variant takes clipping at run time and has no in-kernel gate predictor");
+  static_assert(!FQ || !GATE, "the fake-quant variant has no in-kernel gate predictor");
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
   constexpr int KT = NT / 4;
   constexpr int ROWB = 2 * D;
@@ -279,8 +281,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
   if constexpr (FQ) {
     const float mask_min = P.mask_min;
     const int klimc = qrow + off;                                          // last key a causal row may see
-    const bool fq_s_on = P.fq_s.en, fq_p_on = P.fq_p.en;
-    const bool dump_s = fq_s_on && P.fq_s.dump != nullptr, dump_p = fq_p_on && P.fq_p.dump != nullptr;
+    const bool dump_s = P.fq_s.dump != nullptr, dump_p = P.fq_p.dump != nullptr;
     const int kt_causal = causal ? (max(0, q0 + off + 1) >> 6) : KT;       // first 64-key tile with a key the wave's first row must not see
     const int kt_tail = Sk >> 6;                                           // first 64-key tile with a key >= Sk
 #pragma unroll
@@ -293,11 +294,9 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
           f4 x = s[t];
 #pragma unroll
           for (int r = 0; r < 4; ++r) x[r] = x[r] * sc;
-          if (fq_s_on) {
+          {
             const f4 rel = fq_rel4(x, P.fq_s);
-            if (dump_s && qvalid) {
-              dump4(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0, fq_dump_word(rel, P.fq_s), Sk - key0);
-            }
+            if (dump_s && qvalid) dump4(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0, fq_dump_word(rel, P.fq_s), Sk - key0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[r] = P.fq_s.scale * rel[r];
           }
@@ -349,7 +348,6 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
     if (P.base != 0) den = sum + exp_acc(m * -1.0f);  // softmax_1: + 1*exp(-max)  (softmax_1.py:18-20)
     inv_fq = 1.0f / den;
     // probabilities -> [clip] -> [fq] -> packed 16-bit P^T operand in the first two registers of the score tile
-    const bool clip_on = P.clip != 0;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
       if (kt < n_kt) {
@@ -360,7 +358,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
           f4 pv;
 #pragma unroll
           for (int r = 0; r < 4; ++r) pv[r] = s[t][r] * inv_fq;
-          if (clip_on) {
+          if constexpr (CLIP) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float p = pv[r] * P.clip_w;
@@ -368,12 +366,8 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
               pv[r] = __builtin_fminf(__builtin_fmaxf(p, 0.0f), 1.0f);
             }
           }
-          if (fq_p_on) {
-            pv = fq_rel4(pv, P.fq_p);  // integer valued (idx - zp): exact in f16/bf16; the scale is applied after the product
-            if (dump_p && qvalid) {
-              dump4(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0, fq_dump_word(pv, P.fq_p), Sk - key0);
-            }
-          }
+          pv = fq_rel4(pv, P.fq_p);  // integer valued (idx - zp): exact in f16/bf16; the scale is applied after the product
+          if (dump_p && qvalid) dump4(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0, fq_dump_word(pv, P.fq_p), Sk - key0);
           if (kt >= kt_tail) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -553,7 +547,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = o[dt][r];
-        if (P.fq_p.en) x = P.fq_p.scale * x;
+        x = P.fq_p.scale * x;
         if (P.fq_c.en && P.ctx_before_gate) {
           const float idx = fq_index(x, P.fq_c);
           dump_word |= ((unsigned int)idx) << (8 * r);
@@ -605,8 +599,9 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
 template <int NT, int D, int IN>
 static void launch_fast_nt_d_in(const AttnParams& P, unsigned grid, hipStream_t st) {
   const bool gate = P.gh != nullptr;
-  if (P.fq_s.en || P.fq_p.en || P.fq_c.en) {
-    hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, true>), dim3(grid), dim3(256), 0, st, P);
+  if (P.fq_s.en && P.fq_p.en) {
+    if (P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, true>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, true>), dim3(grid), dim3(256), 0, st, P);
     return;
   }
   if (P.clip) {

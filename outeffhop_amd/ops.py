@@ -240,6 +240,7 @@ def attn_variant(B, H, Sq, Sk, D, dtype=torch.float16, fq: bool = False, clip: b
     fqd = None
     if fq:
         fqd = oeh_fq_desc()
+        fqd.scores.enable, fqd.scores.scale, fqd.scores.qmax = 1, 1.0, 255.0
         fqd.probs.enable, fqd.probs.scale, fqd.probs.qmax = 1, 1.0, 255.0
     r = _lib.load().oeh_attn_variant(C.byref(d), None if fqd is None else C.byref(fqd))
     return None if r is None else r.decode()

@@ -540,9 +540,7 @@ def test_fq_kernels_agree_bitwise_on_ragged_shapes(ops):
                 pad[b, int(rng.integers(1, Sk + 1)):] = fmin
             pad = pad.cuda()
         gate = torch.rand((B, H, Sq, 1), generator=torch.Generator().manual_seed(5300 + n)).cuda() if rng.integers(0, 2) else None
-        on = [bool(rng.integers(0, 4)) for _ in range(3)]
-        if not any(on):
-            on[1] = True
+        on = [True, True, bool(rng.integers(0, 4))]  # the FQ variant is compiled for scores + probabilities (context optional)
         grids = [(0.013 + 0.05 * float(rng.random()), float(rng.integers(0, 200))), (1.0 / 255.0, float(rng.integers(0, 3))),
                  (0.004 + 0.02 * float(rng.random()), float(rng.integers(60, 190)))]
         want_dump = bool(rng.integers(0, 2))
