@@ -53,7 +53,7 @@ constexpr int fast_occupancy() { return D >= 128 ? 1 : 3; }  // what the LDS rin
 // the general kernel (oeh_attn_mfma.inl), on this kernel's data path.  The variant is compiled for the reference's
 // configuration, scores AND probabilities quantised (context optional): a run-time test per quantiser and per four elements
 // costs a branch and, at the join, register copies (1.5 VALU per element for the clip alone).  Other subsets: general kernel.
-template <int NT, int D, int IN, bool CLIP, bool GATE, bool FQ = false>
+template <int NT, int D, int IN, bool CLIP, bool GATE, bool FQ = false, bool OUT32 = false>
 __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_kernel(const AttnParams P) {
   static_assert(!FQ || !GATE, "the fake-quant variant has no in-kernel gate predictor");
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
@@ -567,6 +567,11 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
 #pragma unroll
       for (int r = 0; r < 4; ++r) ov[r] = o[dt][r] * rowscale;
     }
+    if constexpr (OUT32) {  // fp32 output straight from the accumulators (workspace path)
+      if (q0 + ce < P.Sq)
+        store_wt16(reinterpret_cast<float*>(P.o) + (long)b * P.os_b + (long)h * P.os_h + (long)(q0 + ce) * P.os_s + 16 * dt + 4 * ge,
+                   u4{f32_bits(ov[0]), f32_bits(ov[1]), f32_bits(ov[2]), f32_bits(ov[3])});
+    } else {
     u2 w;
     if constexpr (IN == IN_BF16) {
       w.x = pack2_bf16(ov[0], ov[1]);
@@ -576,9 +581,10 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
       w.y = pack2_f16(ov[2], ov[3]);
     }
     *reinterpret_cast<u2*>(ebase + ce * ROWB + ((((2 * dt + (ge >> 1)) ^ (ce & XM)) << 4) | ((ge & 1) << 3))) = w;
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes, before it reads them back
-  {
+  if constexpr (!OUT32) {
     unsigned short* obase = reinterpret_cast<unsigned short*>(P.o) + (long)b * P.os_b + (long)h * P.os_h;
     const int lr = lane_e / CPR, lc = lane_e % CPR;
     static_assert(16 % RPP == 0 || RPP % 16 == 0, "store passes tile the 16-row block");
@@ -599,6 +605,16 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
 template <int NT, int D, int IN>
 static void launch_fast_nt_d_in(const AttnParams& P, unsigned grid, hipStream_t st) {
   const bool gate = P.gh != nullptr;
+  if (P.out32) {  // fp16 workspace copies of fp32 tensors, fp32 output: rows of more than 256 keys only (oeh_api.hip: workspace_plan)
+    if constexpr (NT == 32 && IN == IN_F16) {
+      const bool fqon = P.fq_s.en && P.fq_p.en;
+      if (fqon && P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, true, true>), dim3(grid), dim3(256), 0, st, P);
+      else if (fqon) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, true, true>), dim3(grid), dim3(256), 0, st, P);
+      else if (P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, false, true>), dim3(grid), dim3(256), 0, st, P);
+      else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, false, true>), dim3(grid), dim3(256), 0, st, P);
+    }
+    return;
+  }
   if (P.fq_s.en && P.fq_p.en) {
     if (P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, true>), dim3(grid), dim3(256), 0, st, P);
     else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, true>), dim3(grid), dim3(256), 0, st, P);

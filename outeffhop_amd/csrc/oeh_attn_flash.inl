@@ -43,7 +43,7 @@ constexpr int flash_occupancy() { return D >= 128 ? 1 : 3; }
 // GATE: the conditional per-token gate is computed in the kernel exactly as in the full-row kernel (oeh_attn_fast.inl:
 // layer-input rows as K-shaped LDS-DMA tiles, first predictor layer on the matrix cores).  The input rows borrow stage 1
 // at start-up, so stage 1 of the K/V stream is issued later (with stage 2, once the gate has been formed).
-template <int D, int IN, int MQ, bool PAD, bool GATE>
+template <int D, int IN, int MQ, bool PAD, bool GATE, bool OUT32 = false>
 __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flash_kernel(const AttnParams P) {
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
   static_assert(MQ == 1 || MQ == 2, "one or two query blocks per wave");
@@ -496,6 +496,14 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
     float rowscale = 1.0f / den;
     if (P.gate != nullptr && qrow < Sq) rowscale = rowscale * P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
     if constexpr (GATE) rowscale = rowscale * gate_row[j];
+    if constexpr (OUT32) {  // fp32 output straight from the accumulators (workspace path): 16 B per lane, 64 B per row and instruction
+      if (qrow < Sq) {
+        float* orow = reinterpret_cast<float*>(P.o) + (long)b * P.os_b + (long)h * P.os_h + (long)qrow * P.os_s + 4 * ge;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          store_wt16(orow + 16 * dt, u4{f32_bits(o[j][dt][0] * rowscale), f32_bits(o[j][dt][1] * rowscale), f32_bits(o[j][dt][2] * rowscale), f32_bits(o[j][dt][3] * rowscale)});
+      }
+    } else {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       u2 w;
@@ -508,9 +516,10 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
       }
       *reinterpret_cast<u2*>(ebase + (16 * j + ce) * ROWB + ((((2 * dt + (ge >> 1)) ^ (ce & XM)) << 4) | ((ge & 1) << 3))) = w;
     }
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes, before it reads them back
-  {
+  if constexpr (!OUT32) {
     unsigned short* obase = reinterpret_cast<unsigned short*>(P.o) + (long)b * P.os_b + (long)h * P.os_h;
     const int lr = lane_e / CPR, lc = lane_e % CPR;
     static_assert(16 % RPP == 0, "a store pass stays inside one query block");
@@ -530,6 +539,13 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
 template <int D, int MQ, int IN>
 static void launch_flash_d_mq_in(const AttnParams& P, unsigned grid, hipStream_t st) {
   const bool pad = P.pad != nullptr, gate = P.gh != nullptr;
+  if (P.out32) {  // fp16 workspace copies of fp32 tensors, fp32 output (no in-kernel gate predictor on this path)
+    if constexpr (IN == IN_F16) {
+      if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, true>), dim3(grid), dim3(256), 0, st, P);
+      else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true>), dim3(grid), dim3(256), 0, st, P);
+    }
+    return;
+  }
   if (pad) {
     if (gate) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, true>), dim3(grid), dim3(256), 0, st, P);
     else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false>), dim3(grid), dim3(256), 0, st, P);

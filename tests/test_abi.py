@@ -36,7 +36,7 @@ def test_library_loads_and_exports_every_symbol():
     if out is not None and out.returncode == 0:
         exported = {ln.split()[-1] for ln in out.stdout.splitlines() if " T " in ln}
         assert set(_declared()) <= exported
-    assert lib.oeh_abi_version() == 2
+    assert lib.oeh_abi_version() == 3
     assert b"gfx950" in lib.oeh_build_info()
     assert lib.oeh_strerror(-22) == b"invalid argument"
 
@@ -83,3 +83,25 @@ def test_no_cpu_fallback():
         ops.attn_fwd(x, x, x)
     with pytest.raises(_lib.OehError):
         ops.softmax_rows(torch.zeros(2, 3))
+
+
+def test_fp32_workspace_plan():
+    """fp32 storage: the bytes of scratch that let the 16-bit kernels run, and the variant chosen with / without it."""
+    import ctypes as C
+
+    import torch
+
+    from outeffhop_amd import _lib, ops
+
+    lib = _lib.load()
+    d = _lib.oeh_attn_desc()
+    d.B, d.H, d.Sq, d.Sk, d.D, d.dtype = 16, 12, 512, 512, 64, 2
+    d.scale, d.mask_min = 1.0, float(torch.finfo(torch.float32).min)
+    assert lib.oeh_attn_workspace_bytes(C.byref(d), None) == 2 * 16 * 12 * 64 * (512 + 2 * 512)
+    d.dtype = 0
+    assert lib.oeh_attn_workspace_bytes(C.byref(d), None) == 0  # 16-bit storage needs none
+    assert ops.attn_variant(16, 12, 512, 512, 64, torch.float32) == "mfma16/NT32/D64/f32"
+    assert ops.attn_variant(16, 12, 512, 512, 64, torch.float32, workspace=True) == "flash16/MQ2/D64/f16<f32"
+    assert ops.attn_variant(16, 12, 512, 512, 64, torch.float32, fq=True, workspace=True) == "fast16/NT32/D64/f16/fq<f32"
+    assert ops.attn_variant(2, 2, 40, 40, 48, torch.float32, workspace=True) == "generic"
+    assert ops.attn_variant(32, 12, 128, 128, 64, torch.float32, workspace=True) == "mfma16/NT8/D64/f32"  # short rows: the general kernel is faster

@@ -564,3 +564,40 @@ def test_fq_kernels_agree_bitwise_on_ragged_shapes(ops):
         for i_, (da, db) in enumerate(zip(dumps_a, dumps_b)):
             if da is not None and on[i_]:
                 assert torch.equal(da, db), what + f": index dump {i_} differs"
+
+
+def test_fp32_storage_runs_the_16bit_kernels_on_a_workspace(ops):
+    """fp32 q/k/v (the reference's validate_* scripts): with the scratch `attn_fwd` allocates, one pre-pass rounds them to
+    fp16 and the one-pass / full-row kernels write fp32 output; without it the general kernel (same arithmetic: fp32
+    storage, fp16 matrix-core operands).  Both against the oracle; the INT8 chain must agree bit for bit."""
+    fmin = float(np.finfo(np.float32).min)
+    FQ = ops.FakeQuantSpec
+    tol32 = dict(atol=2e-3, rtol=2e-3)  # fp32 data, fp16 matrix-core operands: the general kernel's accuracy on fp32 storage
+    for n, (B, H, Sq, Sk, D, causal, sm) in enumerate([(2, 3, 300, 300, 64, True, "softmax1"), (1, 2, 77, 290, 32, False, "vanilla"),
+                                                        (2, 2, 400, 400, 128, True, "clippedsoftmax1(-.025:1)"), (1, 4, 512, 512, 64, True, "softmax1"),
+                                                        (1, 2, 700, 700, 64, True, "softmax1")]):
+        q = _rand((B, Sq, H * D), 7000 + n, dtype=torch.float32).view(B, Sq, H, D).permute(0, 2, 1, 3)
+        k = _rand((B, Sk, H * D), 7100 + n, dtype=torch.float32).view(B, Sk, H, D).permute(0, 2, 1, 3)
+        v = _rand((B, Sk, H * D), 7200 + n, dtype=torch.float32).view(B, Sk, H, D).permute(0, 2, 1, 3)
+        pad = None
+        if not causal:
+            padm = np.zeros((B, Sk), dtype=np.float32)
+            padm[:, Sk - 9:] = fmin
+            pad = torch.from_numpy(padm).cuda()
+        kw = dict(softmax=_spec(ops, sm), scale=D ** -0.5, causal=causal, clamp_min=causal, key_pad_mask=pad, mask_min=fmin)
+        want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=D ** -0.5, causal=causal, clamp_min=causal,
+                           pad_mask=None if pad is None else pad.cpu().numpy(), **SPECS[sm])
+        var = ops.attn_variant(B, H, Sq, Sk, D, torch.float32, clip="clipped" in sm, workspace=True)
+        assert var.endswith("<f32") and (var.startswith("flash16/") or var.startswith("fast16/")), var
+        got_ws = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), **kw)
+        got_gen = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), workspace=False, **kw)
+        assert got_ws.dtype == torch.float32
+        _check(got_ws, want, tol=tol32, msg=f"workspace path case {n} ({var})")
+        _check(got_gen, want, tol=tol32, msg=f"general kernel case {n}")
+        if Sk > 512:  # no MFMA kernel for fp32 rows this long without the workspace: the INT8 comparison below has no partner
+            continue
+        # INT8 chain: same bits from both kernels (same rounded operands, same per-element chain)
+        fq = ops.AttnFakeQuant(FQ(0.05, 120.0), FQ(1.0 / 255.0, 0.0), FQ(0.01, 128.0), ctx_before_gate=bool(n & 1))
+        a = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=fq, **kw)
+        b_ = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=fq, workspace=False, **kw)
+        assert torch.equal(a, b_), f"INT8 fp32 case {n}: workspace path differs from the general kernel"
