@@ -37,6 +37,11 @@ WORKLOADS = {
                         desc="OPT-125m attention core B=16 H=12 S=512 d=64 fp16 causal clippedsoftmax1(-.025:1)"),
     "opt_int8": dict(B=16, H=12, S=512, d=64, order="opt", sm=(1, False, 0.0, 1.0), int8=True, gate=False,
                      desc="OPT-125m attention core B=16 H=12 S=512 d=64 fp16 causal softmax1 + 3 fused INT8 fake-quantisers"),
+    # fp32 storage, as the reference's validate_clm.py runs the model (fp16 matrix-core operands; include/oeh.h: workspace)
+    "opt_softmax1_fp32": dict(B=16, H=12, S=512, d=64, order="opt", sm=(1, False, 0.0, 1.0), int8=False, gate=False, fp32=True,
+                              desc="OPT-125m attention core B=16 H=12 S=512 d=64 fp32 storage causal softmax1"),
+    "opt_int8_fp32": dict(B=16, H=12, S=512, d=64, order="opt", sm=(1, False, 0.0, 1.0), int8=True, gate=False, fp32=True,
+                          desc="OPT-125m attention core B=16 H=12 S=512 d=64 fp32 storage causal softmax1 + 3 fused INT8 fake-quantisers"),
     "bert_softmax1": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=False, gate=False,
                           desc="BERT-base attention core B=32 H=12 S=128 d=64 fp16 key-padding mask softmax1"),
     "bert_gated": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=False, gate=True,
@@ -185,8 +190,9 @@ def main():
             q = (q.float() * d ** -0.5).half()  # OPT scales q before QK^T (opt_attention.py:167)
         k = torch.randn(B, S, H * d, generator=g).half()
         v = torch.randn(B, S, H * d, generator=g).half()
-        view = lambda t: t.to(dev).view(B, S, H, d).permute(0, 2, 1, 3)  # noqa: E731  (B,H,S,d) view of (B,S,E)
-        o = torch.empty(B, S, H, d, dtype=torch.float16, device=dev).permute(0, 2, 1, 3)
+        sdt = torch.float32 if w.get("fp32") else torch.float16
+        view = lambda t: t.to(dev).to(sdt).view(B, S, H, d).permute(0, 2, 1, 3)  # noqa: E731  (B,H,S,d) view of (B,S,E)
+        o = torch.empty(B, S, H, d, dtype=sdt, device=dev).permute(0, 2, 1, 3)
         sets.append((view(q), view(k), view(v), o))
     pad = None
     if w["order"] == "bert":
@@ -212,7 +218,7 @@ def main():
     # ---- prebuilt C-ABI descriptors: the timed loop is `oeh_attn_fwd` and nothing else
     def make_call(q, k, v, o):
         dsc = _lib.oeh_attn_desc()
-        dsc.B, dsc.H, dsc.Sq, dsc.Sk, dsc.D, dsc.dtype = B, H, S, S, d, _lib.OEH_F16
+        dsc.B, dsc.H, dsc.Sq, dsc.Sk, dsc.D, dsc.dtype = B, H, S, S, d, (_lib.OEH_F32 if w.get("fp32") else _lib.OEH_F16)
         for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", o)):
             getattr(dsc, name)[:] = [t.stride(0), t.stride(1), t.stride(2)]
         if w["order"] == "opt":
@@ -233,11 +239,18 @@ def main():
             fqd = _lib.oeh_fq_desc()
             ops._fill_fq(fqd.scores, fq.scores), ops._fill_fq(fqd.probs, fq.probs), ops._fill_fq(fqd.ctx, fq.ctx)
             fqd.ctx_quant_before_gate = int(fq.ctx_before_gate)
+        if w.get("fp32"):  # one scratch for all layers: the launches are ordered on one stream
+            need = int(lib.oeh_attn_workspace_bytes(C.byref(dsc), None if fqd is None else C.byref(fqd)))
+            if need > 0:
+                if not workspace:
+                    workspace.append(torch.empty(need, dtype=torch.uint8, device=dev))
+                dsc.workspace, dsc.workspace_bytes = workspace[0].data_ptr(), need
         args = (C.byref(dsc), C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()),
                 C.c_void_p(o.data_ptr()), None if fqd is None else C.byref(fqd))
         return args, (dsc, fqd)
 
     gate_descs = []
+    workspace = []
     calls = [make_call(*s) for s in sets]
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     fwd = lib.oeh_attn_fwd
@@ -312,7 +325,7 @@ def main():
         launches = a.steps * L
         layer_tokens = world * B * S * L * a.steps
         kern_s = dev_ms * 1e-3 / launches
-        elt = 2
+        elt = 4 if w.get("fp32") else 2
         alg_bytes = 4 * B * H * S * d * elt + (B * S * 4 if pad is not None else 0) + (B * S * H * d * elt if gate is not None else 0)  # + gate input (hidden states)
         achieved = alg_bytes / kern_s / 1e9
         traffic = None
@@ -333,10 +346,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16 storage, f32 accumulate" if not w["int8"] else "f16 storage, f32 accumulate, 8-bit fake-quant grids",
+            "dtype": ("f32 storage, f16 matrix operands, f32 accumulate" if w.get("fp32") else "f16 storage, f32 accumulate") + (", 8-bit fake-quant grids" if w["int8"] else ""),
             "data": "synthetic",
             "config": {
-                "workload": w["desc"], "variant": ops.attn_variant(B, H, S, S, d, fq=w["int8"], clip=bool(w["sm"][1])),
+                "workload": w["desc"], "variant": ops.attn_variant(B, H, S, S, d, torch.float32 if w.get("fp32") else torch.float16, fq=w["int8"], clip=bool(w["sm"][1]), workspace=bool(w.get("fp32"))),
                 "batch_per_gpu": B, "seq_len": S, "heads": H, "head_dim": d, "layers_per_step": L,
                 "launches_per_step": L, "model_tokens_per_s": world * B * S * a.steps / wall,
                 "parallelism": f"batch-shard x{world}, no collective in the timed region",
