@@ -136,6 +136,39 @@ class GateState:
         return gate
 
 
+# ---- fused q/k/v projection: the three E->E Linears of a self-attention layer as ONE library GEMM with the
+# concatenated weight, returning strided (B,S,E) views of its (B,S,3E) output (the attention kernel takes strides, so there is
+# no copy either side).  Inference only: parameters keep the reference's names (query/key/value, q_proj/k_proj/v_proj) and the
+# concatenation is cached per module and rebuilt when a weight changes (tensor version counters / storage pointers).
+FUSE_QKV = True
+
+
+def fused_qkv(owner: nn.Module, x: torch.Tensor, lq: nn.Linear, lk: nn.Linear, lv: nn.Linear, q_scale: float = 1.0):
+    """(q, k, v) = (lq(x) * q_scale, lk(x), lv(x)) from one GEMM, or None when the fused form does not apply (autograd on,
+    QuantLinear / hooked / unequal layers, q_scale not a power of two - folding it into the weights is exact only then)."""
+    if not FUSE_QKV or torch.is_grad_enabled() or not x.is_cuda:
+        return None
+    if not (type(lq) is nn.Linear and type(lk) is nn.Linear and type(lv) is nn.Linear) or has_hooks(lq, lk, lv):
+        return None
+    ws = (lq.weight, lk.weight, lv.weight)
+    bs = (lq.bias, lk.bias, lv.bias)
+    if not (ws[0].shape == ws[1].shape == ws[2].shape) or ws[0].dtype != x.dtype or any((b is None) != (bs[0] is None) for b in bs):
+        return None
+    mant, _ = math.frexp(q_scale)
+    if mant != 0.5:
+        return None
+    key = tuple((t._version, t.data_ptr()) for t in ws + tuple(b for b in bs if b is not None)) + (q_scale, x.dtype)
+    cache = owner.__dict__.get("_oeh_qkv_cache")
+    if cache is None or cache[0] != key:
+        w = torch.cat([ws[0].detach() * q_scale, ws[1].detach(), ws[2].detach()], dim=0).contiguous()
+        b = None if bs[0] is None else torch.cat([bs[0].detach() * q_scale, bs[1].detach(), bs[2].detach()], dim=0).contiguous()
+        cache = (key, w, b)
+        owner.__dict__["_oeh_qkv_cache"] = cache
+    y = torch.nn.functional.linear(x, cache[1], cache[2])
+    e = ws[0].shape[0]
+    return y[..., :e], y[..., e:2 * e], y[..., 2 * e:]
+
+
 def has_hooks(*mods: nn.Module) -> bool:
     return any(len(m._forward_hooks) or len(m._forward_pre_hooks) for m in mods)
 

@@ -14,7 +14,7 @@ from typing import Optional, Tuple
 import torch
 from torch import nn
 
-from .attention import AttentionGateType, GateState, attention_core, build_gate, has_hooks, unfused_core
+from .attention import AttentionGateType, GateState, attention_core, build_gate, fused_qkv, has_hooks, unfused_core
 from .softmax import clipped_softmax, spec_of
 
 
@@ -68,6 +68,14 @@ class BertSelfAttentionWithExtras(nn.Module):
 
     # ------------------------------------------------------------------------------------------------
     def _project(self, hidden_states, attention_mask, encoder_hidden_states, encoder_attention_mask, past_key_value):
+        if encoder_hidden_states is None:  # self-attention: one GEMM for the three projections (attention.fused_qkv)
+            qkv = fused_qkv(self, hidden_states, self.query, self.key, self.value)
+            if qkv is not None:
+                q, k, v = (self.transpose_for_scores(t) for t in qkv)
+                if past_key_value is not None:
+                    k = torch.cat([past_key_value[0], k], dim=2)
+                    v = torch.cat([past_key_value[1], v], dim=2)
+                return q, k, v, attention_mask
         q = self.transpose_for_scores(self.query(hidden_states))
         if encoder_hidden_states is not None:
             attention_mask = encoder_attention_mask

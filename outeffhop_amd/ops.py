@@ -61,7 +61,12 @@ def _need_gpu(*ts):
             raise _lib.OehError("outeffhop_amd ops need GPU tensors: the HIP library is the only implementation")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # the handle without building a Stream object (9 us -> 0.5 us)
+
+
 def _stream() -> C.c_void_p:
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

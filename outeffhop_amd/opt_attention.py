@@ -16,7 +16,7 @@ from typing import Optional, Tuple
 import torch
 from torch import nn
 
-from .attention import AttentionGateType, GateState, attention_core, build_gate, has_hooks, unfused_core
+from .attention import AttentionGateType, GateState, attention_core, build_gate, fused_qkv, has_hooks, unfused_core
 from .softmax import clipped_softmax, clipped_softmax1, spec_of
 
 
@@ -79,8 +79,16 @@ class OPTAttentionWithExtras(nn.Module):
                 ) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[Tuple[torch.Tensor]]]:
         """Input shape: Batch x Time x Channel"""
         bsz, tgt_len, _ = hidden_states.size()
-        q = self._heads(self.q_proj(hidden_states) * self.scaling, bsz)
-        if key_value_states is not None and past_key_value is not None:
+        qkv = None
+        if key_value_states is None:  # self-attention: one GEMM for the three projections, the q scaling folded in (attention.fused_qkv)
+            qkv = fused_qkv(self, hidden_states, self.q_proj, self.k_proj, self.v_proj, self.scaling)
+        q = self._heads(qkv[0] if qkv is not None else self.q_proj(hidden_states) * self.scaling, bsz)
+        if qkv is not None:
+            k, v = self._heads(qkv[1], bsz), self._heads(qkv[2], bsz)
+            if past_key_value is not None:
+                k = torch.cat([past_key_value[0], k], dim=2)
+                v = torch.cat([past_key_value[1], v], dim=2)
+        elif key_value_states is not None and past_key_value is not None:
             k, v = past_key_value[0], past_key_value[1]
         elif key_value_states is not None:
             k, v = self._heads(self.k_proj(key_value_states), bsz), self._heads(self.v_proj(key_value_states), bsz)

@@ -261,3 +261,42 @@ def test_gated_modules_in_16bit_use_the_in_kernel_predictor(oa):
         got = o16(hs, attention_mask=cm.half().clamp(min=fmin16))[0]
     _close(got, want.cpu().numpy(), "opt gated fp16", dict(atol=6e-3, rtol=6e-3))
     _close(o16.last_gate_all_probs, o32.last_gate_all_probs.cpu().numpy(), "opt gate probs", dict(atol=2e-3, rtol=2e-3))
+
+
+def test_fused_qkv_projection_matches_three_linears(oa):
+    """one GEMM with the concatenated q/k/v weights (OPT: the q scaling folded in) feeding strided views to
+    the kernel - same module output as three Linears, and the cache follows in-place weight updates."""
+    import torch
+
+    from outeffhop_amd import attention
+    from outeffhop_amd.opt_attention import OPTAttentionWithExtras
+    from outeffhop_amd.softmax import SOFTMAX_MAPPING
+
+    torch.manual_seed(5)
+    dev = torch.device("cuda:0")
+    fmin = torch.finfo(torch.float16).min
+    m = OPTAttentionWithExtras(256, 4, is_decoder=True, softmax_fn=SOFTMAX_MAPPING["softmax1"]).to(dev).half().eval()
+    x = torch.randn(3, 70, 256, device=dev).half()
+    mask = torch.full((70, 70), fmin, device=dev, dtype=torch.float16).triu(1)[None, None].expand(3, 1, 70, 70)
+    with torch.no_grad():
+        outs = {}
+        for fused in (True, False):
+            attention.FUSE_QKV = fused
+            try:
+                outs[fused] = m(x, attention_mask=mask)[0].float()
+            finally:
+                attention.FUSE_QKV = True
+        assert "_oeh_qkv_cache" in m.__dict__
+        assert torch.allclose(outs[True], outs[False], atol=2e-3, rtol=2e-3)
+        m.q_proj.weight.mul_(0.5)  # in-place update: the version counter changes, the cache must be rebuilt
+        a = m(x, attention_mask=mask)[0].float()
+        attention.FUSE_QKV = False
+        try:
+            b = m(x, attention_mask=mask)[0].float()
+        finally:
+            attention.FUSE_QKV = True
+        assert torch.allclose(a, b, atol=2e-3, rtol=2e-3) and not torch.allclose(a, outs[True], atol=1e-4)
+    # with autograd on the three Linears run (the cached concatenation is not part of the graph)
+    m.train()
+    y = m(x, attention_mask=mask)[0]
+    assert y.requires_grad

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Module-level timing (GPU box): the whole attention module (projections + fused core + output projection) of the OPT-125m
+and BERT-base layers, and its parts, in attention-layer tokens/s.  SURVEY 8(f)-1: what sits either side of the core.
+usage: python tools/module_bench.py [fp16|fp32]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from outeffhop_amd import attention
+from outeffhop_amd.bert_attention import BertSelfAttentionWithExtras
+from outeffhop_amd.opt_attention import OPTAttentionWithExtras
+from outeffhop_amd.softmax import SOFTMAX_MAPPING
+
+
+def timeit(fn, n=200):
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    while time.perf_counter() - t < 0.2:
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+
+
+def main():
+    dt = torch.float32 if (len(sys.argv) > 1 and sys.argv[1] == "fp32") else torch.float16
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    fmin = torch.finfo(torch.float32).min
+    with torch.no_grad():
+        # OPT-125m layer: B=16, S=512, E=768, H=12, causal mask tensor as HF passes it
+        B, S, E, H = 16, 512, 768, 12
+        m = OPTAttentionWithExtras(E, H, is_decoder=True, softmax_fn=SOFTMAX_MAPPING["softmax1"]).to(dev).to(dt).eval()
+        x = torch.randn(B, S, E, device=dev, dtype=dt)
+        mask = torch.full((S, S), fmin, device=dev).triu(1)[None, None].expand(B, 1, S, S).to(dt if dt == torch.float32 else torch.float16)
+        mask = torch.clamp(mask.float(), min=torch.finfo(dt).min).to(dt)
+        for fused in (False, True):
+            attention.FUSE_QKV = fused
+            t_mod = timeit(lambda: m(x, attention_mask=mask))
+            print(f"OPT-125m module {dt} fused_qkv={fused}: {t_mod:8.1f} us  {B * S / t_mod:8.1f} M tokens/s")
+        t_q = timeit(lambda: m.q_proj(x))
+        t_o = timeit(lambda: m.out_proj(x))
+        print(f"   parts: one E->E Linear {t_q:.1f} us, out_proj {t_o:.1f} us")
+        # BERT-base layer: B=32, S=128
+        from types import SimpleNamespace
+        cfg = SimpleNamespace(hidden_size=768, num_attention_heads=12, attention_probs_dropout_prob=0.0, max_position_embeddings=512,
+                              is_decoder=False, position_embedding_type="absolute")
+        B, S = 32, 128
+        bm = BertSelfAttentionWithExtras(cfg, softmax_fn=SOFTMAX_MAPPING["softmax1"]).to(dev).to(dt).eval()
+        xb = torch.randn(B, S, E, device=dev, dtype=dt)
+        pad = torch.zeros(B, 1, 1, S, device=dev, dtype=dt)
+        pad[:, :, :, 100:] = torch.finfo(dt).min
+        for fused in (False, True):
+            attention.FUSE_QKV = fused
+            t_mod = timeit(lambda: bm(xb, attention_mask=pad))
+            print(f"BERT-base module {dt} fused_qkv={fused}: {t_mod:8.1f} us  {B * S / t_mod:8.1f} M tokens/s")
+
+
+if __name__ == "__main__":
+    main()
