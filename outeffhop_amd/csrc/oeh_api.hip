@@ -110,13 +110,23 @@ int g_force_flash = 0;                   // tools/microbench.py only
 // The one-pass kernel (oeh_attn_flash.inl) additionally needs the plain softmax_n (no clip) and, with key padding,
 // softmax_1 (a fully padded row is 0 there; under vanilla softmax it is uniform over all keys, which a one-pass
 // kernel that may skip tiles cannot reproduce).  No Sk limit.
-bool flash_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
+bool flash_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq, bool short_rows_too = false) {
   if (!fast_eligible(d, fq) || d->clip || any_fq(fq)) return false;
   if (d->key_pad_mask != nullptr && d->softmax_base != OEH_SOFTMAX_ONE) return false;
+  if (short_rows_too) return true;
   // short rows (<= 128 keys) fit the full-row kernel's registers in one pass, which measures faster there
   // (BERT-base S=128: 10.0 vs 11.7 us per launch)
   if (d->Sk <= 128 && !g_force_flash) return false;
   return true;
+}
+
+// fp32 storage on the one-pass kernel (SRC32 variants: tiles staged through registers, fp16 operands, fp32 output): the same
+// conditions on the problem; the in-kernel gate predictor reads a 16-bit layer input and is not available
+bool flash32_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
+  if (d->dtype != OEH_F32 || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
+  oeh_attn_desc t = *d;
+  t.dtype = OEH_F16;
+  return flash_eligible(&t, fq, true);  // short rows as well: BERT-base S=128 15.4 us against 16.7 us in the general kernel
 }
 
 unsigned long long* g_stamps = nullptr;  // tools/timeline.py only
@@ -141,6 +151,7 @@ Variant pick_variant(const oeh_attn_desc* d, const void* q, const void* k, const
                                      aligned16(v, d->v_stride, eb) && aligned16(o, d->o_stride, eb));
   const bool d_ok = d->D == 32 || d->D == 64 || d->D == 128;
   if (d_ok && al && flash_eligible(d, fq) && !(g_variant_off & (1 << V_FLASH))) return V_FLASH;
+  if (d_ok && al && flash32_eligible(d, fq) && !(g_variant_off & ((1 << V_FLASH) | (1 << 6)))) return V_FLASH;
   if (shape_ok && p_exact && al && fast_eligible(d, fq) && !(g_variant_off & (1 << V_FAST))) return V_FAST;
   if (shape_ok && p_exact && al) return V_MFMA;
   if ((size_t)(d->D + d->Sk) * 4 <= 64 * 1024) return V_GENERIC;
@@ -204,8 +215,9 @@ int64_t workspace_plan(const oeh_attn_desc* d, const oeh_fq_desc* fq, oeh_attn_d
   t.q_stride[0] = H * d->Sq * D; t.q_stride[1] = (int64_t)d->Sq * D; t.q_stride[2] = D;
   t.k_stride[0] = H * d->Sk * D; t.k_stride[1] = (int64_t)d->Sk * D; t.k_stride[2] = D;
   t.v_stride[0] = t.k_stride[0]; t.v_stride[1] = t.k_stride[1]; t.v_stride[2] = D;
+  if (pick_variant(d, nullptr, nullptr, nullptr, nullptr, fq) == V_FLASH) return 0;  // read directly by the one-pass kernel
   const Variant v = pick_variant(&t, nullptr, nullptr, nullptr, nullptr, fq);
-  if (v != V_FLASH && v != V_FAST) return 0;
+  if (v != V_FAST) return 0;
   if (d16 != nullptr) *d16 = t;
   return 2 * (int64_t)d->B * H * D * ((int64_t)d->Sq + 2 * (int64_t)d->Sk);
 }
@@ -252,14 +264,14 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
     }
   }
   const Variant var = pick_variant(desc, q, k, v, o, fq);
-  if (var == V_NONE || (out32 && var != V_FLASH && var != V_FAST)) return OEH_ENOTSUP;
+  if (var == V_NONE || (out32 && var != V_FAST)) return OEH_ENOTSUP;
   if (desc->gate == nullptr && desc->gate_hidden != nullptr) {  // fused gate predictor: 16-bit MFMA variants, 16-B aligned rows
-    if ((var != V_FAST && var != V_FLASH) || desc->gate_units > 16) return OEH_ENOTSUP;  // one 16-unit MFMA tile of hidden units
+    if ((var != V_FAST && var != V_FLASH) || desc->gate_units > 16 || desc->dtype == OEH_F32) return OEH_ENOTSUP;  // one 16-unit MFMA tile of hidden units
     if (((reinterpret_cast<uintptr_t>(desc->gate_hidden) | (uintptr_t)(desc->gate_hidden_stride[0] * 2) | (uintptr_t)(desc->gate_hidden_stride[1] * 2)) & 15) != 0) return OEH_EALIGN;
   }
   AttnParams P;
   fill_params(P, desc, q, k, v, o, fq);
-  P.out32 = out32 ? 1 : 0;
+  P.out32 = (out32 || (var == V_FLASH && desc->dtype == OEH_F32)) ? 1 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (var == V_FLASH) {
     if (desc->scale_div != 0.0f) { P.scale = 1.0f / desc->scale_div; P.scale_div = 0.0f; }  // exact: power of two

@@ -43,9 +43,16 @@ constexpr int flash_occupancy() { return D >= 128 ? 1 : 3; }
 // GATE: the conditional per-token gate is computed in the kernel exactly as in the full-row kernel (oeh_attn_fast.inl:
 // layer-input rows as K-shaped LDS-DMA tiles, first predictor layer on the matrix cores).  The input rows borrow stage 1
 // at start-up, so stage 1 of the K/V stream is issued later (with stage 2, once the gate has been formed).
-template <int D, int IN, int MQ, bool PAD, bool GATE, bool OUT32 = false>
+// SRC32: q, k, v and o are fp32 (the reference's validate_* scripts run fp32 models).  The tiles then come through
+// registers - 32 B of fp32 per lane and piece, rounded to fp16 and written to the SAME LDS images the DMA produces - one
+// 64-key stage ahead: the loads of stage i+1 are issued right after the barrier of tile i and committed to LDS at the top
+// of tile i+1, so they have a tile of compute to land; one barrier per tile as before.  fp16 matrix-core operands, fp32
+// accumulation and fp32 output straight from the accumulators (OUT32): the general kernel's arithmetic on fp32 storage,
+// without its full-row structure and without a conversion pre-pass (which costs more HBM time than the attention itself).
+template <int D, int IN, int MQ, bool PAD, bool GATE, bool OUT32 = false, bool SRC32 = false>
 __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flash_kernel(const AttnParams P) {
-  static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
+  static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit matrix-core operands");
+  static_assert(!SRC32 || (OUT32 && !GATE && IN == IN_F16), "fp32 storage: fp16 operands, fp32 output, no in-kernel gate predictor");
   static_assert(MQ == 1 || MQ == 2, "one or two query blocks per wave");
   constexpr int ROWB = 2 * D;
   constexpr int TILEB = 64 * ROWB;      // one operand tile (64 keys)
@@ -151,7 +158,54 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   // j*TILEB of stage R-1).  The bytes a workgroup needs before its first MFMA are then Q + K tile 0; with Q as ordinary
   // register loads behind the first two stages (returns are in issue order) they were Q + 2 K tiles + 2 V tiles, and the
   // measured start-up is paced by bytes per CU (~20 B/cycle), not by one memory latency.
-  {
+  // SRC32: the register-staged stream (see the kernel comment)
+  f4 kreg[SRC32 ? G : 1][2], vreg[SRC32 ? G : 1][2];
+  auto cvt8 = [](const f4 lo, const f4 hi) { return u4{pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]), pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3])}; };
+  auto load_regs = [&](const int t) {
+    if constexpr (SRC32) {
+      const float* ksrc = reinterpret_cast<const float*>(P.k) + (long)b * P.ks_b + (long)h * P.ks_h;
+      const float* vsrc = reinterpret_cast<const float*>(P.v) + (long)b * P.vs_b + (long)h * P.vs_h;
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int row = piece_row(j);
+        const int kr = min(t * 64 + row, Sk - 1);  // rows past Sk: finite data, masked later
+        const float* kp = ksrc + (long)kr * P.ks_s + (pch ^ swz_k<D>(row)) * 8;
+        const float* vp = vsrc + (long)kr * P.vs_s + ((((pch >> 1) ^ swz_v<D>(row)) << 1) | (pch & 1)) * 8;
+        kreg[j][0] = *reinterpret_cast<const f4*>(kp);
+        kreg[j][1] = *reinterpret_cast<const f4*>(kp + 4);
+        vreg[j][0] = *reinterpret_cast<const f4*>(vp);
+        vreg[j][1] = *reinterpret_cast<const f4*>(vp + 4);
+      }
+    }
+  };
+  auto commit_regs = [&](const int slot) {
+    if constexpr (SRC32) {
+      unsigned char* base = lds + slot * STAGEB + (wave * G) * 1024 + lane * 16;
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        *reinterpret_cast<u4*>(base + j * 1024) = cvt8(kreg[j][0], kreg[j][1]);
+        *reinterpret_cast<u4*>(base + TILEB + j * 1024) = cvt8(vreg[j][0], vreg[j][1]);
+      }
+    }
+  };
+  if constexpr (SRC32) {  // Q: the same LDS image the DMA would write (slab t as a K-shaped tile at t*TILEB of stage R-1)
+    const float* qsrc = reinterpret_cast<const float*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h;
+    unsigned char* qdst = lds + (R - 1) * STAGEB + (wave * G) * 1024 + lane * 16;
+#pragma unroll
+    for (int t = 0; t < MQ; ++t) {
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int row = piece_row(j);
+        int qrow = 64 * slab[t] + row;
+        qrow = qrow < Sq ? qrow : Sq - 1;
+        const float* qp = qsrc + (long)qrow * P.qs_s + (pch ^ swz_k<D>(row)) * 8;
+        const f4 lo = __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp));
+        const f4 hi = __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp + 4));
+        *reinterpret_cast<u4*>(qdst + t * TILEB + j * 1024) = cvt8(lo, hi);
+      }
+    }
+    load_regs(0);
+  } else {
     const unsigned char* qbase = reinterpret_cast<const unsigned char*>(P.q) + 2 * ((long)b * P.qs_b + (long)h * P.qs_h);
     const unsigned qslot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((R - 1) * STAGEB + wave * G * 1024));
 #pragma unroll
@@ -181,8 +235,10 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
       }
     }
   }
-  issue_next();
-  if (!GATE && 1 < n_kt) issue_next();
+  if constexpr (!SRC32) {
+    issue_next();
+    if (!GATE && 1 < n_kt) issue_next();
+  }
   if constexpr (GATE) {  // weights: hidden unit c, inputs 8g.. of each 32-wide k-step; b1 / w2 of units 4g..4g+3
     const int mm = P.g_units > 0 ? P.g_units : 1;  // <= 16 (host)
     const bool uv = c < mm;
@@ -204,6 +260,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   }
   // Q and K tile 0 landed, for every wave: all but the G (V tile 0) + 2G (stage 1) younger transfers
   auto wait_vm = [&](auto nc) {  // s_waitcnt vmcnt(N * G), N compile-time
+    if constexpr (SRC32) return;   // no DMA in flight: the compiler waits for its own loads where they are used
     constexpr int N = decltype(nc)::value * G;
     static_assert(N <= 16, "vmcnt immediates used below");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -455,6 +512,22 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
 
   using J0_0 = std::integral_constant<int, 0>;
   using J0_1 = std::integral_constant<int, 1>;
+  if constexpr (SRC32) {
+    int slot_r = 0;
+    for (int i = 0; i < n_kt; ++i) {
+      commit_regs(slot_r);                  // stage i (its loads were issued a tile ago) -> LDS; the slot's last reader was tile i-3
+      barrier_mem();
+      if (i + 1 < n_kt) load_regs(i + 1);   // lands while tile i is computed
+      const int soff = slot_r * STAGEB;
+      slot_r = (slot_r == R - 1) ? 0 : slot_r + 1;
+      if (i >= nkb[MQ - 1]) continue;
+      if (MQ == 2 && i >= nkb[0]) {
+        if constexpr (MQ == 2) tile(J0_1{}, std::false_type{}, i, soff);
+      } else {
+        tile(J0_0{}, std::false_type{}, i, soff);
+      }
+    }
+  } else {
   tile(J0_0{}, std::true_type{}, 0, 0);  // every block sees key 0: tile 0 is computed by every wave, for all its blocks
   OEH_STAMP(6);
   int slot_i = 1;
@@ -475,6 +548,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
       tile(J0_0{}, std::false_type{}, i, soff);
     }
     if (i < 8) OEH_STAMP(6 + 3 * i);
+  }
   }
   OEH_STAMP(2);
 
@@ -539,10 +613,10 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
 template <int D, int MQ, int IN>
 static void launch_flash_d_mq_in(const AttnParams& P, unsigned grid, hipStream_t st) {
   const bool pad = P.pad != nullptr, gate = P.gh != nullptr;
-  if (P.out32) {  // fp16 workspace copies of fp32 tensors, fp32 output (no in-kernel gate predictor on this path)
+  if (P.out32) {  // fp32 storage read directly (SRC32), fp32 output; no in-kernel gate predictor on this path
     if constexpr (IN == IN_F16) {
-      if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, true>), dim3(grid), dim3(256), 0, st, P);
-      else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true>), dim3(grid), dim3(256), 0, st, P);
+      if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, true, true>), dim3(grid), dim3(256), 0, st, P);
+      else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true, true>), dim3(grid), dim3(256), 0, st, P);
     }
     return;
   }

@@ -567,9 +567,11 @@ def test_fq_kernels_agree_bitwise_on_ragged_shapes(ops):
 
 
 def test_fp32_storage_runs_the_16bit_kernels_on_a_workspace(ops):
-    """fp32 q/k/v (the reference's validate_* scripts): with the scratch `attn_fwd` allocates, one pre-pass rounds them to
-    fp16 and the one-pass / full-row kernels write fp32 output; without it the general kernel (same arithmetic: fp32
-    storage, fp16 matrix-core operands).  Both against the oracle; the INT8 chain must agree bit for bit."""
+    """fp32 q/k/v (the reference's validate_* scripts): plain softmax(_1) is read directly by the one-pass kernel (tiles
+    staged through registers); clipped softmax and the INT8 chain run the full-row kernel on fp16 copies in the scratch
+    `attn_fwd` allocates; `workspace=False` + the diagnostic switch give the general kernel (same arithmetic: fp32 storage,
+    fp16 matrix-core operands).  All against the oracle; the INT8 chain must agree bit for bit."""
+    from outeffhop_amd import _lib
     fmin = float(np.finfo(np.float32).min)
     FQ = ops.FakeQuantSpec
     tol32 = dict(atol=2e-3, rtol=2e-3)  # fp32 data, fp16 matrix-core operands: the general kernel's accuracy on fp32 storage
@@ -588,13 +590,17 @@ def test_fp32_storage_runs_the_16bit_kernels_on_a_workspace(ops):
         want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=D ** -0.5, causal=causal, clamp_min=causal,
                            pad_mask=None if pad is None else pad.cpu().numpy(), **SPECS[sm])
         var = ops.attn_variant(B, H, Sq, Sk, D, torch.float32, clip="clipped" in sm, workspace=True)
-        assert var.endswith("<f32") and (var.startswith("flash16/") or var.startswith("fast16/")), var
+        assert (var.startswith("flash16/") and var.endswith("/f32")) or (var.startswith("fast16/") and var.endswith("<f32")), var
         got_ws = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), **kw)
-        got_gen = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), workspace=False, **kw)
+        _lib.load().oeh_debug_set_variant(1 << 6, 0)  # fp32 one-pass variants off
+        try:
+            got_gen = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), workspace=False, **kw)
+        finally:
+            _lib.load().oeh_debug_set_variant(0, 0)
         assert got_ws.dtype == torch.float32
         _check(got_ws, want, tol=tol32, msg=f"workspace path case {n} ({var})")
         _check(got_gen, want, tol=tol32, msg=f"general kernel case {n}")
-        if Sk > 512:  # no MFMA kernel for fp32 rows this long without the workspace: the INT8 comparison below has no partner
+        if Sk > 512:  # the full-row and general kernels stop at 512 keys: the INT8 comparison below has no pair
             continue
         # INT8 chain: same bits from both kernels (same rounded operands, same per-element chain)
         fq = ops.AttnFakeQuant(FQ(0.05, 120.0), FQ(1.0 / 255.0, 0.0), FQ(0.01, 128.0), ctx_before_gate=bool(n & 1))
