@@ -130,10 +130,11 @@ typedef struct oeh_attn_desc {
   float gate_scaling;
   float* gate_out;
 
-  /* Optional scratch for fp32 storage (the reference's validate_* scripts run fp32 models): with at least
-   * oeh_attn_workspace_bytes(desc, fq) bytes of 16-byte aligned device memory here, q / k / v are rounded to fp16 in one
-   * streaming pre-pass and the 16-bit kernels run on the copies, writing fp32 output from the fp32 accumulators - the
-   * arithmetic of the general kernel (fp32 storage, fp16 matrix-core operands) at about half its time.  NULL or too
+  /* Optional scratch for fp32 storage (the reference's validate_* scripts run fp32 models).  Plain softmax / softmax_1
+   * problems are read in place by the one-pass kernel and need none.  For clipped softmax and the fake-quant chain, with at
+   * least oeh_attn_workspace_bytes(desc, fq) bytes of 16-byte aligned device memory here, q / k / v are rounded to fp16 in
+   * one streaming pre-pass and the full-row kernel runs on the copies, writing fp32 output from the fp32 accumulators - the
+   * arithmetic of the general kernel (fp32 storage, fp16 matrix-core operands) in about 2/3 of its time.  NULL or too
    * small: the general kernel.  The library never allocates; the scratch may be reused by the next call on the stream. */
   void* workspace;
   int64_t workspace_bytes;
