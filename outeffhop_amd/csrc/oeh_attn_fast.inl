@@ -292,13 +292,11 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
           const int t = kt * 4 + sub;
           const int key0 = 16 * t + 4 * g;
           f4 x = s[t];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) x[r] = x[r] * sc;
+          x = x * sc;
           {
             const f4 rel = fq_rel4(x, P.fq_s);
             if (dump_s && qvalid) dump4(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0, fq_dump_word(rel, P.fq_s), Sk - key0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] = P.fq_s.scale * rel[r];
+            x = rel * P.fq_s.scale;
           }
           if (has_pad) {
             const f4 padv = *reinterpret_cast<const f4*>(&lds_pad[key0]);
@@ -333,12 +331,13 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
           const int t = kt * 4 + sub;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float e = exp_acc_nonpos(s[t][r] - m);
-            s[t][r] = e;
-            sum += e;
-          }
+          const f2 m2 = f2{m, m};
+          const f2 e01 = exp_acc_nonpos2(f2{s[t][0], s[t][1]} - m2), e23 = exp_acc_nonpos2(f2{s[t][2], s[t][3]} - m2);
+          s[t] = f4{e01[0], e01[1], e23[0], e23[1]};
+          sum += e01[0];
+          sum += e01[1];
+          sum += e23[0];
+          sum += e23[1];
         }
       }
     }
@@ -356,8 +355,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
           const int t = kt * 4 + sub;
           const int key0 = 16 * t + 4 * g;
           f4 pv;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pv[r] = s[t][r] * inv_fq;
+          pv = s[t] * inv_fq;
           if constexpr (CLIP) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

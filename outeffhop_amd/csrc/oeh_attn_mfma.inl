@@ -243,12 +243,21 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     if (t < nt_wave) {
+      if constexpr (FQ) {
+        const f2 m2 = f2{m, m};
+        const f2 e01 = exp_acc_nonpos2(f2{s[t][0], s[t][1]} - m2), e23 = exp_acc_nonpos2(f2{s[t][2], s[t][3]} - m2);
+        s[t] = f4{e01[0], e01[1], e23[0], e23[1]};
+        sum += e01[0];
+        sum += e01[1];
+        sum += e23[0];
+        sum += e23[1];
+      } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float y = s[t][r] - m;
-        const float e = FQ ? exp_acc(y) : exp_fast(y);
-        s[t][r] = e;
-        sum += e;
+        for (int r = 0; r < 4; ++r) {
+          const float e = exp_fast(s[t][r] - m);
+          s[t][r] = e;
+          sum += e;
+        }
       }
     }
   }
