@@ -9,13 +9,13 @@ from outeffhop_amd import ops
 fmin = float(np.finfo(np.float32).min)
 N = int(sys.argv[1])
 tot = 0
-def case(name, B,H,S,D, kwf):
+def case(name, B,H,S,D, kwf, dt=torch.float16):
     global tot
     for seed in range(2):
         torch.manual_seed(seed)
-        q = (torch.randn(B,S,H*D, device="cuda")*0.3).half().view(B,S,H,D).permute(0,2,1,3)
-        k = torch.randn(B,S,H*D, device="cuda").half().view(B,S,H,D).permute(0,2,1,3)
-        v = torch.randn(B,S,H*D, device="cuda").half().view(B,S,H,D).permute(0,2,1,3)
+        q = (torch.randn(B,S,H*D, device="cuda")*0.3).to(dt).view(B,S,H,D).permute(0,2,1,3)
+        k = torch.randn(B,S,H*D, device="cuda").to(dt).view(B,S,H,D).permute(0,2,1,3)
+        v = torch.randn(B,S,H*D, device="cuda").to(dt).view(B,S,H,D).permute(0,2,1,3)
         pad = torch.zeros(B,S, device="cuda")
         for b in range(B): pad[b, int(S*(0.5+0.5*b/B)):] = fmin
         kw = kwf(pad)
@@ -28,10 +28,17 @@ def case(name, B,H,S,D, kwf):
                 with torch.cuda.stream(s2):
                     ops.attn_fwd(q2,q2,q2, causal=True, clamp_min=True, mask_min=fmin)
             if not torch.equal(ops.attn_fwd(q,k,v, mask_min=fmin, **kw), ref): bad += 1
-        print(f"{name:34s} seed {seed}: {bad} of {N} differ [{ops.attn_variant(B,H,S,S,D, clip=bool(kw.get('softmax') and kw['softmax'].clip))}]"); tot += bad
+        print(f"{name:34s} seed {seed}: {bad} of {N} differ [{ops.attn_variant(B,H,S,S,D, dt, clip=bool(kw.get('softmax') and kw['softmax'].clip), fq=kw.get('fq') is not None, workspace=True)}]"); tot += bad
 case("one-pass pad S=512", 16,12,512,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad))
 case("one-pass causal+pad S=512", 16,12,512,64, lambda pad: dict(causal=True, clamp_min=True, key_pad_mask=pad))
 case("full-row pad S=128 (BERT)", 32,12,128,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad))
 case("full-row clip+pad S=512", 16,12,512,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad, softmax=ops.SoftmaxSpec(1, True, -0.025, 1.1)))
 case("one-pass causal S=512", 16,12,512,64, lambda pad: dict(causal=True, clamp_min=True))
+FQ = ops.FakeQuantSpec
+int8 = ops.AttnFakeQuant(FQ(0.08, 128.0), FQ(1.0 / 255.0, 0.0), FQ(0.02, 128.0))
+case("fp32 one-pass causal S=512", 16,12,512,64, lambda pad: dict(causal=True, clamp_min=True), torch.float32)
+case("fp32 one-pass pad S=512", 16,12,512,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad), torch.float32)
+case("fp32 one-pass pad S=128", 32,12,128,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad), torch.float32)
+case("INT8 full-row causal S=512", 16,12,512,64, lambda pad: dict(causal=True, clamp_min=True, fq=int8))
+case("INT8 fp32 (pre-pass) causal S=512", 16,12,512,64, lambda pad: dict(causal=True, clamp_min=True, fq=int8), torch.float32)
 sys.exit(1 if tot else 0)
