@@ -37,7 +37,7 @@ WORKLOADS = {
                         desc="OPT-125m attention core B=16 H=12 S=512 d=64 fp16 causal clippedsoftmax1(-.025:1)"),
     "opt_int8": dict(B=16, H=12, S=512, d=64, order="opt", sm=(1, False, 0.0, 1.0), int8=True, gate=False,
                      desc="OPT-125m attention core B=16 H=12 S=512 d=64 fp16 causal softmax1 + 3 fused INT8 fake-quantisers"),
-    # fp32 storage, as the reference's validate_clm.py runs the model (fp16 matrix-core operands; include/oeh.h: workspace)
+    # fp32 storage, as the reference's validate_clm.py runs the model (read in place; fp16 matrix-core operands, fp32 output)
     "opt_softmax1_fp32": dict(B=16, H=12, S=512, d=64, order="opt", sm=(1, False, 0.0, 1.0), int8=False, gate=False, fp32=True,
                               desc="OPT-125m attention core B=16 H=12 S=512 d=64 fp32 storage causal softmax1"),
     "opt_int8_fp32": dict(B=16, H=12, S=512, d=64, order="opt", sm=(1, False, 0.0, 1.0), int8=True, gate=False, fp32=True,
@@ -239,18 +239,11 @@ def main():
             fqd = _lib.oeh_fq_desc()
             ops._fill_fq(fqd.scores, fq.scores), ops._fill_fq(fqd.probs, fq.probs), ops._fill_fq(fqd.ctx, fq.ctx)
             fqd.ctx_quant_before_gate = int(fq.ctx_before_gate)
-        if w.get("fp32"):  # one scratch for all layers: the launches are ordered on one stream
-            need = int(lib.oeh_attn_workspace_bytes(C.byref(dsc), None if fqd is None else C.byref(fqd)))
-            if need > 0:
-                if not workspace:
-                    workspace.append(torch.empty(need, dtype=torch.uint8, device=dev))
-                dsc.workspace, dsc.workspace_bytes = workspace[0].data_ptr(), need
         args = (C.byref(dsc), C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()),
                 C.c_void_p(o.data_ptr()), None if fqd is None else C.byref(fqd))
         return args, (dsc, fqd)
 
     gate_descs = []
-    workspace = []
     calls = [make_call(*s) for s in sets]
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     fwd = lib.oeh_attn_fwd
@@ -349,7 +342,7 @@ def main():
             "dtype": ("f32 storage, f16 matrix operands, f32 accumulate" if w.get("fp32") else "f16 storage, f32 accumulate") + (", 8-bit fake-quant grids" if w["int8"] else ""),
             "data": "synthetic",
             "config": {
-                "workload": w["desc"], "variant": ops.attn_variant(B, H, S, S, d, torch.float32 if w.get("fp32") else torch.float16, fq=w["int8"], clip=bool(w["sm"][1]), workspace=bool(w.get("fp32"))),
+                "workload": w["desc"], "variant": ops.attn_variant(B, H, S, S, d, torch.float32 if w.get("fp32") else torch.float16, fq=w["int8"], clip=bool(w["sm"][1])),
                 "batch_per_gpu": B, "seq_len": S, "heads": H, "head_dim": d, "layers_per_step": L,
                 "launches_per_step": L, "model_tokens_per_s": world * B * S * a.steps / wall,
                 "parallelism": f"batch-shard x{world}, no collective in the timed region",

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OEH_ABI_VERSION 3
+#define OEH_ABI_VERSION 2
 
 /* error codes (negative errno style) */
 #define OEH_OK 0
@@ -129,15 +129,6 @@ typedef struct oeh_attn_desc {
   int32_t gate_units;
   float gate_scaling;
   float* gate_out;
-
-  /* Optional scratch for fp32 storage (the reference's validate_* scripts run fp32 models).  Plain softmax / softmax_1
-   * problems are read in place by the one-pass kernel and need none.  For clipped softmax and the fake-quant chain, with at
-   * least oeh_attn_workspace_bytes(desc, fq) bytes of 16-byte aligned device memory here, q / k / v are rounded to fp16 in
-   * one streaming pre-pass and the full-row kernel runs on the copies, writing fp32 output from the fp32 accumulators - the
-   * arithmetic of the general kernel (fp32 storage, fp16 matrix-core operands) in about 2/3 of its time.  NULL or too
-   * small: the general kernel.  The library never allocates; the scratch may be reused by the next call on the stream. */
-  void* workspace;
-  int64_t workspace_bytes;
 } oeh_attn_desc;
 
 /* QK^T -> scale -> [fq] -> mask -> softmax / softmax_1 -> [clip] -> [fq] -> PV -> [fq] -> gate -> [fq]
@@ -182,10 +173,6 @@ const char* oeh_strerror(int code);
  * "fast16/NT32/D64/f16/clip" full-row kernel, "mfma16/NT32/D64/f16/fq" general kernel, "generic") or NULL if
  * unsupported; host only.  The returned string lives in thread-local storage until the next call on this thread. */
 const char* oeh_attn_variant(const oeh_attn_desc* desc, const oeh_fq_desc* fq);
-
-/* bytes of desc->workspace that let an fp32-storage problem run the 16-bit kernels (0: no use for a workspace) */
-int64_t oeh_attn_workspace_bytes(const oeh_attn_desc* desc, const oeh_fq_desc* fq);
-
 #ifdef __cplusplus
 }
 #endif

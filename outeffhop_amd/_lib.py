@@ -48,14 +48,13 @@ class oeh_attn_desc(C.Structure):
         ("gate_hidden", C.c_void_p), ("gate_hidden_stride", C.c_int64 * 2),
         ("gate_w1", C.c_void_p), ("gate_b1", C.c_void_p), ("gate_w2", C.c_void_p), ("gate_b2", C.c_void_p),
         ("gate_units", C.c_int32), ("gate_scaling", C.c_float), ("gate_out", C.c_void_p),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
 # every symbol include/oeh.h declares (tests/test_abi.py checks the .so exports exactly these)
 EXPORTS = (
     "oeh_attn_fwd", "oeh_softmax_rows", "oeh_fake_quant", "oeh_gate_fwd", "oeh_minmax",
-    "oeh_abi_version", "oeh_build_info", "oeh_strerror", "oeh_attn_variant", "oeh_attn_workspace_bytes",
+    "oeh_abi_version", "oeh_build_info", "oeh_strerror", "oeh_attn_variant",
 )
 
 _lib = None
@@ -94,10 +93,8 @@ def load() -> C.CDLL:
     lib.oeh_strerror.restype = C.c_char_p
     lib.oeh_attn_variant.argtypes = [C.POINTER(oeh_attn_desc), C.POINTER(oeh_fq_desc)]
     lib.oeh_attn_variant.restype = C.c_char_p
-    lib.oeh_attn_workspace_bytes.argtypes = [C.POINTER(oeh_attn_desc), C.POINTER(oeh_fq_desc)]
-    lib.oeh_attn_workspace_bytes.restype = C.c_int64
-    if lib.oeh_abi_version() != 3:
-        raise OehError(f"liboeh_hip.so ABI {lib.oeh_abi_version()} != 3 (stale build?)")
+    if lib.oeh_abi_version() != 2:
+        raise OehError(f"liboeh_hip.so ABI {lib.oeh_abi_version()} != 2 (stale build?)")
     _lib = lib
     return lib
 

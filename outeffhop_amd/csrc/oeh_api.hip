@@ -21,8 +21,6 @@ int launch_attn_flash_d128(const AttnParams& P, int in, int mq, hipStream_t st);
 int launch_attn_generic(const AttnParams& P, int in, hipStream_t st);
 int launch_softmax_rows(const void* x, void* y, long rows, int cols, int in, int base, int clip, float w, float g, hipStream_t st);
 int launch_fake_quant(const void* x, void* y, unsigned char* idx, long n, int in, FqP f, hipStream_t st);
-int launch_cvt_qkv(const void* q, const void* k, const void* v, const long* qs, const long* ks, const long* vs, int B, int H, int Sq, int Sk, int D,
-                   void* dst, hipStream_t st);
 int launch_gate(const void* hidden, int in, int B, int T, int H, int d, long hs_b, long hs_t, const float* w1, const float* b1,
                 const float* w2, const float* b2, int m_units, int pool, float scaling, float* out, hipStream_t st);
 int launch_minmax(const void* x, long n, int in, float* out2, hipStream_t st);
@@ -128,6 +126,13 @@ bool flash32_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
   t.dtype = OEH_F16;
   return flash_eligible(&t, fq, true);  // short rows as well: BERT-base S=128 15.4 us against 16.7 us in the general kernel
 }
+// ... and on the full-row kernel (clipped softmax, the INT8 chain, vanilla softmax with key padding)
+bool fast32_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
+  if (d->dtype != OEH_F32 || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
+  oeh_attn_desc t = *d;
+  t.dtype = OEH_F16;
+  return fast_eligible(&t, fq);
+}
 
 unsigned long long* g_stamps = nullptr;  // tools/timeline.py only
 int g_variant_off = 0;                   // tools/microbench.py only: bit (1 << Variant) disables a variant
@@ -153,6 +158,7 @@ Variant pick_variant(const oeh_attn_desc* d, const void* q, const void* k, const
   if (d_ok && al && flash_eligible(d, fq) && !(g_variant_off & (1 << V_FLASH))) return V_FLASH;
   if (d_ok && al && flash32_eligible(d, fq) && !(g_variant_off & ((1 << V_FLASH) | (1 << 6)))) return V_FLASH;
   if (shape_ok && p_exact && al && fast_eligible(d, fq) && !(g_variant_off & (1 << V_FAST))) return V_FAST;
+  if (shape_ok && p_exact && al && fast32_eligible(d, fq) && !(g_variant_off & ((1 << V_FAST) | (1 << 7)))) return V_FAST;
   if (shape_ok && p_exact && al) return V_MFMA;
   if ((size_t)(d->D + d->Sk) * 4 <= 64 * 1024) return V_GENERIC;
   return V_NONE;
@@ -200,28 +206,6 @@ void fill_params(AttnParams& P, const oeh_attn_desc* d, const void* q, const voi
                std::isfinite(d->mask_min) && d->mask_min < -1e4f) ? 1 : 0;
 }
 
-// fp32 storage on the 16-bit kernels (include/oeh.h: workspace): the descriptor of the same problem on contiguous
-// (B,H,S,D) fp16 copies of q, k, v.  Returns the bytes the copies need, 0 when this problem has no use for them.
-int64_t workspace_plan(const oeh_attn_desc* d, const oeh_fq_desc* fq, oeh_attn_desc* d16) {
-  if (d->dtype != OEH_F32 || !(d->D == 32 || d->D == 64 || d->D == 128)) return 0;
-  if (d->gate == nullptr && d->gate_hidden != nullptr) return 0;  // the in-kernel predictor reads a 16-bit layer input
-  // Rows up to 256 keys are faster in the general kernel than pre-pass + 16-bit kernel (OPT shape at S=256: 21.4 vs 23.9 us,
-  // BERT-base S=128: 16.6 vs 24.3 us; S=512: 77 vs 42 us - its NT=32 form runs at two waves per SIMD)
-  if (d->Sk <= 256) return 0;
-  if ((g_variant_off & (1 << 5)) != 0) return 0;                  // tools/microbench.py: workspace path off
-  oeh_attn_desc t = *d;
-  t.dtype = OEH_F16;
-  const int64_t D = d->D, H = d->H;
-  t.q_stride[0] = H * d->Sq * D; t.q_stride[1] = (int64_t)d->Sq * D; t.q_stride[2] = D;
-  t.k_stride[0] = H * d->Sk * D; t.k_stride[1] = (int64_t)d->Sk * D; t.k_stride[2] = D;
-  t.v_stride[0] = t.k_stride[0]; t.v_stride[1] = t.k_stride[1]; t.v_stride[2] = D;
-  if (pick_variant(d, nullptr, nullptr, nullptr, nullptr, fq) == V_FLASH) return 0;  // read directly by the one-pass kernel
-  const Variant v = pick_variant(&t, nullptr, nullptr, nullptr, nullptr, fq);
-  if (v != V_FAST) return 0;
-  if (d16 != nullptr) *d16 = t;
-  return 2 * (int64_t)d->B * H * D * ((int64_t)d->Sq + 2 * (int64_t)d->Sk);
-}
-
 const char* variant_name(Variant v, const oeh_attn_desc* d, bool fq) {
   static thread_local char buf[64];
   if (v == V_GENERIC) return "generic";
@@ -242,36 +226,15 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
                  void* stream) {
   int rc = validate(desc, q, k, v, o, fq);
   if (rc != OEH_OK) return rc;
-  // fp32 storage with a workspace: round q, k, v to fp16 copies in one pre-pass, run the 16-bit kernel on them, fp32 output
-  oeh_attn_desc d16;
-  bool out32 = false;
-  if (desc->dtype == OEH_F32 && desc->workspace != nullptr) {
-    const int64_t need = workspace_plan(desc, fq, &d16);
-    const bool al = aligned16(q, desc->q_stride, 4) && aligned16(k, desc->k_stride, 4) && aligned16(v, desc->v_stride, 4) &&
-                    aligned16(o, desc->o_stride, 2) && (reinterpret_cast<uintptr_t>(desc->workspace) & 15) == 0;
-    if (need > 0 && desc->workspace_bytes >= need && al) {
-      const long qs[3] = {(long)desc->q_stride[0], (long)desc->q_stride[1], (long)desc->q_stride[2]};
-      const long ks[3] = {(long)desc->k_stride[0], (long)desc->k_stride[1], (long)desc->k_stride[2]};
-      const long vs[3] = {(long)desc->v_stride[0], (long)desc->v_stride[1], (long)desc->v_stride[2]};
-      rc = oeh::launch_cvt_qkv(q, k, v, qs, ks, vs, desc->B, desc->H, desc->Sq, desc->Sk, desc->D, desc->workspace, reinterpret_cast<hipStream_t>(stream));
-      if (rc != OEH_OK) return rc;
-      unsigned short* w = reinterpret_cast<unsigned short*>(desc->workspace);
-      q = w;
-      k = w + (int64_t)desc->B * desc->H * desc->Sq * desc->D;
-      v = w + (int64_t)desc->B * desc->H * ((int64_t)desc->Sq + desc->Sk) * desc->D;
-      desc = &d16;
-      out32 = true;
-    }
-  }
   const Variant var = pick_variant(desc, q, k, v, o, fq);
-  if (var == V_NONE || (out32 && var != V_FAST)) return OEH_ENOTSUP;
+  if (var == V_NONE) return OEH_ENOTSUP;
   if (desc->gate == nullptr && desc->gate_hidden != nullptr) {  // fused gate predictor: 16-bit MFMA variants, 16-B aligned rows
     if ((var != V_FAST && var != V_FLASH) || desc->gate_units > 16 || desc->dtype == OEH_F32) return OEH_ENOTSUP;  // one 16-unit MFMA tile of hidden units
     if (((reinterpret_cast<uintptr_t>(desc->gate_hidden) | (uintptr_t)(desc->gate_hidden_stride[0] * 2) | (uintptr_t)(desc->gate_hidden_stride[1] * 2)) & 15) != 0) return OEH_EALIGN;
   }
   AttnParams P;
   fill_params(P, desc, q, k, v, o, fq);
-  P.out32 = (out32 || (var == V_FLASH && desc->dtype == OEH_F32)) ? 1 : 0;
+  P.src32 = (desc->dtype == OEH_F32 && (var == V_FLASH || var == V_FAST)) ? 1 : 0;  // fp32 storage read directly, fp32 output
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (var == V_FLASH) {
     if (desc->scale_div != 0.0f) { P.scale = 1.0f / desc->scale_div; P.scale_div = 0.0f; }  // exact: power of two
@@ -304,18 +267,7 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
 const char* oeh_attn_variant(const oeh_attn_desc* desc, const oeh_fq_desc* fq) {
   if (desc == nullptr || desc->B <= 0 || desc->H <= 0 || desc->Sq <= 0 || desc->Sk <= 0 || desc->D <= 0 || !dtype_ok(desc->dtype))
     return nullptr;
-  oeh_attn_desc d16;
-  if (desc->workspace != nullptr && workspace_plan(desc, fq, &d16) > 0 && desc->workspace_bytes >= workspace_plan(desc, fq, nullptr)) {
-    static thread_local char buf[80];
-    std::snprintf(buf, sizeof(buf), "%s<f32", variant_name(pick_variant(&d16, nullptr, nullptr, nullptr, nullptr, fq), &d16, any_fq(fq)));
-    return buf;
-  }
   return variant_name(pick_variant(desc, nullptr, nullptr, nullptr, nullptr, fq), desc, any_fq(fq));
-}
-
-int64_t oeh_attn_workspace_bytes(const oeh_attn_desc* desc, const oeh_fq_desc* fq) {
-  if (desc == nullptr || desc->B <= 0 || desc->H <= 0 || desc->Sq <= 0 || desc->Sk <= 0 || desc->D <= 0 || !dtype_ok(desc->dtype)) return 0;
-  return workspace_plan(desc, fq, nullptr);
 }
 
 int oeh_softmax_rows(const void* x, void* y, int64_t rows, int32_t cols, int32_t dtype, int32_t softmax_base, int32_t clip,

@@ -53,8 +53,14 @@ constexpr int fast_occupancy() { return D >= 128 ? 1 : 3; }  // what the LDS rin
 // the general kernel (oeh_attn_mfma.inl), on this kernel's data path.  The variant is compiled for the reference's
 // configuration, scores AND probabilities quantised (context optional): a run-time test per quantiser and per four elements
 // costs a branch and, at the join, register copies (1.5 VALU per element for the clip alone).  Other subsets: general kernel.
-template <int NT, int D, int IN, bool CLIP, bool GATE, bool FQ = false, bool OUT32 = false>
-__global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_kernel(const AttnParams P) {
+// SRC32: fp32 storage read directly, as in the one-pass kernel (oeh_attn_flash.inl): the K-then-V tile stream comes
+// through registers (32 B of fp32 per lane and piece, rounded to fp16, written to the LDS image the DMA would produce), one
+// tile ahead - committed at the top of an iteration, the next tile's loads issued right after the barrier.  The staged tile
+// is live through the softmax phase, so these variants are compiled for two waves per SIMD.
+template <int NT, int D, int IN, bool CLIP, bool GATE, bool FQ = false, bool SRC32 = false>
+__global__ __launch_bounds__(256, (SRC32 ? (D >= 128 ? 1 : 2) : fast_occupancy<NT, D>())) void oeh_attn_fast_kernel(const AttnParams P) {
+  static_assert(!SRC32 || (!GATE && IN == IN_F16), "fp32 storage: fp16 operands, fp32 output, no in-kernel gate predictor");
+  constexpr bool OUT32 = SRC32;
   static_assert(!FQ || !GATE, "the fake-quant variant has no in-kernel gate predictor");
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
   constexpr int KT = NT / 4;
@@ -148,7 +154,48 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
   // ---- Q rides the LDS-DMA stream, first, as a K-shaped tile in the V ring's last slot (first used by V tile R-1, long
   // after the operands below are in registers): the bytes in front of the first MFMA are Q + K tile 0, requested together,
   // instead of a register load of Q that had to land before the first transfer could even be issued.
-  {
+  f4 treg[SRC32 ? G : 1][2];  // SRC32: the staged tile
+  auto cvt8 = [](const f4 lo, const f4 hi) { return u4{pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]), pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3])}; };
+  auto load_tile = [&](const int i) {  // tile i of the K-then-V stream -> registers
+    if constexpr (SRC32) {
+      const bool isv = i >= n_kt;
+      const int t = isv ? i - n_kt : i;
+      const float* src = isv ? reinterpret_cast<const float*>(P.v) + (long)b * P.vs_b + (long)h * P.vs_h
+                             : reinterpret_cast<const float*>(P.k) + (long)b * P.ks_b + (long)h * P.ks_h;
+      const long srow = isv ? P.vs_s : P.ks_s;
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int row = piece_row(j);
+        const int kr = min(t * 64 + row, P.Sk - 1);  // rows past Sk: finite data, masked later
+        const int ch = isv ? ((((pch >> 1) ^ swz_v<D>(row)) << 1) | (pch & 1)) : (pch ^ swz_k<D>(row));
+        const float* p = src + (long)kr * srow + ch * 8;
+        treg[j][0] = *reinterpret_cast<const f4*>(p);
+        treg[j][1] = *reinterpret_cast<const f4*>(p + 4);
+      }
+    }
+  };
+  auto commit_tile = [&](const int ring_slot) {  // registers -> ring slot (0..R-1 K ring, R..2R-1 V ring)
+    if constexpr (SRC32) {
+      unsigned char* base = lds + ring_slot * TILEB + (wave * G) * 1024 + lane * 16;
+#pragma unroll
+      for (int j = 0; j < G; ++j) *reinterpret_cast<u4*>(base + j * 1024) = cvt8(treg[j][0], treg[j][1]);
+    }
+  };
+  if constexpr (SRC32) {  // Q: the LDS image the DMA would write (a K-shaped tile in V ring slot R-1)
+    const float* qsrc = reinterpret_cast<const float*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h;
+    unsigned char* qdst = lds + (2 * R - 1) * TILEB + (wave * G) * 1024 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int row = piece_row(j);
+      int qr = qt * 64 + row;
+      qr = qr < P.Sq ? qr : P.Sq - 1;
+      const float* qp = qsrc + (long)qr * P.qs_s + (pch ^ swz_k<D>(row)) * 8;
+      const f4 lo = __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp));
+      const f4 hi = __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp + 4));
+      *reinterpret_cast<u4*>(qdst + j * 1024) = cvt8(lo, hi);
+    }
+    load_tile(0);
+  } else {
     const unsigned short* qbase = reinterpret_cast<const unsigned short*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h;
     const unsigned qslot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((2 * R - 1) * TILEB + wave * G * 1024));
 #pragma unroll
@@ -177,8 +224,10 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
     }
   }
   // stream prologue: two tiles in flight
-  issue_next();
-  if (1 < T) issue_next();
+  if constexpr (!SRC32) {
+    issue_next();
+    if (1 < T) issue_next();
+  }
   if constexpr (GATE) {
     const int mm = P.g_units > 0 ? P.g_units : 1;  // <= 16 (host)
     const bool uv = c < mm;
@@ -202,7 +251,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
   if (has_pad) {  // (compiler-visible loads: its wait for them also covers the transfers above, which the next wait needs anyway)
     for (int i = tid; i < NT * 16; i += 256) lds_pad[i] = (i < P.Sk) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + i) : 0.0f;
   }
-  wait_tiles_in_flight<G>(min(2, T));  // Q landed; the one or two tiles behind it may still be in flight
+  if constexpr (!SRC32) wait_tiles_in_flight<G>(min(2, T));  // Q landed; the one or two tiles behind it may still be in flight
   barrier_mem();
   OEH_STAMP(1);
   const unsigned char* kaddr[KS];
@@ -254,10 +303,16 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
   for (int kt = 0; kt < KT; ++kt) {
     if (kt < n_kt) {
       const int i = kt;
+      if constexpr (SRC32) {
+        commit_tile(kt % R);                       // tile i (loaded an iteration ago) -> its K ring slot; last reader: tile i-3
+        barrier_mem();
+        if (i + 1 < T) load_tile(i + 1);           // lands while tile i is computed
+      } else {
       wait_tiles_in_flight<G>(min(1, T - 1 - i));  // tile i landed; tile i+1 may still be in flight
       barrier_mem();
       OEH_STAMP(2 + kt);
       if (i + 2 < T) issue_next();                 // stream tile i+2, into the slot every wave finished reading one iteration ago
+      }
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
         f4 acc = f4{0.f, 0.f, 0.f, 0.f};
@@ -500,10 +555,16 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
   for (int kt = 0; kt < KT; ++kt) {
     if (kt < n_kt) {
       const int i = n_kt + kt;
+      if constexpr (SRC32) {
+        commit_tile(R + kt % R);
+        barrier_mem();
+        if (i + 1 < T) load_tile(i + 1);
+      } else {
       wait_tiles_in_flight<G>(min(1, T - 1 - i));
       barrier_mem();
       OEH_STAMP(13 + kt);
       if (i + 2 < T) issue_next();
+      }
       constexpr int slot_off_base = R * TILEB;
       const int slot_off = slot_off_base + (kt % R) * TILEB;
 #pragma unroll
@@ -565,7 +626,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
 #pragma unroll
       for (int r = 0; r < 4; ++r) ov[r] = o[dt][r] * rowscale;
     }
-    if constexpr (OUT32) {  // fp32 output straight from the accumulators (workspace path)
+    if constexpr (OUT32) {  // fp32 output straight from the accumulators (fp32 storage)
       if (q0 + ce < P.Sq)
         store_wt16(reinterpret_cast<float*>(P.o) + (long)b * P.os_b + (long)h * P.os_h + (long)(q0 + ce) * P.os_s + 16 * dt + 4 * ge,
                    u4{f32_bits(ov[0]), f32_bits(ov[1]), f32_bits(ov[2]), f32_bits(ov[3])});
@@ -603,8 +664,8 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
 template <int NT, int D, int IN>
 static void launch_fast_nt_d_in(const AttnParams& P, unsigned grid, hipStream_t st) {
   const bool gate = P.gh != nullptr;
-  if (P.out32) {  // fp16 workspace copies of fp32 tensors, fp32 output: rows of more than 256 keys only (oeh_api.hip: workspace_plan)
-    if constexpr (NT == 32 && IN == IN_F16) {
+  if (P.src32) {  // fp32 storage read directly, fp32 output
+    if constexpr (IN == IN_F16) {
       const bool fqon = P.fq_s.en && P.fq_p.en;
       if (fqon && P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, true, true>), dim3(grid), dim3(256), 0, st, P);
       else if (fqon) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, true, true>), dim3(grid), dim3(256), 0, st, P);

@@ -49,10 +49,11 @@ constexpr int flash_occupancy() { return D >= 128 ? 1 : 3; }
 // of tile i+1, so they have a tile of compute to land; one barrier per tile as before.  fp16 matrix-core operands, fp32
 // accumulation and fp32 output straight from the accumulators (OUT32): the general kernel's arithmetic on fp32 storage,
 // without its full-row structure and without a conversion pre-pass (which costs more HBM time than the attention itself).
-template <int D, int IN, int MQ, bool PAD, bool GATE, bool OUT32 = false, bool SRC32 = false>
+template <int D, int IN, int MQ, bool PAD, bool GATE, bool SRC32 = false>
 __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flash_kernel(const AttnParams P) {
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit matrix-core operands");
-  static_assert(!SRC32 || (OUT32 && !GATE && IN == IN_F16), "fp32 storage: fp16 operands, fp32 output, no in-kernel gate predictor");
+  static_assert(!SRC32 || (!GATE && IN == IN_F16), "fp32 storage: fp16 operands, fp32 output, no in-kernel gate predictor");
+  constexpr bool OUT32 = SRC32;
   static_assert(MQ == 1 || MQ == 2, "one or two query blocks per wave");
   constexpr int ROWB = 2 * D;
   constexpr int TILEB = 64 * ROWB;      // one operand tile (64 keys)
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
     float rowscale = 1.0f / den;
     if (P.gate != nullptr && qrow < Sq) rowscale = rowscale * P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
     if constexpr (GATE) rowscale = rowscale * gate_row[j];
-    if constexpr (OUT32) {  // fp32 output straight from the accumulators (workspace path): 16 B per lane, 64 B per row and instruction
+    if constexpr (OUT32) {  // fp32 output straight from the accumulators (fp32 storage): 16 B per lane, 64 B per row and instruction
       if (qrow < Sq) {
         float* orow = reinterpret_cast<float*>(P.o) + (long)b * P.os_b + (long)h * P.os_h + (long)qrow * P.os_s + 4 * ge;
 #pragma unroll
@@ -613,10 +614,10 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
 template <int D, int MQ, int IN>
 static void launch_flash_d_mq_in(const AttnParams& P, unsigned grid, hipStream_t st) {
   const bool pad = P.pad != nullptr, gate = P.gh != nullptr;
-  if (P.out32) {  // fp32 storage read directly (SRC32), fp32 output; no in-kernel gate predictor on this path
+  if (P.src32) {  // fp32 storage read directly, fp32 output; no in-kernel gate predictor on this path
     if constexpr (IN == IN_F16) {
-      if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, true, true>), dim3(grid), dim3(256), 0, st, P);
-      else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true, true>), dim3(grid), dim3(256), 0, st, P);
+      if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, true>), dim3(grid), dim3(256), 0, st, P);
+      else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true>), dim3(grid), dim3(256), 0, st, P);
     }
     return;
   }

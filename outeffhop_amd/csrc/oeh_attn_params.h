@@ -37,7 +37,7 @@ struct AttnParams {
   float* g_out;
   FqP fq_s, fq_p, fq_c;
   int ctx_before_gate;
-  int out32;                  // 16-bit kernels on the fp16 workspace copies of fp32 tensors: o is fp32 (include/oeh.h: workspace)
+  int src32;                  // fp32 q / k / v read directly by the kernel and fp32 output (SRC32 variants)
   // launch geometry
   int nQT;                    // q tiles (64 rows) per (b,h)
   int nBH, nBHpad;            // B*H and B*H rounded up to a multiple of 8 (XCD affinity of a head's q tiles)

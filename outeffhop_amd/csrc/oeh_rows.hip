@@ -292,50 +292,6 @@ int launch_gate(const void* hidden, int in, int B, int T, int H, int d, long hs_
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-// ---- fp32 q / k / v (strided (B,H,S,D) views) -> contiguous fp16 (B,H,S,D) copies, one launch (include/oeh.h: workspace).
-// One 8-element chunk per thread: two 16-B non-temporal loads (the fp32 tensors are read once), one 16-B store (the
-// copies are read by the attention kernel next and should stay in L2 / MALL).  HBM-bound: 6 B per element.
-struct CvtQkv {
-  const float* src[3];
-  long sb[3], sh[3], ss[3];
-  long rows_end[3];   // cumulative row counts: B*H*Sq, + B*H*Sk, + B*H*Sk
-  int S[3];
-  int H, cpr_shift;   // log2(D / 8)
-  unsigned short* dst; // q rows, then k rows, then v rows, D halves each
-};
-__global__ __launch_bounds__(256) void oeh_cvt_qkv_kernel(const CvtQkv a) {
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  const long row = gid >> a.cpr_shift;
-  if (row >= a.rows_end[2]) return;
-  const int ch = (int)(gid & ((1 << a.cpr_shift) - 1));
-  const int t = row < a.rows_end[0] ? 0 : (row < a.rows_end[1] ? 1 : 2);
-  const long r = row - (t == 0 ? 0 : a.rows_end[t - 1]);
-  const long bh = r / a.S[t];
-  const int sidx = (int)(r - bh * a.S[t]);
-  const long bidx = bh / a.H;
-  const int hidx = (int)(bh - bidx * a.H);
-  const float* p = a.src[t] + bidx * a.sb[t] + hidx * a.sh[t] + (long)sidx * a.ss[t] + ch * 8;
-  const f4 lo = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
-  const f4 hi = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p) + 1);
-  const u4 w = u4{pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]), pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3])};
-  *reinterpret_cast<u4*>(a.dst + gid * 8) = w;
-}
-int launch_cvt_qkv(const void* q, const void* k, const void* v, const long* qs, const long* ks, const long* vs, int B, int H, int Sq, int Sk, int D,
-                   void* dst, hipStream_t st) {
-  CvtQkv a;
-  a.src[0] = (const float*)q; a.src[1] = (const float*)k; a.src[2] = (const float*)v;
-  const long* strides[3] = {qs, ks, vs};
-  for (int t = 0; t < 3; ++t) { a.sb[t] = strides[t][0]; a.sh[t] = strides[t][1]; a.ss[t] = strides[t][2]; }
-  a.S[0] = Sq; a.S[1] = Sk; a.S[2] = Sk;
-  a.rows_end[0] = (long)B * H * Sq; a.rows_end[1] = a.rows_end[0] + (long)B * H * Sk; a.rows_end[2] = a.rows_end[1] + (long)B * H * Sk;
-  a.H = H;
-  a.cpr_shift = D == 32 ? 2 : (D == 64 ? 3 : 4);
-  a.dst = (unsigned short*)dst;
-  const long chunks = a.rows_end[2] << a.cpr_shift;
-  hipLaunchKernelGGL(oeh_cvt_qkv_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, a);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
-}
-
 
 // ---------------------------------------------------------------------------------------------------------
 // min / max: order-preserving int keys + atomics, decoded in place by a 1-thread kernel.

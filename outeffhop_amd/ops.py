@@ -102,7 +102,6 @@ def attn_fwd(
     fq: Optional[AttnFakeQuant] = None,
     out: Optional[torch.Tensor] = None,
     gate_mlp: Optional["GatePredictor"] = None,
-    workspace=None,
     _prepared: Optional[list] = None,
 ) -> torch.Tensor:
     """Fused attention core.  q,k,v are logical (B,H,S,D) views (any batch/head/seq strides, unit head-dim
@@ -110,9 +109,7 @@ def attn_fwd(
     reference's head merge (bert_attention.py:335-337) is a free `.permute(0,2,1,3).reshape(B,Sq,H*D)`.
 
     key_pad_mask: additive (B,Sk) [or anything reshapeable to it, e.g. HF's (B,1,1,Sk)];
-    full_mask: additive (B,1,Sq,Sk); gate: fp32, broadcastable to (B,H,Sq,1), already times the scaling factor.
-    workspace (fp32 storage only): None = allocate the scratch the 16-bit kernels need, a uint8 tensor = use it,
-    False = none (general kernel)."""
+    full_mask: additive (B,1,Sq,Sk); gate: fp32, broadcastable to (B,H,Sq,1), already times the scaling factor."""
     _need_gpu(q, k, v, key_pad_mask, full_mask, gate, out)
     if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
         raise ValueError("q, k, v must be 4-D (B,H,S,D) views")
@@ -192,14 +189,6 @@ def attn_fwd(
         _fill_fq(fqd.ctx, fq.ctx)
         fqd.ctx_quant_before_gate = int(bool(fq.ctx_before_gate))
     lib = _lib.load()
-    if q.dtype == torch.float32 and workspace is not False:
-        # fp32 storage: scratch for fp16 copies of q/k/v lets the 16-bit kernels run (include/oeh.h: workspace)
-        need = int(lib.oeh_attn_workspace_bytes(C.byref(d), None if fqd is None else C.byref(fqd)))
-        if need > 0:
-            ws = workspace if isinstance(workspace, torch.Tensor) else torch.empty(need, dtype=torch.uint8, device=q.device)
-            if ws.numel() * ws.element_size() >= need and ws.is_contiguous():
-                keep.append(ws)
-                d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     if _prepared is not None:  # hand back the prebuilt C call instead of launching (bench / hipGraph loops)
         args = (C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), None if fqd is None else C.byref(fqd))
         _prepared.extend([lib.oeh_attn_fwd, args, (d, fqd, keep, q, k, v, out)])
@@ -246,13 +235,10 @@ class PreparedAttn:
             _lib.check(rc, "oeh_attn_fwd")
 
 
-def attn_variant(B, H, Sq, Sk, D, dtype=torch.float16, fq: bool = False, clip: bool = False, workspace: bool = False) -> Optional[str]:
-    """Name of the kernel variant the library would pick (host only; no GPU needed).  workspace: fp32 storage with the
-    scratch for fp16 copies supplied (what `attn_fwd` does by default)."""
+def attn_variant(B, H, Sq, Sk, D, dtype=torch.float16, fq: bool = False, clip: bool = False) -> Optional[str]:
+    """Name of the kernel variant the library would pick (host only; no GPU needed)."""
     d = oeh_attn_desc()
     d.B, d.H, d.Sq, d.Sk, d.D, d.dtype = B, H, Sq, Sk, D, _DT[dtype]
-    if workspace:
-        d.workspace, d.workspace_bytes = 16, 1 << 62  # never dereferenced by oeh_attn_variant
     d.scale, d.mask_min = 1.0, float(torch.finfo(torch.float32).min)
     if clip:
         d.clip, d.gamma, d.eta = 1, -0.025, 1.0

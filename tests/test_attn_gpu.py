@@ -566,18 +566,18 @@ def test_fq_kernels_agree_bitwise_on_ragged_shapes(ops):
                 assert torch.equal(da, db), what + f": index dump {i_} differs"
 
 
-def test_fp32_storage_runs_the_16bit_kernels_on_a_workspace(ops):
-    """fp32 q/k/v (the reference's validate_* scripts): plain softmax(_1) is read directly by the one-pass kernel (tiles
-    staged through registers); clipped softmax and the INT8 chain run the full-row kernel on fp16 copies in the scratch
-    `attn_fwd` allocates; `workspace=False` + the diagnostic switch give the general kernel (same arithmetic: fp32 storage,
-    fp16 matrix-core operands).  All against the oracle; the INT8 chain must agree bit for bit."""
+def test_fp32_storage_is_read_in_place_by_the_16bit_operand_kernels(ops):
+    """fp32 q/k/v (the reference's validate_* scripts): the one-pass kernel (plain softmax / softmax_1) and the full-row kernel
+    (clipped softmax, INT8 chain) stage fp32 tiles through registers; the diagnostic switch gives the general kernel (same
+    arithmetic: fp32 storage, fp16 matrix-core operands).  All against the oracle; the INT8 chain must agree bit for bit."""
     from outeffhop_amd import _lib
+
     fmin = float(np.finfo(np.float32).min)
     FQ = ops.FakeQuantSpec
     tol32 = dict(atol=2e-3, rtol=2e-3)  # fp32 data, fp16 matrix-core operands: the general kernel's accuracy on fp32 storage
     for n, (B, H, Sq, Sk, D, causal, sm) in enumerate([(2, 3, 300, 300, 64, True, "softmax1"), (1, 2, 77, 290, 32, False, "vanilla"),
                                                         (2, 2, 400, 400, 128, True, "clippedsoftmax1(-.025:1)"), (1, 4, 512, 512, 64, True, "softmax1"),
-                                                        (1, 2, 700, 700, 64, True, "softmax1")]):
+                                                        (3, 2, 100, 100, 64, False, "clippedsoftmax1(-.025:1)"), (1, 2, 700, 700, 64, True, "softmax1")]):
         q = _rand((B, Sq, H * D), 7000 + n, dtype=torch.float32).view(B, Sq, H, D).permute(0, 2, 1, 3)
         k = _rand((B, Sk, H * D), 7100 + n, dtype=torch.float32).view(B, Sk, H, D).permute(0, 2, 1, 3)
         v = _rand((B, Sk, H * D), 7200 + n, dtype=torch.float32).view(B, Sk, H, D).permute(0, 2, 1, 3)
@@ -589,21 +589,25 @@ def test_fp32_storage_runs_the_16bit_kernels_on_a_workspace(ops):
         kw = dict(softmax=_spec(ops, sm), scale=D ** -0.5, causal=causal, clamp_min=causal, key_pad_mask=pad, mask_min=fmin)
         want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=D ** -0.5, causal=causal, clamp_min=causal,
                            pad_mask=None if pad is None else pad.cpu().numpy(), **SPECS[sm])
-        var = ops.attn_variant(B, H, Sq, Sk, D, torch.float32, clip="clipped" in sm, workspace=True)
-        assert (var.startswith("flash16/") and var.endswith("/f32")) or (var.startswith("fast16/") and var.endswith("<f32")), var
-        got_ws = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), **kw)
-        _lib.load().oeh_debug_set_variant(1 << 6, 0)  # fp32 one-pass variants off
+        var = ops.attn_variant(B, H, Sq, Sk, D, torch.float32, clip="clipped" in sm)
+        assert (var.startswith("flash16/") or var.startswith("fast16/")) and "/f32" in var, var
+        got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), **kw)
+        assert got.dtype == torch.float32
+        _check(got, want, tol=tol32, msg=f"fp32 in place, case {n} ({var})")
+        if Sk > 512:  # the full-row and general kernels stop at 512 keys: no pair for the comparisons below
+            continue
+        _lib.load().oeh_debug_set_variant((1 << 6) | (1 << 7), 0)  # fp32 forms of the one-pass / full-row kernels off
         try:
-            got_gen = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), workspace=False, **kw)
+            got_gen = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), **kw)
         finally:
             _lib.load().oeh_debug_set_variant(0, 0)
-        assert got_ws.dtype == torch.float32
-        _check(got_ws, want, tol=tol32, msg=f"workspace path case {n} ({var})")
         _check(got_gen, want, tol=tol32, msg=f"general kernel case {n}")
-        if Sk > 512:  # the full-row and general kernels stop at 512 keys: the INT8 comparison below has no pair
-            continue
         # INT8 chain: same bits from both kernels (same rounded operands, same per-element chain)
         fq = ops.AttnFakeQuant(FQ(0.05, 120.0), FQ(1.0 / 255.0, 0.0), FQ(0.01, 128.0), ctx_before_gate=bool(n & 1))
         a = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=fq, **kw)
-        b_ = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=fq, workspace=False, **kw)
-        assert torch.equal(a, b_), f"INT8 fp32 case {n}: workspace path differs from the general kernel"
+        _lib.load().oeh_debug_set_variant((1 << 6) | (1 << 7), 0)
+        try:
+            b_ = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=fq, **kw)
+        finally:
+            _lib.load().oeh_debug_set_variant(0, 0)
+        assert torch.equal(a, b_), f"INT8 fp32 case {n}: the full-row kernel differs from the general kernel"

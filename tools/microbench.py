@@ -4,8 +4,7 @@ rotating over enough buffer sets to exceed the 256 MiB Infinity Cache.  Usage:
     python tools/microbench.py "B=16,H=12,S=512,D=64,causal=1" "B=32,H=12,S=128,D=64,pad=1" ...
 keys: B H S D causal pad clip int8 dtype(f16|bf16|f32) full iters reps gate base graph(=launches per captured graph)
       gmlp (>= 0: per-token gate predictor with that many hidden units evaluated in the kernel; 0 = Linear)
-      ws (fp32 storage: 0 = no workspace, general kernel)
-      off (bit mask of kernel variants to disable: 2 = one-pass, 4 = full-row; 256 = one-pass also for Sk <= 128)  mq (force one-pass query blocks per wave)
+      off (bit mask of kernel variants to disable: 2 = one-pass, 4 = full-row; 64 / 128 = their fp32-storage forms; 256 = one-pass also for Sk <= 128)  mq (force one-pass query blocks per wave)
 """
 import ctypes as C
 import sys
@@ -19,7 +18,7 @@ from outeffhop_amd import _lib, ops
 
 
 def run(spec):
-    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, reps=1, graph=0, gmlp=-1, ws=1)
+    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, reps=1, graph=0, gmlp=-1)
     for item in spec.split(","):
         k, v = item.split("=")
         kv[k] = v if k == "dtype" else int(v)
@@ -62,7 +61,7 @@ def run(spec):
     spec_sm = ops.SoftmaxSpec(kv["base"], bool(kv["clip"]), -0.025 if kv["clip"] else 0.0, 1.1 if kv["clip"] else 1.0)
     out = torch.empty(B, S, H, D, dtype=dt, device="cuda").permute(0, 2, 1, 3)
     kw = dict(softmax=spec_sm, causal=bool(kv["causal"]), clamp_min=bool(kv["causal"] or kv["full"]), key_pad_mask=pad, full_mask=full,
-              gate=gate, fq=fq, mask_min=fmin, out=out, gate_mlp=gmlp, workspace=None if kv["ws"] else False)
+              gate=gate, fq=fq, mask_min=fmin, out=out, gate_mlp=gmlp)
     calls = [ops.PreparedAttn(*st, **kw) for st in sets]
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for i in range(10):
