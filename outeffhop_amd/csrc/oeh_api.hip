@@ -95,6 +95,7 @@ bool fast_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
   if (d->dtype == OEH_F32 || d->full_mask != nullptr) return false;
   if (any_fq(fq)) {  // the FQ variant: scores and probabilities both quantised (the reference's configuration), no in-kernel predictor
     if (!(fq->scores.enable && fq->probs.enable) || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
+    if (fq->scores.dump_idx != nullptr || fq->probs.dump_idx != nullptr || fq->ctx.dump_idx != nullptr) return false;  // test-only dumps: general kernel
   }
   if (d->scale_div != 0.0f ? !is_pow2(d->scale_div) : !(d->scale > 0.0f && std::isfinite(d->scale))) return false;
   if (d->clip && d->gamma > 0.0f) return false;

@@ -52,7 +52,8 @@ constexpr int fast_occupancy() { return D >= 128 ? 1 : 3; }  // what the LDS rin
 // order literally - scale, quantise, masks added (not substituted), x - m, 1-ulp exp, normalise, [clip], quantise - as in
 // the general kernel (oeh_attn_mfma.inl), on this kernel's data path.  The variant is compiled for the reference's
 // configuration, scores AND probabilities quantised (context optional): a run-time test per quantiser and per four elements
-// costs a branch and, at the join, register copies (1.5 VALU per element for the clip alone).  Other subsets: general kernel.
+// costs a branch and, at the join, register copies (1.5 VALU per element for the clip alone).  Other subsets, and the
+// test-only uint8 index dumps (a uniform branch per four elements per quantiser even when off): general kernel.
 // SRC32: fp32 storage read directly, as in the one-pass kernel (oeh_attn_flash.inl): the K-then-V tile stream comes
 // through registers (32 B of fp32 per lane and piece, rounded to fp16, written to the LDS image the DMA would produce), one
 // tile ahead - committed at the top of an iteration, the next tile's loads issued right after the barrier.  The staged tile
@@ -336,7 +337,6 @@ __global__ __launch_bounds__(256, (SRC32 ? (D >= 128 ? 1 : 2) : fast_occupancy<N
   if constexpr (FQ) {
     const float mask_min = P.mask_min;
     const int klimc = qrow + off;                                          // last key a causal row may see
-    const bool dump_s = P.fq_s.dump != nullptr, dump_p = P.fq_p.dump != nullptr;
     const int kt_causal = causal ? (max(0, q0 + off + 1) >> 6) : KT;       // first 64-key tile with a key the wave's first row must not see
     const int kt_tail = Sk >> 6;                                           // first 64-key tile with a key >= Sk
 #pragma unroll
@@ -350,7 +350,6 @@ __global__ __launch_bounds__(256, (SRC32 ? (D >= 128 ? 1 : 2) : fast_occupancy<N
           x = x * sc;
           {
             const f4 rel = fq_rel4(x, P.fq_s);
-            if (dump_s && qvalid) dump4(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0, fq_dump_word(rel, P.fq_s), Sk - key0);
             x = rel * P.fq_s.scale;
           }
           if (has_pad) {
@@ -420,7 +419,6 @@ __global__ __launch_bounds__(256, (SRC32 ? (D >= 128 ? 1 : 2) : fast_occupancy<N
             }
           }
           pv = fq_rel4(pv, P.fq_p);  // integer valued (idx - zp): exact in f16/bf16; the scale is applied after the product
-          if (dump_p && qvalid) dump4(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0, fq_dump_word(pv, P.fq_p), Sk - key0);
           if (kt >= kt_tail) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -602,26 +600,22 @@ __global__ __launch_bounds__(256, (SRC32 ? (D >= 128 ? 1 : 2) : fast_occupancy<N
   for (int dt = 0; dt < DT; ++dt) {
     float ov[4];
     if constexpr (FQ) {  // [scale of the quantised P] [fq] gate [fq]: the general kernel's epilogue chain
-      unsigned int dump_word = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = o[dt][r];
         x = P.fq_p.scale * x;
         if (P.fq_c.en && P.ctx_before_gate) {
           const float idx = fq_index(x, P.fq_c);
-          dump_word |= ((unsigned int)idx) << (8 * r);
           x = fq_dequant(idx, P.fq_c);
         }
         if (P.gate != nullptr) x = x * rowscale;
         if (P.fq_c.en && !P.ctx_before_gate) {
           const float idx = fq_index(x, P.fq_c);
-          dump_word |= ((unsigned int)idx) << (8 * r);
           x = fq_dequant(idx, P.fq_c);
         }
         ov[r] = x;
       }
-      if (P.fq_c.en && P.fq_c.dump != nullptr && q0 + ce < P.Sq)
-        dump4(P.fq_c.dump + (((long)b * P.H + h) * P.Sq + q0 + ce) * D + 16 * dt + 4 * ge, dump_word, 4);
+
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) ov[r] = o[dt][r] * rowscale;
