@@ -341,7 +341,16 @@ __global__ __launch_bounds__(256, (SRC32 ? (D >= 128 ? 1 : 2) : fast_occupancy<N
     const int kt_tail = Sk >> 6;                                           // first 64-key tile with a key >= Sk
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-      if (kt < n_kt) {
+      if (kt < n_kt && !has_pad && kt < kt_causal && kt < kt_tail) {
+        // no mask touches this 64-key tile: the chain without its four per-sub-tile uniform tests (one test per tile)
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          const int t = kt * 4 + sub;
+          const f4 x = fq_rel4(s[t] * sc, P.fq_s) * P.fq_s.scale;
+          s[t] = x;
+          m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(x[0], x[1])), __builtin_fmaxf(x[2], x[3]));
+        }
+      } else if (kt < n_kt) {
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
           const int t = kt * 4 + sub;
