@@ -289,6 +289,7 @@ int oeh_fake_quant(const void* x, void* y, uint8_t* idx, int64_t n, int32_t dtyp
   FqP f;
   std::memset(&f, 0, sizeof(f));
   f.en = 1; f.scale = scale; f.rscale = 1.0f / scale; f.zp = zero_point; f.qmax = qmax;
+  f.lo = -zero_point; f.hi = qmax - zero_point;
   return oeh::launch_fake_quant(x, y, idx, n, dtype, f, reinterpret_cast<hipStream_t>(stream));
 }
 

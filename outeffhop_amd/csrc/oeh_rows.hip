@@ -58,7 +58,121 @@ __global__ __launch_bounds__(256) void oeh_softmax_rows_kernel(const void* __res
   }
 }
 
+// ---- 16-byte vector access for the streaming kernels: VEC elements per access (4 fp32 / 8 x 16-bit)
+template <int IN>
+struct Vec16 {
+  static constexpr int N = 16 / In<IN>::bytes;
+  static __device__ __forceinline__ void load(const void* p, float* out) {
+    const u4 w = *reinterpret_cast<const u4*>(p);
+    if constexpr (IN == IN_F32) {
+      out[0] = bits_f32(w.x); out[1] = bits_f32(w.y); out[2] = bits_f32(w.z); out[3] = bits_f32(w.w);
+    } else {
+      const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        out[2 * i] = In<IN>::to_f32((unsigned short)(ws[i] & 0xffffu));
+        out[2 * i + 1] = In<IN>::to_f32((unsigned short)(ws[i] >> 16));
+      }
+    }
+  }
+  static __device__ __forceinline__ void store(void* p, const float* v) {
+    u4 w;
+    if constexpr (IN == IN_F32) {
+      w = u4{f32_bits(v[0]), f32_bits(v[1]), f32_bits(v[2]), f32_bits(v[3])};
+    } else if constexpr (IN == IN_BF16) {
+      w = u4{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
+    } else {
+      w = u4{pack2_f16(v[0], v[1]), pack2_f16(v[2], v[3]), pack2_f16(v[4], v[5]), pack2_f16(v[6], v[7])};
+    }
+    *reinterpret_cast<u4*>(p) = w;
+  }
+};
+
+// softmax rows of up to 64*VEC*CH elements: ONE WAVE per row, the row in registers (16-B loads, lane-strided chunks), wave
+// reductions by shuffles - no LDS, no workgroup barrier; four rows per 256-thread workgroup.  Same per-element arithmetic as
+// the staged kernel above (1-ulp exp, true division).
+template <int IN, int CH>
+__global__ __launch_bounds__(256) void oeh_softmax_rows_wave_kernel(const void* __restrict__ xin, void* yout, long rows, int cols,
+                                                                   int base, int clip, float clip_w, float clip_g) {
+  constexpr int N = Vec16<IN>::N;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const unsigned char* x = reinterpret_cast<const unsigned char*>(xin) + row * cols * In<IN>::bytes;
+  unsigned char* y = reinterpret_cast<unsigned char*>(yout) + row * cols * In<IN>::bytes;
+  const int nchunk = cols / N;
+  float v[CH][N];
+  float m = -__builtin_inff();
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunk) {
+      Vec16<IN>::load(x + (long)ch * 16, v[c]);
+#pragma unroll
+      for (int i = 0; i < N; ++i) m = __builtin_fmaxf(m, v[c][i]);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
+  float sum = 0.0f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (lane + 64 * c < nchunk) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        v[c][i] = exp_acc(v[c][i] - m);
+        sum += v[c][i];
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  float den = sum;
+  if (base != 0) den = sum + exp_acc(m * -1.0f);
+  const float rden = 1.0f / den;  // RN(1/den): e/den below is the three-instruction correctly rounded quotient (oeh_common.h: fq_quot)
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const float q0 = v[c][i] * rden;
+        float p = __builtin_fmaf(__builtin_fmaf(-q0, den, v[c][i]), rden, q0);
+        if (!(den < 3.0e38f)) p = v[c][i] / den;  // softmax_1 of a fully masked row: den = inf, p = 0 (row-uniform test)
+        if (clip) {
+          p = p * clip_w;
+          p = p + clip_g;
+          p = __builtin_fminf(__builtin_fmaxf(p, 0.0f), 1.0f);
+        }
+        v[c][i] = p;
+      }
+      Vec16<IN>::store(y + (long)ch * 16, v[c]);
+    }
+  }
+}
+
+template <int IN>
+static bool launch_softmax_rows_wave(const void* x, void* y, long rows, int cols, int base, int clip, float w, float g, hipStream_t st) {
+  constexpr int N = Vec16<IN>::N;
+  if (cols % N != 0 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) != 0) return false;
+  const int nchunk = cols / N;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  if (nchunk <= 64) hipLaunchKernelGGL((oeh_softmax_rows_wave_kernel<IN, 1>), dim3(grid), dim3(256), 0, st, x, y, rows, cols, base, clip, w, g);
+  else if (nchunk <= 128) hipLaunchKernelGGL((oeh_softmax_rows_wave_kernel<IN, 2>), dim3(grid), dim3(256), 0, st, x, y, rows, cols, base, clip, w, g);
+  else if (nchunk <= 256) hipLaunchKernelGGL((oeh_softmax_rows_wave_kernel<IN, 4>), dim3(grid), dim3(256), 0, st, x, y, rows, cols, base, clip, w, g);
+  else if (nchunk <= 512) hipLaunchKernelGGL((oeh_softmax_rows_wave_kernel<IN, 8>), dim3(grid), dim3(256), 0, st, x, y, rows, cols, base, clip, w, g);
+  else return false;
+  return true;
+}
+
 int launch_softmax_rows(const void* x, void* y, long rows, int cols, int in, int base, int clip, float w, float g, hipStream_t st) {
+  {  // rows that fit a wave's registers (<= 2048 fp32 / 4096 16-bit elements, multiple of the 16-B vector)
+    bool done;
+    switch (in) {
+      case IN_F16: done = launch_softmax_rows_wave<IN_F16>(x, y, rows, cols, base, clip, w, g, st); break;
+      case IN_BF16: done = launch_softmax_rows_wave<IN_BF16>(x, y, rows, cols, base, clip, w, g, st); break;
+      default: done = launch_softmax_rows_wave<IN_F32>(x, y, rows, cols, base, clip, w, g, st); break;
+    }
+    if (done) return hipGetLastError() == hipSuccess ? 0 : -5;
+  }
   const bool staged = cols <= 15872;
   const size_t shmem = staged ? (size_t)cols * 4 : 0;
   const unsigned grid = (unsigned)(rows < 65536 ? rows : 65536);
@@ -92,7 +206,53 @@ __global__ __launch_bounds__(256) void oeh_fake_quant_kernel(const void* __restr
   }
 }
 
+// 16-B accesses, the three-instruction correctly rounded quotient (oeh_common.h: fq_quot) instead of a division; the
+// (n % VEC) tail elements are done by the last thread with the scalar formula
+template <int IN>
+__global__ __launch_bounds__(256) void oeh_fake_quant_vec_kernel(const void* __restrict__ xin, void* yout, unsigned char* idx_out, long n, FqP f) {
+  constexpr int N = Vec16<IN>::N;
+  const long nvec = n / N;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    float v[N];
+    Vec16<IN>::load(reinterpret_cast<const unsigned char*>(xin) + i * 16, v);
+    unsigned int packed[N / 4];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const float rel = fq_rel(v[k], f);
+      if (k % 4 == 0) packed[k / 4] = 0;
+      packed[k / 4] |= ((unsigned int)(rel + f.zp)) << (8 * (k % 4));
+      v[k] = f.scale * rel;
+    }
+    if (yout) Vec16<IN>::store(reinterpret_cast<unsigned char*>(yout) + i * 16, v);
+    if (idx_out) {
+#pragma unroll
+      for (int k = 0; k < N / 4; ++k) reinterpret_cast<unsigned int*>(idx_out + i * N)[k] = packed[k];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    typedef typename In<IN>::elem E;
+    for (long i = nvec * N; i < n; ++i) {
+      const float rel = fq_rel(In<IN>::to_f32(reinterpret_cast<const E*>(xin)[i]), f);
+      if (idx_out) idx_out[i] = (unsigned char)(rel + f.zp);
+      if (yout) reinterpret_cast<E*>(yout)[i] = In<IN>::from_f32(f.scale * rel);
+    }
+  }
+}
+
 int launch_fake_quant(const void* x, void* y, unsigned char* idx, long n, int in, FqP f, hipStream_t st) {
+  if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && (reinterpret_cast<uintptr_t>(idx) & 3) == 0 && (idx == nullptr || f.qmax <= 255.0f)) {
+    const long nvec = n / (in == IN_F32 ? 4 : 8);
+    long blocks = (nvec + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    switch (in) {
+      case IN_F16: hipLaunchKernelGGL(oeh_fake_quant_vec_kernel<IN_F16>, dim3((unsigned)blocks), dim3(256), 0, st, x, y, idx, n, f); break;
+      case IN_BF16: hipLaunchKernelGGL(oeh_fake_quant_vec_kernel<IN_BF16>, dim3((unsigned)blocks), dim3(256), 0, st, x, y, idx, n, f); break;
+      default: hipLaunchKernelGGL(oeh_fake_quant_vec_kernel<IN_F32>, dim3((unsigned)blocks), dim3(256), 0, st, x, y, idx, n, f); break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+  }
   long blocks = (n + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
@@ -324,12 +484,75 @@ __global__ __launch_bounds__(256) void oeh_minmax_kernel(const void* __restrict_
   }
 }
 
+// 16-B loads, four in flight per thread; one atomic pair per workgroup
+template <int IN>
+__global__ __launch_bounds__(256) void oeh_minmax_vec_kernel(const void* __restrict__ xin, long n, int* keys) {
+  constexpr int N = Vec16<IN>::N;
+  __shared__ float red[8];
+  const long nvec = n / N;
+  const long stride = (long)gridDim.x * blockDim.x;
+  float lo = __builtin_inff(), hi = -__builtin_inff();
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < nvec; i += 4 * stride) {
+    float v[4][N];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Vec16<IN>::load(reinterpret_cast<const unsigned char*>(xin) + (i + u * stride) * 16, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        lo = __builtin_fminf(lo, v[u][k]);
+        hi = __builtin_fmaxf(hi, v[u][k]);
+      }
+  }
+  for (; i < nvec; i += stride) {
+    float v[N];
+    Vec16<IN>::load(reinterpret_cast<const unsigned char*>(xin) + i * 16, v);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      lo = __builtin_fminf(lo, v[k]);
+      hi = __builtin_fmaxf(hi, v[k]);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    typedef typename In<IN>::elem E;
+    for (long t = nvec * N; t < n; ++t) {
+      const float v = In<IN>::to_f32(reinterpret_cast<const E*>(xin)[t]);
+      lo = __builtin_fminf(lo, v);
+      hi = __builtin_fmaxf(hi, v);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = __builtin_fminf(lo, __shfl_xor(lo, o));
+    hi = __builtin_fmaxf(hi, __shfl_xor(hi, o));
+  }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = lo; red[4 + (threadIdx.x >> 6)] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMin(&keys[0], f2key(__builtin_fminf(__builtin_fminf(red[0], red[1]), __builtin_fminf(red[2], red[3]))));
+    atomicMax(&keys[1], f2key(__builtin_fmaxf(__builtin_fmaxf(red[4], red[5]), __builtin_fmaxf(red[6], red[7]))));
+  }
+}
+
 int launch_minmax(const void* x, long n, int in, float* out2, hipStream_t st) {
   int* keys = reinterpret_cast<int*>(out2);
+  hipLaunchKernelGGL(oeh_minmax_init_kernel, dim3(1), dim3(1), 0, st, keys);
+  if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const long nvec = n / (in == IN_F32 ? 4 : 8);
+    long vb = (nvec + 1023) / 1024;  // four vectors per thread
+    if (vb > 2048) vb = 2048;
+    if (vb < 1) vb = 1;
+    switch (in) {
+      case IN_F16: hipLaunchKernelGGL(oeh_minmax_vec_kernel<IN_F16>, dim3((unsigned)vb), dim3(256), 0, st, x, n, keys); break;
+      case IN_BF16: hipLaunchKernelGGL(oeh_minmax_vec_kernel<IN_BF16>, dim3((unsigned)vb), dim3(256), 0, st, x, n, keys); break;
+      default: hipLaunchKernelGGL(oeh_minmax_vec_kernel<IN_F32>, dim3((unsigned)vb), dim3(256), 0, st, x, n, keys); break;
+    }
+    hipLaunchKernelGGL(oeh_minmax_fin_kernel, dim3(1), dim3(1), 0, st, keys);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+  }
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(oeh_minmax_init_kernel, dim3(1), dim3(1), 0, st, keys);
   switch (in) {
     case IN_F16: hipLaunchKernelGGL(oeh_minmax_kernel<IN_F16>, dim3((unsigned)blocks), dim3(256), 0, st, x, n, keys); break;
     case IN_BF16: hipLaunchKernelGGL(oeh_minmax_kernel<IN_BF16>, dim3((unsigned)blocks), dim3(256), 0, st, x, n, keys); break;
