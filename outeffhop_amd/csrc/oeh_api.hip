@@ -97,7 +97,11 @@ bool fast_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
     if (!(fq->scores.enable && fq->probs.enable) || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
     if (fq->scores.dump_idx != nullptr || fq->probs.dump_idx != nullptr || fq->ctx.dump_idx != nullptr) return false;  // test-only dumps: general kernel
   }
-  if (d->scale_div != 0.0f ? !is_pow2(d->scale_div) : !(d->scale > 0.0f && std::isfinite(d->scale))) return false;
+  // a divisor (BERT order, bert_attention.py:265): a power of two is the same multiply exactly; any other positive divisor
+  // becomes a multiply by RN(1/div) - one more rounding of 6e-8 relative, far inside the accuracy of the 16-bit paths -
+  // except under fake-quant, where the index must come from the reference's own rounding (general kernel: true division)
+  if (d->scale_div != 0.0f ? !(is_pow2(d->scale_div) || (!any_fq(fq) && d->scale_div > 0.0f && std::isfinite(d->scale_div)))
+                           : !(d->scale > 0.0f && std::isfinite(d->scale))) return false;
   if (d->clip && d->gamma > 0.0f) return false;
   if (d->causal && d->Sq > d->Sk) return false;
   if ((d->causal || d->key_pad_mask != nullptr) && !(d->mask_min < -1.0e4f)) return false;
@@ -238,7 +242,7 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
   P.src32 = (desc->dtype == OEH_F32 && (var == V_FLASH || var == V_FAST)) ? 1 : 0;  // fp32 storage read directly, fp32 output
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (var == V_FLASH) {
-    if (desc->scale_div != 0.0f) { P.scale = 1.0f / desc->scale_div; P.scale_div = 0.0f; }  // exact: power of two
+    if (desc->scale_div != 0.0f) { P.scale = 1.0f / desc->scale_div; P.scale_div = 0.0f; }  // (fast_eligible: exact for a power of two)
     const int mq = flash_mq(desc);
     P.nQT = (desc->Sq + 64 * mq - 1) / (64 * mq);
     switch (desc->D) {
@@ -248,7 +252,7 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
     }
   }
   if (var == V_FAST) {
-    if (desc->scale_div != 0.0f) { P.scale = 1.0f / desc->scale_div; P.scale_div = 0.0f; }  // exact: power of two
+    if (desc->scale_div != 0.0f) { P.scale = 1.0f / desc->scale_div; P.scale_div = 0.0f; }  // (fast_eligible: exact for a power of two)
     switch (desc->D) {
       case 32: return oeh::launch_attn_fast_d32(P, desc->dtype, st);
       case 64: return oeh::launch_attn_fast_d64(P, desc->dtype, st);

@@ -611,3 +611,26 @@ def test_fp32_storage_is_read_in_place_by_the_16bit_operand_kernels(ops):
         finally:
             _lib.load().oeh_debug_set_variant(0, 0)
         assert torch.equal(a, b_), f"INT8 fp32 case {n}: the full-row kernel differs from the general kernel"
+
+
+@pytest.mark.parametrize("D", [32, 128])
+def test_bert_order_with_a_divisor_that_is_not_a_power_of_two(ops, D):
+    """scores / sqrt(d) with d = 32 / 128 (bert_attention.py:265): the 16-bit kernels multiply by RN(1/sqrt(d)); under
+    fake-quant the general kernel divides."""
+    B, H, S = 2, 3, 200
+    fmin = float(np.finfo(np.float32).min)
+    q, k, v = _rand((B, H, S, D), 910), _rand((B, H, S, D), 911), _rand((B, H, S, D), 912)
+    padm = np.zeros((B, S), dtype=np.float32)
+    padm[1, 150:] = fmin
+    div = float(np.sqrt(D))
+    want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=div, scale_is_divisor=True, pad_mask=padm, **SPECS["softmax1"])
+    got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=_spec(ops, "softmax1"), scale_div=div, key_pad_mask=torch.from_numpy(padm).cuda(), mask_min=fmin)
+    _check(got, want, msg=f"divisor sqrt({D})")
+    from outeffhop_amd import _lib
+    d = _lib.oeh_attn_desc()
+    d.B, d.H, d.Sq, d.Sk, d.D, d.dtype, d.scale, d.scale_div, d.mask_min, d.softmax_base = B, H, S, S, D, 0, 1.0, div, fmin, 1
+    assert _lib.load().oeh_attn_variant(d, None).decode().startswith("flash16/")
+    fqd = _lib.oeh_fq_desc()
+    for f in (fqd.scores, fqd.probs):
+        f.enable, f.scale, f.qmax = 1, 0.05, 255.0
+    assert _lib.load().oeh_attn_variant(d, fqd).decode().startswith("mfma16/")
