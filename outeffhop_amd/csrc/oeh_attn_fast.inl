@@ -56,10 +56,9 @@ constexpr int fast_occupancy() { return D >= 128 ? 1 : 3; }  // what the LDS rin
 // test-only uint8 index dumps (a uniform branch per four elements per quantiser even when off): general kernel.
 // SRC32: fp32 storage read directly, as in the one-pass kernel (oeh_attn_flash.inl): the K-then-V tile stream comes
 // through registers (32 B of fp32 per lane and piece, rounded to fp16, written to the LDS image the DMA would produce), one
-// tile ahead - committed at the top of an iteration, the next tile's loads issued right after the barrier.  The staged tile
-// is live through the softmax phase, so these variants are compiled for two waves per SIMD.
+// tile ahead - committed at the top of an iteration, the next tile's loads issued right after the barrier.
 template <int NT, int D, int IN, bool CLIP, bool GATE, bool FQ = false, bool SRC32 = false>
-__global__ __launch_bounds__(256, (SRC32 ? (D >= 128 ? 1 : 2) : fast_occupancy<NT, D>())) void oeh_attn_fast_kernel(const AttnParams P) {
+__global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_kernel(const AttnParams P) {
   static_assert(!SRC32 || (!GATE && IN == IN_F16), "fp32 storage: fp16 operands, fp32 output, no in-kernel gate predictor");
   constexpr bool OUT32 = SRC32;
   static_assert(!FQ || !GATE, "the fake-quant variant has no in-kernel gate predictor");
@@ -307,7 +306,9 @@ __global__ __launch_bounds__(256, (SRC32 ? (D >= 128 ? 1 : 2) : fast_occupancy<N
       if constexpr (SRC32) {
         commit_tile(kt % R);                       // tile i (loaded an iteration ago) -> its K ring slot; last reader: tile i-3
         barrier_mem();
-        if (i + 1 < T) load_tile(i + 1);           // lands while tile i is computed
+        // lands while tile i is computed.  D < 128: V tile 0 is requested only after the softmax phase - staged through it,
+        // it would cost the 512-key forms a wave per SIMD (INT8 fp32 52 -> 46 us, clip 37.9 -> 34.4 us with the request deferred)
+        if (i + 1 < (D < 128 ? n_kt : T)) load_tile(i + 1);
       } else {
       wait_tiles_in_flight<G>(min(1, T - 1 - i));  // tile i landed; tile i+1 may still be in flight
       barrier_mem();
@@ -549,6 +550,7 @@ __global__ __launch_bounds__(256, (SRC32 ? (D >= 128 ? 1 : 2) : fast_occupancy<N
   }
 
   }  // !FQ
+  if constexpr (SRC32 && D < 128) load_tile(n_kt);  // V tile 0
   OEH_STAMP(12);
   // =========================== phase 3: O^T = V^T P^T ===========================
   f4 o[DT];
