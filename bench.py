@@ -140,7 +140,15 @@ def int8_check():
     fq = ops.AttnFakeQuant(FQ(*d_s, dump=dumps["scores"]), FQ(*d_p, dump=dumps["probs"]), FQ(*d_c, dump=dumps["ctx"]), ctx_before_gate=True)
     got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=ops.SoftmaxSpec(1, False, 0.0, 1.0), causal=True, clamp_min=True,
                        mask_min=float(np.finfo(np.float32).min), fq=fq)
+    # the call above asks for index dumps and therefore runs the general kernel; the production call (no dumps) runs the
+    # full-row kernel's FQ variant - the kernel the opt_int8 workload times.  Its output is what max_abs_err is taken from,
+    # and it must equal the dumped run bit for bit.
+    fq_prod = ops.AttnFakeQuant(FQ(*d_s), FQ(*d_p), FQ(*d_c), ctx_before_gate=True)
+    got_prod = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=ops.SoftmaxSpec(1, False, 0.0, 1.0), causal=True, clamp_min=True,
+                            mask_min=float(np.finfo(np.float32).min), fq=fq_prod)
     torch.cuda.synchronize()
+    same_bits = bool(torch.equal(got, got_prod))
+    got = got_prod
     tri = np.tril(np.ones((S, S), dtype=bool))[None, None]
     flips, total = 0, 0
     for n in ("scores", "probs", "ctx"):
@@ -149,6 +157,7 @@ def int8_check():
         flips += int((a_[sel] != b_[sel]).sum())
         total += int(sel.sum())
     return {"max_abs_err": float(np.abs(got.float().cpu().numpy() - want).max()), "quantiser_index_mismatch_rate": flips / total,
+            "production_kernel": ops.attn_variant(B, H, S, S, D, fq=True), "production_kernel_equals_index_dump_run_bitwise": same_bits,
             "sample": f"B={B} H={H} S={S} d={D} fp16 causal softmax1, 8-bit scores/probs/context quantisers, vs oracle/oeh_oracle.py"}
 
 
