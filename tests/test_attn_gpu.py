@@ -634,3 +634,49 @@ def test_bert_order_with_a_divisor_that_is_not_a_power_of_two(ops, D):
     for f in (fqd.scores, fqd.probs):
         f.enable, f.scale, f.qmax = 1, 0.05, 255.0
     assert _lib.load().oeh_attn_variant(d, fqd).decode().startswith("mfma16/")
+
+
+def test_randomised_sweep_fp32_storage(ops):
+    """The same kind of sweep on fp32 tensors: the register-staged fp32 forms of the one-pass and the full-row kernel and
+    the general kernel, ragged shapes, strided head views, masks, gates, clipped and plain softmax, against the oracle."""
+    from outeffhop_amd import _lib
+
+    lib = _lib.load()
+    fmin = float(np.finfo(np.float32).min)
+    rng = np.random.default_rng(424242)
+    tol32 = dict(atol=2e-3, rtol=2e-3)
+    seen = set()
+    try:
+        for n in range(30):
+            D = int(rng.choice([32, 64, 64, 128]))
+            H, B = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+            Sk = int(rng.integers(17, 600))
+            causal = bool(rng.integers(0, 2))
+            Sq = int(rng.integers(max(1, Sk - 150), Sk + 1)) if causal else int(rng.integers(1, 300))
+            sm = ["softmax1", "vanilla", "clippedsoftmax1(-.025:1)"][int(rng.integers(0, 3))]
+            pad = (not causal) and bool(rng.integers(0, 2))
+            gated = bool(rng.integers(0, 2))
+            q = _rand((B, Sq, H * D), 8000 + n, dtype=torch.float32).view(B, Sq, H, D).permute(0, 2, 1, 3)
+            k = _rand((B, Sk, H * D), 8100 + n, dtype=torch.float32).view(B, Sk, H, D).permute(0, 2, 1, 3)
+            v = _rand((B, Sk, H * D), 8200 + n, dtype=torch.float32).view(B, Sk, H, D).permute(0, 2, 1, 3)
+            padm = None
+            if pad:
+                padm = np.zeros((B, Sk), dtype=np.float32)
+                for b in range(B):
+                    padm[b, int(rng.integers(1, Sk + 1)):] = fmin
+            gate = torch.rand((B, H, Sq, 1), generator=torch.Generator().manual_seed(8300 + n)) if gated else None
+            want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=D ** -0.5, causal=causal, clamp_min=causal, pad_mask=padm,
+                               gate=None if gate is None else gate.numpy(), **SPECS[sm])
+            for off_mask in (0, 1 << 6, (1 << 6) | (1 << 7)):   # as picked; fp32 one-pass off; both fp32 forms off (general / generic)
+                lib.oeh_debug_set_variant(off_mask, 0)
+                var = ops.attn_variant(B, H, Sq, Sk, D, torch.float32, clip="clipped" in sm)
+                if var is None:
+                    continue
+                seen.add(var.split("/")[0])
+                got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=_spec(ops, sm), scale=D ** -0.5, causal=causal, clamp_min=causal,
+                                   key_pad_mask=None if padm is None else torch.from_numpy(padm).cuda(),
+                                   gate=None if gate is None else gate.cuda(), mask_min=fmin)
+                _check(got, want, tol=tol32, msg=f"cfg {n} {(B, H, Sq, Sk, D, causal, sm, pad, gated)} via {var}")
+    finally:
+        lib.oeh_debug_set_variant(0, 0)
+    assert {"flash16", "fast16", "mfma16"} <= seen
