@@ -49,9 +49,9 @@ __device__ __forceinline__ float fq_quot(float x, const FqP& f) {
 // for two instructions less per element; x_q = scale * rel, and rel itself is the integer the P operand carries.
 __device__ __forceinline__ float fq_rel(float x, const FqP& f) { return __builtin_amdgcn_fmed3f(__builtin_rintf(fq_quot(x, f)), f.lo, f.hi); }
 // (A packed form of the quotient - v_pk_mul_f32 / v_pk_fma_f32 on element pairs - measured much slower in the full-row
-// kernel: 55 vs 39 us on the INT8 OPT shape, 25.5 vs 13.9 us on BERT-base; the three packed operations of a pair form one
-// dependent chain.  The range reduction of the exponential below, whose packed operations are independent of each other,
-// is packed.)
+// kernel: 55 vs 39 us on the INT8 OPT shape, 25.5 vs 13.9 us on BERT-base.  Packed fp32 buys no throughput on this chip
+// anyway: tools/pk_bench.hip times 16 scalar VALU operations at 37.7 cycles per wave and the same arithmetic as 8 packed
+// ones at 37.1 - a wave64 fp32 operation issues in ~2.3 cycles, a packed one in twice that.)
 __device__ __forceinline__ f4 fq_rel4(f4 x, const FqP& f) { return f4{fq_rel(x[0], f), fq_rel(x[1], f), fq_rel(x[2], f), fq_rel(x[3], f)}; }
 __device__ __forceinline__ float fq_index(float x, const FqP& f) { return fq_rel(x, f) + f.zp; }
 __device__ __forceinline__ float fq_dequant(float idx, const FqP& f) { return f.scale * (idx - f.zp); }
