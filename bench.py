@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-check", action="store_true", help="N > 1: skip the shard-parity check (all_gather of the ranks' layer-0 outputs "
+                    "over RCCL, each compared bit for bit with rank 0's own run of that shard)")
     return ap.parse_args()
 
 
@@ -161,14 +163,62 @@ def int8_check():
             "sample": f"B={B} H={H} S={S} d={D} fp16 causal softmax1, 8-bit scores/probs/context quantisers, vs oracle/oeh_oracle.py"}
 
 
+def fp16_check():
+    """north_star: "within 1e-3 fp16".  The headline kernel against the reference arithmetic (CPU oracle) on a bounded sample
+    of the headline workload (B=1 H=2 S=512 d=64 fp16 causal softmax1 / clippedsoftmax1), with the error split into its two
+    parts: the kernel's own arithmetic BEFORE the final rounding (taken from the fp32-output form of the same kernel on the
+    same fp16 values) and the rounding of the result to fp16 storage (in fp16 ulps of the reference value: <= 0.5 ulp is
+    the rounding alone).  Part of the cpu_baseline leg: the oracle is the checker only."""
+    import numpy as np
+    import torch
+
+    from oracle import oeh_oracle as O
+    from outeffhop_amd import ops
+
+    B, H, S, D = 1, 2, 512, 64
+    g = torch.Generator().manual_seed(1235)
+    q = (torch.randn(B, H, S, D, generator=g) * D ** -0.5).half()
+    k = torch.randn(B, H, S, D, generator=g).half()
+    v = torch.randn(B, H, S, D, generator=g).half()
+    fmin = float(np.finfo(np.float32).min)
+    out = {}
+    for name, sm in (("softmax1", (1, False, 0.0, 1.0)), ("clippedsoftmax1(-.025:1)", (1, True, -0.025, 1.1))):
+        want = O.attn_core(q.float().numpy(), k.float().numpy(), v.float().numpy(), base=sm[0], clip=sm[1], gamma=sm[2], eta=sm[3],
+                           causal=True, clamp_min=True)
+        kw = dict(softmax=ops.SoftmaxSpec(*sm), causal=True, clamp_min=True, mask_min=fmin)
+        got16 = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), **kw).float().cpu().numpy()
+        got32 = ops.attn_fwd(q.cuda().float(), k.cuda().float(), v.cuda().float(), **kw).cpu().numpy()
+        ulp = np.maximum(np.spacing(np.abs(want).astype(np.float16)).astype(np.float32), np.float32(2.0 ** -24))  # fp16 ulp at the reference value
+        out[name] = {"max_abs_err_fp16_output": float(np.abs(got16 - want).max()),
+                     "max_abs_err_before_output_rounding": float(np.abs(got32 - want).max()),
+                     "max_err_in_fp16_ulps_of_reference": float((np.abs(got16 - want) / ulp).max()),
+                     "max_abs_reference": float(np.abs(want).max())}
+    out["sample"] = f"B={B} H={H} S={S} d={D} fp16 causal, vs oracle/oeh_oracle.py (fp32 reference arithmetic on the fp16 values)"
+    return out
+
+
 def main():
     a = parse()
     import numpy as np
     import torch
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, fresh child
+        # processes of torch.distributed.run) BEFORE this process touches the GPU, and hand their exit code on.  An N-GPU
+        # request never falls through to a 1-GPU measurement.
+        from outeffhop_amd.dist import launch_ranks
+
+        have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+        if have < a.gpus:
+            print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible; refusing to report a {a.gpus}-GPU line", file=sys.stderr)
+            sys.exit(2)
+        sys.exit(launch_ranks(os.path.abspath(__file__), a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or without a launcher)", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
 
@@ -179,7 +229,6 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(0)
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local if world > 1 else 0)
 
     from outeffhop_amd import _lib, ops
@@ -190,42 +239,61 @@ def main():
     base, clip, gamma, eta = w["sm"]
     fmin = float(np.finfo(np.float32).min)
 
-    # ---- synthetic inputs, resident in HBM before the timed region; one buffer set per layer
-    g = torch.Generator(device="cpu").manual_seed(1235 + rank)
+    # ---- synthetic inputs, resident in HBM before the timed region; one buffer set per layer.  Per-rank data come from a
+    # generator seeded with the rank (so that rank 0 can regenerate any rank's shard for the parity check); the gate
+    # predictor weights are replicated (one seed for all ranks).
+    sdt = torch.float32 if w.get("fp32") else torch.float16
+
+    def gen_layers(r, n_layers):
+        """CPU tensors of rank r's first n_layers layers: [(q, k, v, gate_in | None)], (B,S,E) fp16 values."""
+        g = torch.Generator(device="cpu").manual_seed(1235 + r)
+        out = []
+        for _ in range(n_layers):
+            q = torch.randn(B, S, H * d, generator=g).half()
+            if w["order"] == "opt":
+                q = (q.float() * d ** -0.5).half()  # OPT scales q before QK^T (opt_attention.py:167)
+            k = torch.randn(B, S, H * d, generator=g).half()
+            v = torch.randn(B, S, H * d, generator=g).half()
+            gi = torch.randn(B, S, H * d, generator=g).half() if w["gate"] else None  # the layer's hidden states
+            out.append((q, k, v, gi))
+        return out
+
+    def gen_pad(r):
+        if w["order"] != "bert":
+            return None
+        g = torch.Generator(device="cpu").manual_seed(77 + r)
+        lens = torch.randint(S // 2, S + 1, (B,), generator=g)
+        pad_ = torch.zeros(B, S)
+        for b_, n_ in enumerate(lens.tolist()):
+            pad_[b_, n_:] = fmin
+        return pad_
+
+    view = lambda t: t.to(dev).to(sdt).view(B, S, H, d).permute(0, 2, 1, 3)  # noqa: E731  (B,H,S,d) view of (B,S,E)
     sets = []
-    for _ in range(L):
-        q = torch.randn(B, S, H * d, generator=g).half()
-        if w["order"] == "opt":
-            q = (q.float() * d ** -0.5).half()  # OPT scales q before QK^T (opt_attention.py:167)
-        k = torch.randn(B, S, H * d, generator=g).half()
-        v = torch.randn(B, S, H * d, generator=g).half()
-        sdt = torch.float32 if w.get("fp32") else torch.float16
-        view = lambda t: t.to(dev).to(sdt).view(B, S, H, d).permute(0, 2, 1, 3)  # noqa: E731  (B,H,S,d) view of (B,S,E)
+    gate_in = [] if w["gate"] else None
+    for q, k, v, gi in gen_layers(rank, L):
         o = torch.empty(B, S, H, d, dtype=sdt, device=dev).permute(0, 2, 1, 3)
         sets.append((view(q), view(k), view(v), o))
-    pad = None
-    if w["order"] == "bert":
-        lens = torch.randint(S // 2, S + 1, (B,), generator=g)
-        pad = torch.zeros(B, S)
-        for b_, n_ in enumerate(lens.tolist()):
-            pad[b_, n_:] = fmin
+        if gi is not None:
+            gate_in.append(gi.to(dev))
+    pad = gen_pad(rank)
+    if pad is not None:
         pad = pad.to(dev)
     gate = None
-    gate_in = None
     if w["gate"]:  # conditional_per_token gate, --attn_gate_mlp (submit_outlier_bert.sh:257-259): computed INSIDE the timed step
         gate = True
-        gw1 = (torch.randn(H, 16, d, generator=g) * 0.02).to(dev)
+        gg = torch.Generator(device="cpu").manual_seed(4242)
+        gw1 = (torch.randn(H, 16, d, generator=gg) * 0.02).to(dev)
         gb1 = torch.zeros(H, 16, device=dev)
-        gw2 = (torch.randn(H, 16, generator=g) * 0.02).to(dev)
+        gw2 = (torch.randn(H, 16, generator=gg) * 0.02).to(dev)
         gb2 = torch.full((H,), float(np.log(0.25 / 0.75)), device=dev)  # bias init logit(attn_gate_init = 0.25)
-        gate_in = [torch.randn(B, S, H * d, generator=g).half().to(dev) for _ in range(L)]  # the layers' hidden states
     fq = None
     if w["int8"]:
         FQ = ops.FakeQuantSpec
         fq = ops.AttnFakeQuant(FQ(0.08, 128.0), FQ(1.0 / 255.0, 0.0), FQ(0.02, 128.0), ctx_before_gate=(w["order"] == "opt"))
 
     # ---- prebuilt C-ABI descriptors: the timed loop is `oeh_attn_fwd` and nothing else
-    def make_call(q, k, v, o):
+    def make_call(q, k, v, o, pad=pad, hd=None):
         dsc = _lib.oeh_attn_desc()
         dsc.B, dsc.H, dsc.Sq, dsc.Sk, dsc.D, dsc.dtype = B, H, S, S, d, (_lib.OEH_F32 if w.get("fp32") else _lib.OEH_F16)
         for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", o)):
@@ -236,9 +304,7 @@ def main():
             dsc.scale, dsc.scale_div = 1.0, 8.0
             dsc.key_pad_mask, dsc.key_pad_dtype, dsc.key_pad_stride = pad.data_ptr(), _lib.OEH_F32, pad.stride(0)
         dsc.softmax_base, dsc.clip, dsc.gamma, dsc.eta, dsc.mask_min = base, int(clip), gamma, eta, fmin
-        if gate_in is not None:  # per-layer predictor input: the gate is evaluated in the kernel
-            hd = gate_in[len(gate_descs)]
-            gate_descs.append(hd)
+        if hd is not None:  # per-layer predictor input: the gate is evaluated in the kernel
             dsc.gate_hidden = hd.data_ptr()
             dsc.gate_hidden_stride[:] = [hd.stride(0), hd.stride(1)]
             dsc.gate_w1, dsc.gate_b1, dsc.gate_w2, dsc.gate_b2 = gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr()
@@ -252,8 +318,7 @@ def main():
                 C.c_void_p(o.data_ptr()), None if fqd is None else C.byref(fqd))
         return args, (dsc, fqd)
 
-    gate_descs = []
-    calls = [make_call(*s) for s in sets]
+    calls = [make_call(*s_, hd=(gate_in[i] if gate_in is not None else None)) for i, s_ in enumerate(sets)]
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     fwd = lib.oeh_attn_fwd
     def step():
@@ -318,10 +383,35 @@ def main():
         graph_us = e0.elapsed_time(e1) * 1e3 / (30 * L)
     except Exception:
         graph_us = None
+    seen, shard_check = 1, None
     if dist is not None:
-        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
+        from outeffhop_amd.dist import gather_equal, max_over_ranks, ranks_seen
+
+        wall = max_over_ranks(wall, dev)
+        seen = ranks_seen(dev)  # ranks that answered a SUM all-reduce over RCCL
+        if not a.no_check:
+            # parity mode: every rank's layer-0 output travels to every rank by ONE all_gather over RCCL/xGMI; rank 0
+            # regenerates each rank's shard of the inputs, runs it on its own GPU and compares bit for bit (a sample's rows
+            # do not depend on which GPU, or which batch neighbours, they were computed with).  Outside the timed region.
+            parts = gather_equal(sets[0][3].permute(0, 2, 1, 3).contiguous())
+            if rank == 0:
+                bad, worst = [], 0.0
+                for r in range(world):
+                    (q_, k_, v_, gi_), = gen_layers(r, 1)
+                    pr = gen_pad(r)
+                    pr = None if pr is None else pr.to(dev)
+                    o_ = torch.empty(B, S, H, d, dtype=sdt, device=dev).permute(0, 2, 1, 3)
+                    hd_ = None if gi_ is None else gi_.to(dev)
+                    args_, keep_ = make_call(view(q_), view(k_), view(v_), o_, pad=pr, hd=hd_)
+                    if fwd(*args_, stream) != 0:
+                        raise RuntimeError("oeh_attn_fwd (shard check)")
+                    torch.cuda.synchronize()
+                    mine = o_.permute(0, 2, 1, 3).contiguous()
+                    if not torch.equal(mine, parts[r]):
+                        bad.append(r)
+                        worst = max(worst, float((mine.float() - parts[r].float()).abs().max()))
+                shard_check = {"ranks": world, "bitwise_equal": not bad, "mismatching_ranks": bad, "max_abs_diff": worst,
+                               "what": "layer-0 output of every rank (all_gather over RCCL) vs rank 0's own run of that rank's shard"}
 
     if rank == 0:
         launches = a.steps * L
@@ -332,16 +422,20 @@ def main():
         achieved = alg_bytes / kern_s / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):  # measured separately with rocprofv3 --pmc (see profiles/README.md); bytes per launch
+        if os.path.exists(tf):  # NOT measured in this run: bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md)
             try:
                 traffic = json.load(open(tf)).get(a.workload)
             except Exception:
                 traffic = None
+        # useful matrix flops: both products over the keys a query row may see (causal: S(S+1)/2 of the S*S pairs)
+        pairs = S * (S + 1) // 2 if w["order"] == "opt" else S * S
+        flops = 4 * B * H * pairs * d
         rec = {
             "metric": "attention tokens/sec/GPU (OPT-125m S=512 softmax1); INT8 max-abs-err vs ref",
             "value": layer_tokens / wall,
             "unit": "attention-layer tokens/s (all GPUs)",
             "n_gpus": world,
+            "rccl_ranks_seen": seen,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": wall * 1e3 / a.steps,
@@ -358,17 +452,22 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel_us": kern_s * 1e6,
+                "traffic": traffic, "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, not this run)",
+                "kernel_us": kern_s * 1e6,
                 "kernel_us_p10_p50_p90": [round(spread[4], 2), round(spread[20], 2), round(spread[36], 2)],
                 "kernel_us_hipgraph": None if graph_us is None else round(graph_us, 2),
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "flops_per_launch": 4 * B * H * S * S * d, "tflops": 4 * B * H * S * S * d / kern_s / 1e12,
+                "flops_per_launch": flops, "tflops": flops / kern_s / 1e12,
+                "flops_note": "useful flops (causal: visible query-key pairs only); reported, not the bound",
             },
         }
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(w, a.cpu_seconds)
             rec["config"]["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
             rec["cpu_baseline"]["int8_vs_reference"] = int8_check()
+            rec["cpu_baseline"]["fp16_vs_reference"] = fp16_check()
+        if shard_check is not None:
+            rec["shard_check"] = shard_check
         print(json.dumps(rec), flush=True)
     if dist is not None:
         dist.barrier()

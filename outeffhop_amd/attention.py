@@ -8,6 +8,7 @@ Reference anchors: AttentionGateType / logit  OutEffHop/transformers_language/mo
 from __future__ import annotations
 
 import math
+import weakref
 from enum import Flag
 from typing import Optional, Tuple
 
@@ -15,7 +16,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import ops
+from . import _lib, ops
 from .ops import AttnFakeQuant, SoftmaxSpec
 from .softmax import spec_of
 
@@ -184,18 +185,24 @@ def split_mask(mask: Optional[torch.Tensor], B: int, Sq: int, Sk: int):
     return None, mask.expand(B, 1, Sq, Sk)
 
 
-_causal_cache = {}
+_causal_cache = {}  # id(mask) -> (weakref to the mask tensor, its version counter, result)
 
 
 def classify_causal(mask: torch.Tensor):
     """Recognise HF's decoder mask: a (B,1,T,S) additive tensor that equals causal(finfo.min above the shifted
     diagonal) + key-padding(finfo.min columns), up to the clamp at finfo.min the attention applies anyway
-    (opt_attention.py:220-223).  Returns (True, pad_vector_or_None) or (False, None).  One pass over the mask per
-    distinct tensor - HF hands the same tensor to every layer - cached on identity."""
-    key = (mask.data_ptr(), tuple(mask.shape), mask._version, mask.dtype)
+    (opt_attention.py:220-223).  Returns (True, pad_vector_or_None) or (False, None).
+
+    One pass over the mask per distinct tensor OBJECT: HF hands the same tensor to every layer of a forward, so the
+    result is remembered - keyed on the identity of the live object (a weak reference that must still point at
+    `mask`) and its version counter, never on its address: the caching allocator gives the next batch's mask the
+    same address, and a result remembered by address would apply the previous batch's padding to it."""
+    key = id(mask)
     hit = _causal_cache.get(key)
     if hit is not None:
-        return hit
+        if hit[0]() is mask and hit[1] == mask._version:
+            return hit[2]
+        del _causal_cache[key]
     B, _, T, S = mask.shape
     fmin = torch.finfo(mask.dtype).min
     causal = torch.full((T, S), fmin, dtype=mask.dtype, device=mask.device).triu(1 + S - T)
@@ -203,9 +210,16 @@ def classify_causal(mask: torch.Tensor):
     recon = (causal[None, None] + pad[:, None, None, :]).clamp(min=fmin)
     ok = bool(torch.equal(mask.clamp(min=fmin), recon)) and bool(((pad == 0) | (pad == fmin)).all())
     res = (True, (pad.contiguous() if bool((pad != 0).any()) else None)) if ok else (False, None)
+
+    def _forget(dead, _k=key):  # the mask object is gone: its id may be reused by any other object
+        ent = _causal_cache.get(_k)
+        if ent is not None and ent[0] is dead:
+            del _causal_cache[_k]
+
+    ref = weakref.ref(mask, _forget)
     if len(_causal_cache) > 64:
         _causal_cache.clear()
-    _causal_cache[key] = res
+    _causal_cache[key] = (ref, mask._version, res)
     return res
 
 
@@ -235,11 +249,13 @@ def attention_core(
     out = None
     if gate_mlp is not None:
         units = 0 if gate_mlp.w1.dim() == 2 else gate_mlp.w1.shape[1]
-        if full is None and ops.fused_gate_ok(B, H, Sq, Sk, D, q.dtype, clip=bool(spec.clip), fq=fq is not None, units=units):
+        if full is None and ops.fused_gate_ok(B, H, Sq, Sk, D, q.dtype, clip=bool(spec.clip), fq=fq is not None, units=units,
+                                              base=spec.base, gamma=spec.gamma, key_pad=pad is not None, causal=causal,
+                                              scale=scale, scale_div=scale_div, mask_min=mask_min):
             try:
                 out = ops.attn_fwd(q, k, v, gate_mlp=gate_mlp, **kw)
-            except _lib.OehError as e:  # a mask / option combination the full-row kernel does not take after all
-                if e.code != -95:
+            except _lib.OehError as e:  # an option combination the 16-bit MFMA kernels do not take after all (alignment ...)
+                if e.code not in (-95, -14):
                     raise
         if out is None:
             gp = gate_mlp
@@ -291,7 +307,3 @@ def unfused_core(
     if head_mask is not None:
         used = used * head_mask
     return torch.matmul(used, v), probs, used
-
-
-def default_scale(d: int) -> float:
-    return 1.0 / math.sqrt(d)

@@ -5,7 +5,11 @@ the max-over-ranks of the wall time and, in parity mode, one all_gather of the p
 """
 from __future__ import annotations
 
-from typing import Callable, List, Sequence, Tuple
+import os
+import socket
+import subprocess
+import sys
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -57,3 +61,42 @@ def run_sharded(fn: Callable[..., torch.Tensor], tensors: Sequence[torch.Tensor]
     world, rank = dist.get_world_size(), dist.get_rank()
     out = fn(*shard(tensors, world, rank))
     return gather_batch(out, tensors[0].shape[0]) if gather else out
+
+
+def ranks_seen(device=None) -> int:
+    """How many ranks take part in the job, counted by a SUM all-reduce of ones over the process group's transport
+    (RCCL over xGMI under "nccl"): the bench reports it so that an N-GPU line is backed by N ranks that really
+    answered a collective, not by an environment variable."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    t = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def gather_equal(local: torch.Tensor) -> List[torch.Tensor]:
+    """all_gather of same-shaped per-rank tensors (weak scaling: every rank holds B_local samples); parity mode only."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [local]
+    parts = [torch.empty_like(local) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, local.contiguous())
+    return parts
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def launch_ranks(script: str, nproc: int, argv: Sequence[str], env: Optional[dict] = None, timeout: Optional[float] = None) -> int:
+    """Start `script` as `nproc` ranks of one node (one process per GPU) through `python -m torch.distributed.run` in a
+    CHILD process and return its exit code; the child's stdout / stderr are the caller's.  Must be called before the
+    calling process has initialised the GPU (it never does here: the caller only parses arguments) - a process that
+    has touched the GPU must not be replaced by, or fork into, GPU work on this pool.  Rendezvous on 127.0.0.1."""
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    e.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(nproc)}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script, *argv]
+    return subprocess.run(cmd, env=e, timeout=timeout).returncode

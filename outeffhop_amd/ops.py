@@ -5,7 +5,6 @@ liboeh_hip.so; tensors that are not on a GPU are an error (there is no CPU path 
 from __future__ import annotations
 
 import ctypes as C
-import math
 from dataclasses import dataclass
 from typing import Optional
 
@@ -56,9 +55,39 @@ class AttnFakeQuant:
 
 
 def _need_gpu(*ts):
+    """Every tensor on ONE GPU, and none of them part of an autograd graph being recorded: the library is the only
+    implementation (no CPU path) and it is forward-only - its outputs carry no grad_fn, so running it under autograd
+    would drop the gradients of q / k / v / gate silently.  Raise instead (inference: `with torch.no_grad():`)."""
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise _lib.OehError("outeffhop_amd ops need GPU tensors: the HIP library is the only implementation")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise _lib.OehError(f"outeffhop_amd ops need all tensors on one GPU, got {dev} and {t.device}")
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
+        raise _lib.OehError("outeffhop_amd is forward-only (the backward pass is out of scope, DESIGN.md section 7): an input requires "
+                            "grad while autograd is recording - run inference under torch.no_grad() / torch.inference_mode()")
+    return dev
+
+
+class _on_device:
+    """Make the tensors' GPU the current HIP device for the launch (kernels run on the stream of the CURRENT device)."""
+
+    def __init__(self, dev):
+        self.dev, self.prev = dev, None
+
+    def __enter__(self):
+        if self.dev is not None and self.dev.index is not None and self.dev.index != torch.cuda.current_device():
+            self.prev = torch.cuda.current_device()
+            torch.cuda.set_device(self.dev)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # the handle without building a Stream object (9 us -> 0.5 us)
@@ -110,7 +139,7 @@ def attn_fwd(
 
     key_pad_mask: additive (B,Sk) [or anything reshapeable to it, e.g. HF's (B,1,1,Sk)];
     full_mask: additive (B,1,Sq,Sk); gate: fp32, broadcastable to (B,H,Sq,1), already times the scaling factor."""
-    _need_gpu(q, k, v, key_pad_mask, full_mask, gate, out)
+    dev = _need_gpu(q, k, v, key_pad_mask, full_mask, gate, out)
     if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
         raise ValueError("q, k, v must be 4-D (B,H,S,D) views")
     B, H, Sq, D = q.shape
@@ -193,7 +222,8 @@ def attn_fwd(
         args = (C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), None if fqd is None else C.byref(fqd))
         _prepared.extend([lib.oeh_attn_fwd, args, (d, fqd, keep, q, k, v, out)])
         return out
-    rc = lib.oeh_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), None if fqd is None else C.byref(fqd), _stream())
+    with _on_device(dev):
+        rc = lib.oeh_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), None if fqd is None else C.byref(fqd), _stream())
     _lib.check(rc, "oeh_attn_fwd")
     return out
 
@@ -212,11 +242,13 @@ class GatePredictor:
     out: Optional[torch.Tensor] = None
 
 
-def fused_gate_ok(B, H, Sq, Sk, D, dtype, clip: bool = False, fq: bool = False, units: int = 0) -> bool:
-    """True when `attn_fwd(..., gate_mlp=...)` is supported for this problem (else: `gate_fwd` + `gate=`)."""
+def fused_gate_ok(B, H, Sq, Sk, D, dtype, clip: bool = False, fq: bool = False, units: int = 0, **problem) -> bool:
+    """True when `attn_fwd(..., gate_mlp=...)` is supported for this problem (else: `gate_fwd` + `gate=`).  `problem`: the
+    remaining descriptor fields that decide the kernel variant (`attn_variant`'s keywords: base, gamma, key_pad, causal,
+    scale, scale_div, mask_min) - the probe must describe the real call, not a default one."""
     if dtype not in (torch.float16, torch.bfloat16) or fq or int(units) > 16:
         return False
-    v = attn_variant(B, H, Sq, Sk, D, dtype, clip=clip)
+    v = attn_variant(B, H, Sq, Sk, D, dtype, clip=clip, **problem)
     return v is not None and (v.startswith("fast16/") or v.startswith("flash16/"))
 
 
@@ -235,13 +267,20 @@ class PreparedAttn:
             _lib.check(rc, "oeh_attn_fwd")
 
 
-def attn_variant(B, H, Sq, Sk, D, dtype=torch.float16, fq: bool = False, clip: bool = False) -> Optional[str]:
-    """Name of the kernel variant the library would pick (host only; no GPU needed)."""
+def attn_variant(B, H, Sq, Sk, D, dtype=torch.float16, fq: bool = False, clip: bool = False, *, base: int = 1, gamma: float = -0.025,
+                 key_pad: bool = False, full_mask: bool = False, causal: bool = False, scale: float = 1.0, scale_div: float = 0.0,
+                 mask_min: Optional[float] = None) -> Optional[str]:
+    """Name of the kernel variant the library would pick for this problem (host only; no GPU needed)."""
     d = oeh_attn_desc()
     d.B, d.H, d.Sq, d.Sk, d.D, d.dtype = B, H, Sq, Sk, D, _DT[dtype]
-    d.scale, d.mask_min = 1.0, float(torch.finfo(torch.float32).min)
+    d.scale, d.scale_div = float(scale), float(scale_div)
+    d.mask_min = float(torch.finfo(torch.float32).min if mask_min is None else mask_min)
+    d.softmax_base, d.causal = int(base), int(bool(causal))
+    # only nullness of the mask pointers matters to the selection (host only: nothing is dereferenced)
+    d.key_pad_mask, d.key_pad_dtype = (1 if key_pad else None), OEH_F32
+    d.full_mask, d.full_mask_dtype = (1 if full_mask else None), OEH_F32
     if clip:
-        d.clip, d.gamma, d.eta = 1, -0.025, 1.0
+        d.clip, d.gamma, d.eta = 1, float(gamma), 1.0
     fqd = None
     if fq:
         fqd = oeh_fq_desc()
@@ -253,7 +292,7 @@ def attn_variant(B, H, Sq, Sk, D, dtype=torch.float16, fq: bool = False, clip: b
 
 def softmax_rows(x: torch.Tensor, spec: SoftmaxSpec = SoftmaxSpec(), dim: int = -1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """SOFTMAX_MAPPING callable on the GPU: softmax / softmax_1 / clipped variants along `dim`."""
-    _need_gpu(x, out)
+    dev = _need_gpu(x, out)
     if x.dtype not in _DT:
         raise ValueError(f"unsupported dtype {x.dtype}")
     nd = x.dim()
@@ -264,21 +303,23 @@ def softmax_rows(x: torch.Tensor, spec: SoftmaxSpec = SoftmaxSpec(), dim: int = 
     cols = xc.shape[-1]
     rows = xc.numel() // max(cols, 1)
     if xc.numel():
-        rc = _lib.load().oeh_softmax_rows(_ptr(xc), _ptr(y), rows, cols, _DT[x.dtype], int(spec.base), int(bool(spec.clip)),
-                                          float(spec.gamma), float(spec.eta), _stream())
+        with _on_device(dev):
+            rc = _lib.load().oeh_softmax_rows(_ptr(xc), _ptr(y), rows, cols, _DT[x.dtype], int(spec.base), int(bool(spec.clip)),
+                                              float(spec.gamma), float(spec.eta), _stream())
         _lib.check(rc, "oeh_softmax_rows")
     return y if dim == nd - 1 else y.transpose(dim, -1)
 
 
 def fake_quant(x: torch.Tensor, spec: FakeQuantSpec, want_idx: bool = False):
     """Fixed-range per-tensor asymmetric fake-quant; returns x_q (and the uint8 indices if asked)."""
-    _need_gpu(x)
+    dev = _need_gpu(x)
     if x.dtype not in _DT:
         raise ValueError(f"unsupported dtype {x.dtype}")
     xc = x.contiguous()
     y = torch.empty_like(xc)
     idx = torch.empty(xc.shape, dtype=torch.uint8, device=x.device) if want_idx else None
-    rc = _lib.load().oeh_fake_quant(_ptr(xc), _ptr(y), _ptr(idx), xc.numel(), _DT[x.dtype], spec.scale, spec.zero_point, spec.qmax, _stream())
+    with _on_device(dev):
+        rc = _lib.load().oeh_fake_quant(_ptr(xc), _ptr(y), _ptr(idx), xc.numel(), _DT[x.dtype], spec.scale, spec.zero_point, spec.qmax, _stream())
     _lib.check(rc, "oeh_fake_quant")
     return (y, idx) if want_idx else y
 
@@ -287,7 +328,7 @@ def gate_fwd(hidden: torch.Tensor, H: int, w1: torch.Tensor, b1: torch.Tensor, w
              b2: Optional[torch.Tensor] = None, per_head_pool: bool = False, scaling: float = 1.0) -> torch.Tensor:
     """Per-head gate predictors on the module input (bert_attention.py:301-327).  hidden (B,T,H*d);
     w1 (H,d)|(H,m,d), b1 (H)|(H,m), w2 (H,m), b2 (H).  Returns sigmoid(logit)*scaling as (B,H,T,1) or (B,H,1,1) fp32."""
-    _need_gpu(hidden, w1, b1, w2, b2)
+    dev = _need_gpu(hidden, w1, b1, w2, b2)
     B, T, E = hidden.shape
     d = E // H
     hc = hidden if hidden.stride(2) == 1 else hidden.contiguous()
@@ -295,20 +336,19 @@ def gate_fwd(hidden: torch.Tensor, H: int, w1: torch.Tensor, b1: torch.Tensor, w
     f = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()  # noqa: E731
     w1, b1, w2, b2 = f(w1), f(b1), f(w2), f(b2)
     out = torch.empty((B, H, T), dtype=torch.float32, device=hidden.device)
-    rc = _lib.load().oeh_gate_fwd(_ptr(hc), _DT[hidden.dtype], B, T, H, d, hc.stride(0), hc.stride(1), _ptr(w1), _ptr(b1), _ptr(w2),
-                                  _ptr(b2), m_units, int(per_head_pool), float(scaling), _ptr(out), _stream())
+    with _on_device(dev):
+        rc = _lib.load().oeh_gate_fwd(_ptr(hc), _DT[hidden.dtype], B, T, H, d, hc.stride(0), hc.stride(1), _ptr(w1), _ptr(b1), _ptr(w2),
+                                      _ptr(b2), m_units, int(per_head_pool), float(scaling), _ptr(out), _stream())
     _lib.check(rc, "oeh_gate_fwd")
     return out[:, :, :1, None] if per_head_pool else out[..., None]
 
 
 def minmax(x: torch.Tensor) -> torch.Tensor:
     """(min, max) of a tensor as a 2-element fp32 GPU tensor, no host round trip (range_estimators.py:96-97)."""
-    _need_gpu(x)
+    dev = _need_gpu(x)
     xc = x.contiguous()
     out = torch.empty(2, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().oeh_minmax(_ptr(xc), xc.numel(), _DT[x.dtype], _ptr(out), _stream()), "oeh_minmax")
+    with _on_device(dev):
+        rc = _lib.load().oeh_minmax(_ptr(xc), xc.numel(), _DT[x.dtype], _ptr(out), _stream())
+    _lib.check(rc, "oeh_minmax")
     return out
-
-
-def sdpa_scale(d: int) -> float:
-    return 1.0 / math.sqrt(d)

@@ -452,6 +452,13 @@ class QuantizedModule(nn.Module):
         self.cached_params = None
         return super()._apply(*args, **kwargs)
 
+    def _load_from_state_dict(self, *args, **kwargs):
+        # a quantised checkpoint carries `_quant_a` / `_quant_w` = True: the host copies must follow the loaded buffers,
+        # or the module would silently run in full precision (one device read per load, none per forward)
+        super()._load_from_state_dict(*args, **kwargs)
+        self.cached_params = None
+        self._qa, self._qw = bool(self._quant_a.item()), bool(self._quant_w.item())
+
     def extra_repr(self):
         return f"weight_quant={self._qw}, act_quant={self._qa}"
 

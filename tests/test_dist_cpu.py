@@ -47,3 +47,37 @@ def _worker(rank, world, port, B):
 def test_two_rank_gloo(B):
     port = 29500 + (os.getpid() % 1000) + B
     mp.spawn(_worker, args=(2, port, B), nprocs=2, join=True)
+
+
+def test_launch_ranks_starts_one_process_per_rank(tmp_path):
+    """`python bench.py --gpus N` starts its own N ranks through outeffhop_amd.dist.launch_ranks (it used
+    to fall through to a 1-GPU measurement).  Here: 2 ranks on CPU/gloo, rendezvous on 127.0.0.1."""
+    import json
+    import sys
+
+    from outeffhop_amd.dist import launch_ranks
+
+    out = tmp_path / "seen.json"
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dist_child.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    rc = launch_ranks(child, 2, [str(out)], env=env, timeout=300)
+    assert rc == 0
+    got = json.loads(out.read_text())
+    assert got == {"world": 2, "seen": 2, "wall": 11.0, "parts": [0.0, 1.0], "master": "127.0.0.1"}
+
+
+def test_bench_refuses_an_n_gpu_line_it_cannot_measure():
+    """No launcher, fewer GPUs than asked: exit code 2 and no JSON line (never `n_gpus: 1` for `--gpus 8`); a launcher
+    whose WORLD_SIZE disagrees with --gpus is refused too."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("8 GPUs visible: the request would be served")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr and "n_gpus" not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env={**env, "WORLD_SIZE": "2", "RANK": "0"},
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr and "n_gpus" not in r.stdout

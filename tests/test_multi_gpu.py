@@ -1,0 +1,28 @@
+"""Two ranks over RCCL ("nccl") on a box with >= 2 GPUs: the bench's own launcher, its shard-parity check (all_gather of the
+ranks' outputs, each compared bit for bit with rank 0's run of that shard) and `rccl_ranks_seen`.  Skipped on the 1-GPU
+boxes the round's `-m gpu` run uses; the same plumbing runs on gloo in tests/test_dist_cpu.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("workload", ["opt_softmax1", "bert_gated"])
+def test_bench_two_ranks_over_rccl(workload):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks_seen"] == 2 and rec["scaling"] == "weak"
+    assert rec["shard_check"]["ranks"] == 2 and rec["shard_check"]["bitwise_equal"], rec["shard_check"]
