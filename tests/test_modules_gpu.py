@@ -307,12 +307,23 @@ def test_fused_qkv_projection_matches_three_linears(oa):
         assert torch.isfinite(m(x, attention_mask=mask)[0]).all()
 
 
-def _decoder_mask(B, T, lens, dtype, dev):
+def _decoder_mask(B, T, lens, dtype, dev, at=None):
+    """HF's decoder mask (causal + right padding), as a NEW tensor; `at`: try to have the caching allocator place it at this
+    address (the block the previous batch's mask has just given back) - candidates that land elsewhere are held until one fits."""
     fmin = torch.finfo(dtype).min
     m = torch.full((T, T), fmin, dtype=dtype, device=dev).triu(1)[None, None].repeat(B, 1, 1, 1)
     for b, n in enumerate(lens):
         m[b, :, :, n:] = fmin
-    return m
+    if at is None:
+        return m.clone()
+    held = []
+    for _ in range(256):
+        cand = torch.empty_like(m)
+        if cand.data_ptr() == at:
+            break
+        held.append(cand)
+    cand.copy_(m)
+    return cand
 
 
 @pytest.mark.parametrize("quantised", [False, True])
@@ -345,7 +356,7 @@ def test_opt_consecutive_batches_with_different_padding(oa, quantised):
     for trial in range(6):
         lens = [T - 7 * ((trial + 2 * b) % 5) for b in range(B)]
         x = torch.randn(B, T, 128, device=dev)
-        mask = _decoder_mask(B, T, lens, torch.float32, dev)
+        mask = _decoder_mask(B, T, lens, torch.float32, dev, at=addr)
         same_addr += int(mask.data_ptr() == addr)
         addr = mask.data_ptr()
         with torch.no_grad():
