@@ -34,6 +34,9 @@ namespace {
 bool dtype_ok(int d) { return d == OEH_F16 || d == OEH_BF16 || d == OEH_F32; }
 int elem_bytes(int d) { return d == OEH_F32 ? 4 : 2; }
 
+// RN(scale * log2(e)), the product formed in double
+float scale_log2e(float scale) { return (float)((double)scale * 1.4426950408889634074); }
+
 FqP make_fq(const oeh_fq* f) {
   FqP r;
   std::memset(&r, 0, sizeof(r));
@@ -46,6 +49,7 @@ FqP make_fq(const oeh_fq* f) {
     r.lo = -f->zero_point;
     r.hi = f->qmax - f->zero_point;
     r.dump = f->dump_idx;
+    r.c2 = scale_log2e(f->scale);
   }
   return r;
 }
@@ -294,6 +298,7 @@ int oeh_fake_quant(const void* x, void* y, uint8_t* idx, int64_t n, int32_t dtyp
   std::memset(&f, 0, sizeof(f));
   f.en = 1; f.scale = scale; f.rscale = 1.0f / scale; f.zp = zero_point; f.qmax = qmax;
   f.lo = -zero_point; f.hi = qmax - zero_point;
+  f.c2 = scale_log2e(scale);
   return oeh::launch_fake_quant(x, y, idx, n, dtype, f, reinterpret_cast<hipStream_t>(stream));
 }
 

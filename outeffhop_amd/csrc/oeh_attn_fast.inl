@@ -39,8 +39,10 @@ __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
 }
 
 // waves per SIMD the register allocator must leave room for: 3 at NT=32 (<= 168 VGPRs), LDS allows 3 workgroups (50 KB each)
-template <int NT, int D>
-constexpr int fast_occupancy() { return D >= 128 ? 1 : 3; }  // what the LDS rings allow (6 tiles of 64 x 2D bytes)
+template <int NT, int D, bool SRC32>
+constexpr int fast_occupancy() {  // what the LDS rings allow (6 tiles of 64 x 2D bytes); the fp32 forms of the 512-key kernel
+  return D >= 128 ? 1 : ((SRC32 && NT >= 32) ? 2 : 3);  // carry hi+lo operands and the staged tile: 2 waves per SIMD, no spills
+}
 
 // GATE: the conditional per-token gate (include/oeh.h: gate_hidden ...) is computed in the kernel.  The layer-input rows
 // of the workgroup arrive as one more K-shaped LDS-DMA tile; the first predictor layer is ONE small product on the matrix
@@ -48,20 +50,26 @@ constexpr int fast_occupancy() { return D >= 128 ? 1 : 3; }  // what the LDS rin
 // registers), with the weights rounded to the storage dtype - what the reference's Linear does in a 16-bit model; the
 // second layer, the sigmoid and the scaling are a few VALU operations per lane and one register carries the result to the
 // epilogue.  A separate variant: the others carry none of it.
-// FQ: the fused fake-quantisers (scores / probabilities / context).  The per-element chain is then the reference's op
+// FQ: the fused fake-quantisers (scores / probabilities / context); two forms, separate variants because a kernel that holds
+// both allocates registers for the union (143 spilled).  FQ == 1: no key padding, no clipping (OPT) - the chain runs on the
+// quantiser grid (see phase 2).  FQ == 2: the per-element chain is the reference's op
 // order literally - scale, quantise, masks added (not substituted), x - m, 1-ulp exp, normalise, [clip], quantise - as in
 // the general kernel (oeh_attn_mfma.inl), on this kernel's data path.  The variant is compiled for the reference's
 // configuration, scores AND probabilities quantised (context optional): a run-time test per quantiser and per four elements
 // costs a branch and, at the join, register copies (1.5 VALU per element for the clip alone).  Other subsets, and the
 // test-only uint8 index dumps (a uniform branch per four elements per quantiser even when off): general kernel.
 // SRC32: fp32 storage read directly, as in the one-pass kernel (oeh_attn_flash.inl): the K-then-V tile stream comes
-// through registers (32 B of fp32 per lane and piece, rounded to fp16, written to the LDS image the DMA would produce), one
-// tile ahead - committed at the top of an iteration, the next tile's loads issued right after the barrier.
-template <int NT, int D, int IN, bool CLIP, bool GATE, bool FQ = false, bool SRC32 = false>
-__global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_kernel(const AttnParams P) {
-  static_assert(!SRC32 || (!GATE && IN == IN_F16), "fp32 storage: fp16 operands, fp32 output, no in-kernel gate predictor");
+// through registers (32 B of fp32 per lane and piece), one tile ahead - committed at the top of an iteration, the next tile's
+// loads issued right after the barrier - and is written to LDS as TWO fp16 images (hi, lo: oeh_common.h split8) in the layout
+// the DMA would produce; every product is accumulated from the operand pairs (3 MFMAs per score k-step, 2 per context k-step),
+// i.e. with fp32 accuracy.  Two ring slots shared by the K-then-V stream (a slot's readers are all behind the barrier that
+// precedes its next commit); Q goes global -> registers directly.
+template <int NT, int D, int IN, bool CLIP, bool GATE, int FQ = 0, bool SRC32 = false>
+__global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_attn_fast_kernel(const AttnParams P) {
+  static_assert(!SRC32 || (!GATE && IN == IN_F16), "fp32 storage: fp16 operand pairs, fp32 output, no in-kernel gate predictor");
   constexpr bool OUT32 = SRC32;
   static_assert(!FQ || !GATE, "the fake-quant variant has no in-kernel gate predictor");
+  static_assert(FQ != 1 || !CLIP, "FQ == 1 (the chain on the quantiser grid) is the unclipped form");
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
   constexpr int KT = NT / 4;
   constexpr int ROWB = 2 * D;
@@ -74,8 +82,10 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
   constexpr int R = 3;                // slots per ring (K ring, V ring)
   constexpr float NEG = -3.0e38f;
 
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * R * TILEB + NT * 16 * 4];
-  float* lds_pad = reinterpret_cast<float*>(lds + 2 * R * TILEB);
+  constexpr int SLOT32 = 2 * TILEB;   // SRC32: one ring slot = hi image + lo image
+  constexpr int RINGB = SRC32 ? 2 * SLOT32 : 2 * R * TILEB;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RINGB + NT * 16 * 4];
+  float* lds_pad = reinterpret_cast<float*>(lds + RINGB);
 
   const int bid = blockIdx.x;
   const int qt_rev = bid / P.nBHpad;
@@ -155,7 +165,6 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
   // after the operands below are in registers): the bytes in front of the first MFMA are Q + K tile 0, requested together,
   // instead of a register load of Q that had to land before the first transfer could even be issued.
   f4 treg[SRC32 ? G : 1][2];  // SRC32: the staged tile
-  auto cvt8 = [](const f4 lo, const f4 hi) { return u4{pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]), pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3])}; };
   auto load_tile = [&](const int i) {  // tile i of the K-then-V stream -> registers
     if constexpr (SRC32) {
       const bool isv = i >= n_kt;
@@ -174,26 +183,25 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
       }
     }
   };
-  auto commit_tile = [&](const int ring_slot) {  // registers -> ring slot (0..R-1 K ring, R..2R-1 V ring)
+  auto commit_tile = [&](const int slot) {  // registers -> ring slot (stream tile i -> slot i & 1), split into the two images
     if constexpr (SRC32) {
-      unsigned char* base = lds + ring_slot * TILEB + (wave * G) * 1024 + lane * 16;
+      unsigned char* base = lds + slot * SLOT32 + (wave * G) * 1024 + lane * 16;
 #pragma unroll
-      for (int j = 0; j < G; ++j) *reinterpret_cast<u4*>(base + j * 1024) = cvt8(treg[j][0], treg[j][1]);
+      for (int j = 0; j < G; ++j) {
+        u4 hi, lo;
+        split8(treg[j][0], treg[j][1], hi, lo);
+        *reinterpret_cast<u4*>(base + j * 1024) = hi;
+        *reinterpret_cast<u4*>(base + TILEB + j * 1024) = lo;
+      }
     }
   };
-  if constexpr (SRC32) {  // Q: the LDS image the DMA would write (a K-shaped tile in V ring slot R-1)
-    const float* qsrc = reinterpret_cast<const float*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h;
-    unsigned char* qdst = lds + (2 * R - 1) * TILEB + (wave * G) * 1024 + lane * 16;
+  u4 qf[KS], ql[SRC32 ? KS : 1];  // Q^T operands of this lane's query row (SRC32: the hi / lo pair)
+  if constexpr (SRC32) {  // Q: global -> registers in the operand layout (row q0 + c, elements 32 ks + 8 g ..), no LDS round trip
+    const int qr = min(qrow, P.Sq - 1);  // rows past Sq: finite data, never stored
+    const float* qp = reinterpret_cast<const float*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h + (long)qr * P.qs_s + 8 * g;
 #pragma unroll
-    for (int j = 0; j < G; ++j) {
-      const int row = piece_row(j);
-      int qr = qt * 64 + row;
-      qr = qr < P.Sq ? qr : P.Sq - 1;
-      const float* qp = qsrc + (long)qr * P.qs_s + (pch ^ swz_k<D>(row)) * 8;
-      const f4 lo = __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp));
-      const f4 hi = __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp + 4));
-      *reinterpret_cast<u4*>(qdst + j * 1024) = cvt8(lo, hi);
-    }
+    for (int ks = 0; ks < KS; ++ks)
+      split8(__builtin_nontemporal_load(reinterpret_cast<const f4*>(qp + 32 * ks)), __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp + 32 * ks + 4)), qf[ks], ql[ks]);
     load_tile(0);
   } else {
     const unsigned short* qbase = reinterpret_cast<const unsigned short*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h;
@@ -257,9 +265,10 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
   const unsigned char* kaddr[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) kaddr[ks] = lds + c * ROWB + (((ks * 4 + g) ^ swz_k<D>(c)) << 4);  // swz_k(16*sub + c) == swz_k(c)
-  u4 qf[KS];
+  if constexpr (!SRC32) {
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u4*>(kaddr[ks] + (2 * R - 1) * TILEB + wave * 16 * ROWB);
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u4*>(kaddr[ks] + (2 * R - 1) * TILEB + wave * 16 * ROWB);
+  }
   float gate_row = 1.0f;  // GATE: sigmoid(logit) * scaling of this lane's query row
   if constexpr (GATE) {
     f4 acc = f4{0.f, 0.f, 0.f, 0.f};
@@ -304,23 +313,36 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
     if (kt < n_kt) {
       const int i = kt;
       if constexpr (SRC32) {
-        commit_tile(kt % R);                       // tile i (loaded an iteration ago) -> its K ring slot; last reader: tile i-3
+        commit_tile(kt & 1);                       // tile i (loaded an iteration ago) -> its ring slot; last readers: tile i-2, behind the previous barrier
         barrier_mem();
-        // lands while tile i is computed.  D < 128: V tile 0 is requested only after the softmax phase - staged through it,
-        // it would cost the 512-key forms a wave per SIMD (INT8 fp32 52 -> 46 us, clip 37.9 -> 34.4 us with the request deferred)
-        if (i + 1 < (D < 128 ? n_kt : T)) load_tile(i + 1);
+        if (i + 1 < T) load_tile(i + 1);           // lands while tile i is computed (after the last K tile: V tile 0, awaited after the softmax phase)
       } else {
       wait_tiles_in_flight<G>(min(1, T - 1 - i));  // tile i landed; tile i+1 may still be in flight
       barrier_mem();
       OEH_STAMP(2 + kt);
       if (i + 2 < T) issue_next();                 // stream tile i+2, into the slot every wave finished reading one iteration ago
       }
+      const int koff = SRC32 ? (kt & 1) * SLOT32 : (kt % R) * TILEB;  // compile-time after unrolling
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
         f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (SRC32) {
+          f4 accx = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          acc = mfma16<IN>(*reinterpret_cast<const u4*>(kaddr[ks] + (kt % R) * TILEB + sub * 16 * ROWB), qf[ks], acc);
+          for (int ks = 0; ks < KS; ++ks) {
+            const u4 kh = *reinterpret_cast<const u4*>(kaddr[ks] + koff + sub * 16 * ROWB);
+            const u4 kl = *reinterpret_cast<const u4*>(kaddr[ks] + koff + TILEB + sub * 16 * ROWB);
+            acc = mfma16<IN>(kh, qf[ks], acc);
+            accx = mfma16<IN>(kh, ql[ks], accx);
+            accx = mfma16<IN>(kl, qf[ks], accx);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(accx[r], kSplitDown, acc[r]);
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+            acc = mfma16<IN>(*reinterpret_cast<const u4*>(kaddr[ks] + koff + sub * 16 * ROWB), qf[ks], acc);
+        }
         s[kt * 4 + sub] = acc;
       }
     }
@@ -340,6 +362,89 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
     const int klimc = qrow + off;                                          // last key a causal row may see
     const int kt_causal = causal ? (max(0, q0 + off + 1) >> 6) : KT;       // first 64-key tile with a key the wave's first row must not see
     const int kt_tail = Sk >> 6;                                           // first 64-key tile with a key >= Sk
+    if constexpr (FQ == 1) {
+      // ---- the chain on the quantiser GRID (no key padding, no clipping: OPT's configuration).  Once a score is on its
+      // grid only the integer rel = idx - zp matters: the row maximum is scale * max(rel), x - m is scale * (rel - rel_max)
+      // - formed here without the reference's two roundings of scale * rel - and exp(x - m) = exp2((rel - rel_max) * c2)
+      // needs no range reduction: the argument's rounding error is 2^-24 |t|, i.e. below one ulp of the result wherever the
+      // probability is not negligible.  The score that reaches the quantiser is a matrix-core dot product (its summation
+      // order differs from the reference's bmm by more than an ulp anyway), so the quotient is one multiply by RN(sc / scale)
+      // and the probability's index comes from e * RN(1 / (den scale_p)): ~2 ulp in front of rint() instead of 1.5, twelve
+      // vector operations per score element instead of twenty-five.  A key the row must not see carries RELMASK: its
+      // exponential is exactly 0, as in the reference (a causal row always sees key 0, so the row maximum is a real score).
+      constexpr float RELMASK = -1.0e30f;
+      const float k1 = sc * P.fq_s.rscale, slo = P.fq_s.lo, shi = P.fq_s.hi;
+      const int klime = causal ? min(klimc, Sk - 1) : Sk - 1;                 // last key of this lane's row
+      float mr = RELMASK;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        if (kt < n_kt) {
+          const bool open_tile = kt < kt_causal && kt < kt_tail;               // no mask touches this 64-key tile (wave-uniform)
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub) {
+            const int t = kt * 4 + sub;
+            const int key0 = 16 * t + 4 * g;
+            f4 rel;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rel[r] = __builtin_amdgcn_fmed3f(__builtin_rintf(s[t][r] * k1), slo, shi);
+            if (!open_tile) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (key0 + r > klime) rel[r] = RELMASK;
+            }
+            s[t] = rel;
+            mr = __builtin_fmaxf(__builtin_fmaxf(mr, __builtin_fmaxf(rel[0], rel[1])), __builtin_fmaxf(rel[2], rel[3]));
+          }
+        }
+      }
+      mr = __builtin_fmaxf(mr, __shfl_xor(mr, 16));
+      mr = __builtin_fmaxf(mr, __shfl_xor(mr, 32));
+      m = mr * P.fq_s.scale;                                                  // the reference's row maximum, fl(scale * rel_max)
+      const float c2 = P.fq_s.c2;
+      f4 sum4 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        if (kt < n_kt) {
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub) {
+            const int t = kt * 4 + sub;
+            f4 e;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float d = s[t][r] - mr;
+              e[r] = __builtin_amdgcn_exp2f(d * c2);
+            }
+            s[t] = e;
+            sum4 = sum4 + e;
+          }
+        }
+      }
+      float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      float den = sum;
+      if (P.base != 0) den = sum + exp_acc(m * -1.0f);                       // softmax_1: + 1*exp(-max)  (softmax_1.py:18-20)
+      inv_fq = 1.0f / den;
+      const float cinv = inv_fq * P.fq_p.rscale, plo = P.fq_p.lo, phi = P.fq_p.hi;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        if (kt < n_kt) {
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub) {
+            const int t = kt * 4 + sub;
+            float pv[4];  // integer valued (idx - zp): exact in f16/bf16; the scale is applied after the product
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_fmed3f(__builtin_rintf(s[t][r] * cinv), plo, phi);
+            const unsigned lo = (IN == IN_BF16) ? pack2_bf16(pv[0], pv[1]) : pack2_f16(pv[0], pv[1]);
+            const unsigned hi = (IN == IN_BF16) ? pack2_bf16(pv[2], pv[3]) : pack2_f16(pv[2], pv[3]);
+            s[t][0] = bits_f32(lo);
+            s[t][1] = bits_f32(hi);
+          }
+        }
+      }
+    } else {
+      // ---- the reference's op order literally (key padding adds arbitrary values to the dequantised scores; the clip needs
+      // the probability itself)
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
       if (kt < n_kt && !has_pad && kt < kt_causal && kt < kt_tail) {
@@ -440,6 +545,8 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
           s[t][1] = bits_f32(hi);
         }
       }
+    }
+  
     }
   }
   float inv = inv_fq;
@@ -550,12 +657,15 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
   }
 
   }  // !FQ
-  if constexpr (SRC32 && D < 128) load_tile(n_kt);  // V tile 0
   OEH_STAMP(12);
   // =========================== phase 3: O^T = V^T P^T ===========================
-  f4 o[DT];
+  f4 o[DT], ox[SRC32 ? DT : 1];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) o[dt] = f4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (SRC32) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) ox[dt] = f4{0.f, 0.f, 0.f, 0.f};
+  }
   const int vrow = 4 * g + (c >> 2);
   const unsigned char* vaddr[DT];
 #pragma unroll
@@ -565,7 +675,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
     if (kt < n_kt) {
       const int i = n_kt + kt;
       if constexpr (SRC32) {
-        commit_tile(R + kt % R);
+        commit_tile(i & 1);
         barrier_mem();
         if (i + 1 < T) load_tile(i + 1);
       } else {
@@ -574,8 +684,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
       OEH_STAMP(13 + kt);
       if (i + 2 < T) issue_next();
       }
-      constexpr int slot_off_base = R * TILEB;
-      const int slot_off = slot_off_base + (kt % R) * TILEB;
+      const int slot_off = SRC32 ? (i & 1) * SLOT32 : R * TILEB + (kt % R) * TILEB;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int t0 = kt * 4 + 2 * u;
@@ -587,9 +696,21 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
           const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + 16 * ROWB));
           const u2 l2 = __builtin_bit_cast(u2, lo), h2 = __builtin_bit_cast(u2, hi);
           o[dt] = mfma16<IN>(u4{l2.x, l2.y, h2.x, h2.y}, pb, o[dt]);
+          if constexpr (SRC32) {  // the lo image of V
+            const s4 lol = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + TILEB));
+            const s4 hil = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + TILEB + 16 * ROWB));
+            const u2 l3 = __builtin_bit_cast(u2, lol), h3 = __builtin_bit_cast(u2, hil);
+            ox[dt] = mfma16<IN>(u4{l3.x, l3.y, h3.x, h3.y}, pb, ox[dt]);
+          }
         }
       }
     }
+  }
+  if constexpr (SRC32) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[dt][r] = __builtin_fmaf(ox[dt][r], kSplitDown, o[dt][r]);
   }
 
   OEH_STAMP(21);
@@ -669,19 +790,22 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D>())) void oeh_attn_fast_
 template <int NT, int D, int IN>
 static void launch_fast_nt_d_in(const AttnParams& P, unsigned grid, hipStream_t st) {
   const bool gate = P.gh != nullptr;
+  const bool fqon = P.fq_s.en && P.fq_p.en;
+  const bool grid_chain = fqon && !P.clip && P.pad == nullptr;  // FQ == 1
   if (P.src32) {  // fp32 storage read directly, fp32 output
     if constexpr (IN == IN_F16) {
-      const bool fqon = P.fq_s.en && P.fq_p.en;
-      if (fqon && P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, true, true>), dim3(grid), dim3(256), 0, st, P);
-      else if (fqon) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, true, true>), dim3(grid), dim3(256), 0, st, P);
-      else if (P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, false, true>), dim3(grid), dim3(256), 0, st, P);
-      else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, false, true>), dim3(grid), dim3(256), 0, st, P);
+      if (grid_chain) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 1, true>), dim3(grid), dim3(256), 0, st, P);
+      else if (fqon && P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 2, true>), dim3(grid), dim3(256), 0, st, P);
+      else if (fqon) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 2, true>), dim3(grid), dim3(256), 0, st, P);
+      else if (P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 0, true>), dim3(grid), dim3(256), 0, st, P);
+      else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 0, true>), dim3(grid), dim3(256), 0, st, P);
     }
     return;
   }
-  if (P.fq_s.en && P.fq_p.en) {
-    if (P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, true>), dim3(grid), dim3(256), 0, st, P);
-    else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, true>), dim3(grid), dim3(256), 0, st, P);
+  if (fqon) {
+    if (grid_chain) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 1>), dim3(grid), dim3(256), 0, st, P);
+    else if (P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 2>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 2>), dim3(grid), dim3(256), 0, st, P);
     return;
   }
   if (P.clip) {

@@ -37,20 +37,22 @@ __device__ __forceinline__ float row_allreduce_max(float x) {
   return __builtin_fmaxf(bits_f32(b[0]), bits_f32(b[1]));
 }
 
-template <int D, int MQ>
-constexpr int flash_occupancy() { return D >= 128 ? 1 : 3; }
+template <int D, int MQ, bool SRC32>
+constexpr int flash_occupancy() { return D >= 128 ? 1 : (SRC32 ? 2 : 3); }  // fp32 forms: operand pairs + the staged stage, 2 waves per SIMD
 
 // GATE: the conditional per-token gate is computed in the kernel exactly as in the full-row kernel (oeh_attn_fast.inl:
 // layer-input rows as K-shaped LDS-DMA tiles, first predictor layer on the matrix cores).  The input rows borrow stage 1
 // at start-up, so stage 1 of the K/V stream is issued later (with stage 2, once the gate has been formed).
 // SRC32: q, k, v and o are fp32 (the reference's validate_* scripts run fp32 models).  The tiles then come through
-// registers - 32 B of fp32 per lane and piece, rounded to fp16 and written to the SAME LDS images the DMA produces - one
-// 64-key stage ahead: the loads of stage i+1 are issued right after the barrier of tile i and committed to LDS at the top
-// of tile i+1, so they have a tile of compute to land; one barrier per tile as before.  fp16 matrix-core operands, fp32
-// accumulation and fp32 output straight from the accumulators (OUT32): the general kernel's arithmetic on fp32 storage,
-// without its full-row structure and without a conversion pre-pass (which costs more HBM time than the attention itself).
+// registers - 32 B of fp32 per lane and piece, split into the fp16 operand pair (hi, lo) of oeh_common.h: split8 and written
+// as two LDS images in the layout the DMA produces - one 64-key stage ahead: the loads of stage i+1 are issued right after
+// the barrier of tile i and committed to LDS at the top of tile i+1, so they have a tile of compute to land; one barrier
+// per tile as before, two ring slots (a slot's readers are all behind the barrier that precedes its next commit).  Scores
+// from three MFMAs per k-step (q.k = qh.kh + 2^-11 (qh.kl + ql.kh)), the context from two (P is an fp16 operand, V the pair):
+// fp32 accuracy on the scores, fp32 accumulation and fp32 output straight from the accumulators (OUT32); Q goes global ->
+// registers directly.  No conversion pre-pass (which costs more HBM time than the attention itself).
 template <int D, int IN, int MQ, bool PAD, bool GATE, bool SRC32 = false>
-__global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flash_kernel(const AttnParams P) {
+__global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_attn_flash_kernel(const AttnParams P) {
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit matrix-core operands");
   static_assert(!SRC32 || (!GATE && IN == IN_F16), "fp32 storage: fp16 operands, fp32 output, no in-kernel gate predictor");
   constexpr bool OUT32 = SRC32;
@@ -68,7 +70,8 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   constexpr float NEGT = -1.0e30f;      // exponent argument of a masked key: exp2 -> 0 exactly
   constexpr float kThr = 8.0f;          // lazy reference: P stays <= 2^8 (exact range for f16 / bf16 operands)
 
-  __shared__ __attribute__((aligned(16))) unsigned char lds[R * STAGEB];
+  constexpr int SLOT32 = 2 * STAGEB;    // SRC32: one ring slot = hi images (K, V) + lo images (K, V)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SRC32 ? 2 * SLOT32 : R * STAGEB];
   constexpr int PADROW = 1024;          // keys of the padding row kept in LDS (PAD variant)
   __shared__ __attribute__((aligned(16))) float lds_padrow[PAD ? PADROW : 4];
   __shared__ int lds_last[4];
@@ -161,7 +164,6 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   // measured start-up is paced by bytes per CU (~20 B/cycle), not by one memory latency.
   // SRC32: the register-staged stream (see the kernel comment)
   f4 kreg[SRC32 ? G : 1][2], vreg[SRC32 ? G : 1][2];
-  auto cvt8 = [](const f4 lo, const f4 hi) { return u4{pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]), pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3])}; };
   auto load_regs = [&](const int t) {
     if constexpr (SRC32) {
       const float* ksrc = reinterpret_cast<const float*>(P.k) + (long)b * P.ks_b + (long)h * P.ks_h;
@@ -181,29 +183,28 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   };
   auto commit_regs = [&](const int slot) {
     if constexpr (SRC32) {
-      unsigned char* base = lds + slot * STAGEB + (wave * G) * 1024 + lane * 16;
+      unsigned char* base = lds + slot * SLOT32 + (wave * G) * 1024 + lane * 16;
 #pragma unroll
       for (int j = 0; j < G; ++j) {
-        *reinterpret_cast<u4*>(base + j * 1024) = cvt8(kreg[j][0], kreg[j][1]);
-        *reinterpret_cast<u4*>(base + TILEB + j * 1024) = cvt8(vreg[j][0], vreg[j][1]);
+        u4 hi, lo;
+        split8(kreg[j][0], kreg[j][1], hi, lo);
+        *reinterpret_cast<u4*>(base + j * 1024) = hi;
+        *reinterpret_cast<u4*>(base + STAGEB + j * 1024) = lo;
+        split8(vreg[j][0], vreg[j][1], hi, lo);
+        *reinterpret_cast<u4*>(base + TILEB + j * 1024) = hi;
+        *reinterpret_cast<u4*>(base + STAGEB + TILEB + j * 1024) = lo;
       }
     }
   };
-  if constexpr (SRC32) {  // Q: the same LDS image the DMA would write (slab t as a K-shaped tile at t*TILEB of stage R-1)
-    const float* qsrc = reinterpret_cast<const float*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h;
-    unsigned char* qdst = lds + (R - 1) * STAGEB + (wave * G) * 1024 + lane * 16;
+  u4 qf[MQ][KS], ql[SRC32 ? MQ : 1][SRC32 ? KS : 1];  // Q^T operands per block (SRC32: the hi / lo pair)
+  if constexpr (SRC32) {  // Q: global -> registers in the operand layout (row rb[j] + c, elements 32 ks + 8 g ..)
 #pragma unroll
-    for (int t = 0; t < MQ; ++t) {
+    for (int j = 0; j < MQ; ++j) {
+      const int qr = min(rb[j] + c, Sq - 1);  // rows past Sq: finite data, never stored
+      const float* qp = reinterpret_cast<const float*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h + (long)qr * P.qs_s + 8 * g;
 #pragma unroll
-      for (int j = 0; j < G; ++j) {
-        const int row = piece_row(j);
-        int qrow = 64 * slab[t] + row;
-        qrow = qrow < Sq ? qrow : Sq - 1;
-        const float* qp = qsrc + (long)qrow * P.qs_s + (pch ^ swz_k<D>(row)) * 8;
-        const f4 lo = __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp));
-        const f4 hi = __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp + 4));
-        *reinterpret_cast<u4*>(qdst + t * TILEB + j * 1024) = cvt8(lo, hi);
-      }
+      for (int ks = 0; ks < KS; ++ks)
+        split8(__builtin_nontemporal_load(reinterpret_cast<const f4*>(qp + 32 * ks)), __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp + 32 * ks + 4)), qf[j][ks], ql[j][ks]);
     }
     load_regs(0);
   } else {
@@ -309,12 +310,13 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   for (int dt = 0; dt < DT; ++dt) vaddr[dt] = lds + TILEB + vrow * ROWB + ((dt ^ swz_v<D>(vrow)) << 5) + ((c & 3) << 3);
 
   // Q^T operands from the Q stage; read complete before the first loop barrier, after which the stage is refilled
-  u4 qf[MQ][KS];
+  if constexpr (!SRC32) {
 #pragma unroll
-  for (int j = 0; j < MQ; ++j)
+    for (int j = 0; j < MQ; ++j)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      qf[j][ks] = *reinterpret_cast<const u4*>(kaddr[ks] + (R - 1) * STAGEB + j * TILEB + wave * 16 * ROWB);
+      for (int ks = 0; ks < KS; ++ks)
+        qf[j][ks] = *reinterpret_cast<const u4*>(kaddr[ks] + (R - 1) * STAGEB + j * TILEB + wave * 16 * ROWB);
+  }
   float gate_row[MQ];  // GATE: sigmoid(logit) * scaling of this lane's query row in block j
 #pragma unroll
   for (int j = 0; j < MQ; ++j) gate_row[j] = 1.0f;
@@ -367,13 +369,17 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   // moves only when a tile maximum exceeds it by 2^8.  softmax_1's "+1" is exp2(mcneg) (= exp(-reference)).
   float mcneg[MQ];
   f4 lacc[MQ];                          // row sums of the ROUNDED P, accumulated by a ones-row MFMA (every register = l)
-  f4 o[MQ][DT];
+  f4 o[MQ][DT], ox[SRC32 ? MQ : 1][SRC32 ? DT : 1];  // ox: the V-lo part of the context (SRC32), scaled by 2^-11 at the end
 #pragma unroll
   for (int j = 0; j < MQ; ++j) {
     mcneg[j] = 0.0f;
     lacc[j] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[j][dt] = f4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (SRC32) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) ox[j][dt] = f4{0.f, 0.f, 0.f, 0.f};
+    }
   }
 
   // ---- one 64-key tile for blocks J0..MQ-1 of this wave (J0 = 1: block 0's rows end before this tile)
@@ -384,13 +390,25 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
     f4 s[MQ][4];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
-      u4 kf[KS];
+      u4 kf[KS], kl[SRC32 ? KS : 1];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const u4*>(kaddr[ks] + soff + sub * 16 * ROWB);
+      for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = *reinterpret_cast<const u4*>(kaddr[ks] + soff + sub * 16 * ROWB);
+        if constexpr (SRC32) kl[ks] = *reinterpret_cast<const u4*>(kaddr[ks] + soff + STAGEB + sub * 16 * ROWB);
+      }
 #pragma unroll
       for (int j = J0; j < MQ; ++j) {
         f4 acc = f4{0.f, 0.f, 0.f, 0.f};
         for (int ks = 0; ks < KS; ++ks) acc = mfma16<IN>(kf[ks], qf[j][ks], acc);
+        if constexpr (SRC32) {
+          f4 accx = f4{0.f, 0.f, 0.f, 0.f};
+          for (int ks = 0; ks < KS; ++ks) {
+            accx = mfma16<IN>(kf[ks], ql[j][ks], accx);
+            accx = mfma16<IN>(kl[ks], qf[j][ks], accx);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(accx[r], kSplitDown, acc[r]);
+        }
         s[j][sub] = acc;
       }
     }
@@ -471,6 +489,12 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
           for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[j][dt][r] *= alpha;
+          if constexpr (SRC32) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) ox[j][dt][r] *= alpha;
+          }
         }
       }
 #pragma unroll
@@ -507,6 +531,14 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
         const u4 va = u4{l2.x, l2.y, h2.x, h2.y};
 #pragma unroll
         for (int j = J0; j < MQ; ++j) o[j][dt] = mfma16<IN>(va, pb[j][u], o[j][dt]);
+        if constexpr (SRC32) {  // the lo image of V
+          const s4 lol = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + STAGEB));
+          const s4 hil = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + STAGEB + 16 * ROWB));
+          const u2 l3 = __builtin_bit_cast(u2, lol), h3 = __builtin_bit_cast(u2, hil);
+          const u4 vl = u4{l3.x, l3.y, h3.x, h3.y};
+#pragma unroll
+          for (int j = J0; j < MQ; ++j) ox[j][dt] = mfma16<IN>(vl, pb[j][u], ox[j][dt]);
+        }
       }
     }
   };
@@ -516,11 +548,11 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
   if constexpr (SRC32) {
     int slot_r = 0;
     for (int i = 0; i < n_kt; ++i) {
-      commit_regs(slot_r);                  // stage i (its loads were issued a tile ago) -> LDS; the slot's last reader was tile i-3
+      commit_regs(slot_r);                  // stage i (its loads were issued a tile ago) -> LDS; the slot's last readers (tile i-2) are behind the previous barrier
       barrier_mem();
       if (i + 1 < n_kt) load_regs(i + 1);   // lands while tile i is computed
-      const int soff = slot_r * STAGEB;
-      slot_r = (slot_r == R - 1) ? 0 : slot_r + 1;
+      const int soff = slot_r * SLOT32;
+      slot_r ^= 1;
       if (i >= nkb[MQ - 1]) continue;
       if (MQ == 2 && i >= nkb[0]) {
         if constexpr (MQ == 2) tile(J0_1{}, std::false_type{}, i, soff);
@@ -575,8 +607,12 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ>())) void oeh_attn_flas
       if (qrow < Sq) {
         float* orow = reinterpret_cast<float*>(P.o) + (long)b * P.os_b + (long)h * P.os_h + (long)qrow * P.os_s + 4 * ge;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-          store_wt16(orow + 16 * dt, u4{f32_bits(o[j][dt][0] * rowscale), f32_bits(o[j][dt][1] * rowscale), f32_bits(o[j][dt][2] * rowscale), f32_bits(o[j][dt][3] * rowscale)});
+        for (int dt = 0; dt < DT; ++dt) {
+          f4 ov;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ov[r] = __builtin_fmaf(ox[j][dt][r], kSplitDown, o[j][dt][r]) * rowscale;
+          store_wt16(orow + 16 * dt, u4{f32_bits(ov[0]), f32_bits(ov[1]), f32_bits(ov[2]), f32_bits(ov[3])});
+        }
       }
     } else {
 #pragma unroll

@@ -55,11 +55,13 @@ __device__ __forceinline__ void dump4(unsigned char* p, unsigned int word, int n
     if (r < nvalid) p[r] = (unsigned char)(word >> (8 * r));
 }
 
-template <int NT>
-constexpr int occupancy_hint() { return NT >= 32 ? 2 : (NT >= 16 ? 3 : 4); }
+template <int NT, int D, int IN>
+constexpr int occupancy_hint() { return (NT >= 32 || (D >= 128 && IN == IN_F32)) ? 2 : (NT >= 16 ? 3 : 4); }  // (fp32, D = 128: 64 KB of LDS)
 
-template <int NT, int D, int IN, bool FQ>
-__global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kernel(const AttnParams P) {
+// FQ: 0 none | 1 the chain on the quantiser grid (the production INT8 arithmetic of oeh_attn_fast.inl: scores and
+// probabilities quantised, multiplicative scale, no padding / full mask / clip) | 2 every other fake-quant configuration
+template <int NT, int D, int IN, int FQ>
+__global__ __launch_bounds__(256, (occupancy_hint<NT, D, IN>())) void oeh_attn_mfma_kernel(const AttnParams P) {
   constexpr int KT = NT / 4;            // 64-key LDS tiles
   constexpr int ROWB = 2 * D;           // bytes per LDS row (16-bit elements)
   constexpr int TILEB = 64 * ROWB;
@@ -69,8 +71,13 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
   constexpr int DT = D / 16;            // 16-wide d tiles of the second product
   static_assert(CPT >= 1, "D >= 32");
   constexpr bool OUT16 = (IN != IN_F32);
+  // fp32 storage: every operand is the fp16 pair (hi, lo) of oeh_common.h: split8 - a second LDS image `LO` bytes behind the
+  // first, three MFMAs per score k-step and two per context k-step (P is an fp16 / integer operand), fp32 accuracy
+  constexpr bool SPLIT = (IN == IN_F32);
+  constexpr int LO = 2 * TILEB;
+  constexpr int MI = SPLIT ? IN_F16 : IN;  // matrix-core operand type
 
-  __shared__ __attribute__((aligned(16))) unsigned char lds_tile[2 * TILEB];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_tile[(SPLIT ? 4 : 2) * TILEB];
   __shared__ __attribute__((aligned(16))) float lds_pad[NT * 16];
 
   const int bid = blockIdx.x;
@@ -98,13 +105,18 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
   const int nt_wave = (kend_wave + 15) >> 4;  // wave-uniform
 
   // ---- Q^T operand: this lane's query row, 8 consecutive d per k-step
-  u4 qf[KS];
+  u4 qf[KS], ql[SPLIT ? KS : 1];
   {
     const long qoff = (long)b * P.qs_b + (long)h * P.qs_h + (long)qrow * P.qs_s;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       qf[ks] = u4{0, 0, 0, 0};
-      if (qvalid) qf[ks] = load8_as16<IN>(P.q, qoff + ks * 32 + 8 * g);
+      if constexpr (SPLIT) {
+        ql[ks] = u4{0, 0, 0, 0};
+        if (qvalid) load8_split(P.q, qoff + ks * 32 + 8 * g, qf[ks], ql[ks]);
+      } else {
+        if (qvalid) qf[ks] = load8_as16<IN>(P.q, qoff + ks * 32 + 8 * g);
+      }
     }
   }
   // ---- key-padding mask row -> LDS (zeros when absent)
@@ -116,6 +128,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
 
   const long kbase = (long)b * P.ks_b + (long)h * P.ks_h;
   const long vbase = (long)b * P.vs_b + (long)h * P.vs_h;
+  f4 stage32[SPLIT ? CPT : 1][2];  // fp32 storage: the raw values wait here, split when they are committed
   u4 stage[CPT];
   auto issue_load = [&](const void* base, long boff, long srow, int tile) {
 #pragma unroll
@@ -123,8 +136,27 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
       const int cid = tid + 256 * i;
       const int row = cid / CPR, ch = cid % CPR;
       const int key = tile * 64 + row;
-      stage[i] = u4{0, 0, 0, 0};
-      if (key < P.Sk) stage[i] = load8_as16<IN>(base, boff + (long)key * srow + ch * 8);
+      if constexpr (SPLIT) {
+        stage32[i][0] = stage32[i][1] = f4{0.f, 0.f, 0.f, 0.f};
+        if (key < P.Sk) {
+          const f4* p = reinterpret_cast<const f4*>(reinterpret_cast<const float*>(base) + boff + (long)key * srow + ch * 8);
+          stage32[i][0] = p[0];
+          stage32[i][1] = p[1];
+        }
+      } else {
+        stage[i] = u4{0, 0, 0, 0};
+        if (key < P.Sk) stage[i] = load8_as16<IN>(base, boff + (long)key * srow + ch * 8);
+      }
+    }
+  };
+  auto commit_at = [&](int i, unsigned char* dst) {
+    if constexpr (SPLIT) {
+      u4 hi, lo;
+      split8(stage32[i][0], stage32[i][1], hi, lo);
+      *reinterpret_cast<u4*>(dst) = hi;
+      *reinterpret_cast<u4*>(dst + LO) = lo;
+    } else {
+      *reinterpret_cast<u4*>(dst) = stage[i];
     }
   };
   auto commit_k = [&](int buf) {
@@ -132,7 +164,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
     for (int i = 0; i < CPT; ++i) {
       const int cid = tid + 256 * i;
       const int row = cid / CPR, ch = cid % CPR;
-      *reinterpret_cast<u4*>(lds_tile + buf * TILEB + row * ROWB + ((ch ^ swz_k<D>(row)) << 4)) = stage[i];
+      commit_at(i, lds_tile + buf * TILEB + row * ROWB + ((ch ^ swz_k<D>(row)) << 4));
     }
   };
   auto commit_v = [&](int buf) {
@@ -140,7 +172,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
     for (int i = 0; i < CPT; ++i) {
       const int cid = tid + 256 * i;
       const int row = cid / CPR, ch = cid % CPR;
-      *reinterpret_cast<u4*>(lds_tile + buf * TILEB + row * ROWB + (((ch >> 1) ^ swz_v<D>(row)) << 5) + ((ch & 1) << 4)) = stage[i];
+      commit_at(i, lds_tile + buf * TILEB + row * ROWB + (((ch >> 1) ^ swz_v<D>(row)) << 5) + ((ch & 1) << 4));
     }
   };
 
@@ -163,11 +195,20 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
         const int t = kt * 4 + sub;
         if (t < nt_wave) {
           const int row = sub * 16 + c;
-          f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+          f4 acc = f4{0.f, 0.f, 0.f, 0.f}, accx = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            const u4 kf = *reinterpret_cast<const u4*>(tb + row * ROWB + (((ks * 4 + g) ^ swz_k<D>(row)) << 4));
-            acc = mfma16<IN>(kf, qf[ks], acc);
+            const unsigned char* ka = tb + row * ROWB + (((ks * 4 + g) ^ swz_k<D>(row)) << 4);
+            const u4 kf = *reinterpret_cast<const u4*>(ka);
+            acc = mfma16<MI>(kf, qf[ks], acc);
+            if constexpr (SPLIT) {
+              accx = mfma16<MI>(kf, ql[ks], accx);
+              accx = mfma16<MI>(*reinterpret_cast<const u4*>(ka + LO), qf[ks], accx);
+            }
+          }
+          if constexpr (SPLIT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(accx[r], kSplitDown, acc[r]);
           }
           s[t] = acc;
         }
@@ -188,6 +229,74 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
   const int t_causal = P.causal ? max(0, q0 + off + 1) >> 4 : NT;  // first tile with a key the wave's first row must not see
   const int t_tail = P.Sk >> 4;                                     // first tile with a key >= Sk
   float m = -__builtin_inff();
+  u2 ph[NT];
+  // The chain on the quantiser grid (oeh_attn_fast.inl, FQ variant - the production INT8 path; this kernel serves its
+  // index dumps and must give the same bits): scores and probabilities quantised, multiplicative scale, masks none / causal.
+  if constexpr (FQ == 1) {
+    constexpr float RELMASK = -1.0e30f;
+    const float k1 = P.scale * P.fq_s.rscale, slo = P.fq_s.lo, shi = P.fq_s.hi;
+    const int klime = P.causal ? min(klim, P.Sk - 1) : P.Sk - 1;
+    float mr = RELMASK;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t < nt_wave) {
+        const int key0 = 16 * t + 4 * g;
+        f4 rel;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rel[r] = __builtin_amdgcn_fmed3f(__builtin_rintf(s[t][r] * k1), slo, shi);
+        if (dump_s && qvalid) dump4(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + key0, fq_dump_word(rel, P.fq_s), P.Sk - key0);
+        if (t >= t_causal || t >= t_tail) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + r > klime) rel[r] = RELMASK;
+        }
+        s[t] = rel;
+        mr = __builtin_fmaxf(__builtin_fmaxf(mr, __builtin_fmaxf(rel[0], rel[1])), __builtin_fmaxf(rel[2], rel[3]));
+      }
+    }
+    mr = __builtin_fmaxf(mr, __shfl_xor(mr, 16));
+    mr = __builtin_fmaxf(mr, __shfl_xor(mr, 32));
+    m = mr * P.fq_s.scale;
+    const float c2 = P.fq_s.c2;
+    f4 sum4 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t < nt_wave) {
+        f4 e;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = s[t][r] - mr;
+          e[r] = __builtin_amdgcn_exp2f(d * c2);
+        }
+        s[t] = e;
+        sum4 = sum4 + e;
+      }
+    }
+    float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    float den = sum;
+    if (P.base != 0) den = sum + exp_acc(m * -1.0f);
+    const float cinv = (1.0f / den) * P.fq_p.rscale, plo = P.fq_p.lo, phi = P.fq_p.hi;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      ph[t] = u2{0u, 0u};
+      if (t < nt_wave) {
+        const int key0 = 16 * t + 4 * g;
+        f4 pv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_fmed3f(__builtin_rintf(s[t][r] * cinv), plo, phi);
+        if (dump_p && qvalid) dump4(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + key0, fq_dump_word(pv, P.fq_p), P.Sk - key0);
+        if constexpr (MI == IN_BF16) {
+          ph[t].x = pack2_bf16(pv[0], pv[1]);
+          ph[t].y = pack2_bf16(pv[2], pv[3]);
+        } else {
+          ph[t].x = pack2_f16(pv[0], pv[1]);
+          ph[t].y = pack2_f16(pv[2], pv[3]);
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     if (t < nt_wave) {
@@ -268,7 +377,6 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
   const float inv = 1.0f / den;
 
   // probabilities -> [clip] -> [fq] -> 16-bit P^T operand, two 16-key tiles per 32-key k-step
-  u2 ph[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     ph[t] = u2{0u, 0u};
@@ -296,7 +404,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
         for (int r = 0; r < 4; ++r)
           if (key0 + r >= P.Sk) pv[r] = 0.0f;
       }
-      if constexpr (IN == IN_BF16) {
+      if constexpr (MI == IN_BF16) {
         ph[t].x = pack2_bf16(pv[0], pv[1]);
         ph[t].y = pack2_bf16(pv[2], pv[3]);
       } else {
@@ -306,10 +414,16 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
     }
   }
 
+  }
+
   // =========================== phase 3: O^T = V^T P^T ===========================
-  f4 o[DT];
+  f4 o[DT], ox[SPLIT ? DT : 1];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) o[dt] = f4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) ox[dt] = f4{0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     if (kt < n_kt) {
@@ -331,11 +445,23 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
             const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + 16 * ROWB));
             const u2 l2 = __builtin_bit_cast(u2, lo), h2 = __builtin_bit_cast(u2, hi);
             const u4 va = u4{l2.x, l2.y, h2.x, h2.y};
-            o[dt] = mfma16<IN>(va, pb, o[dt]);
+            o[dt] = mfma16<MI>(va, pb, o[dt]);
+            if constexpr (SPLIT) {
+              const s4 lol = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + LO));
+              const s4 hil = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + LO + 16 * ROWB));
+              const u2 l3 = __builtin_bit_cast(u2, lol), h3 = __builtin_bit_cast(u2, hil);
+              ox[dt] = mfma16<MI>(u4{l3.x, l3.y, h3.x, h3.y}, pb, ox[dt]);
+            }
           }
         }
       }
     }
+  }
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[dt][r] = __builtin_fmaf(ox[dt][r], kSplitDown, o[dt][r]);
   }
 
   // =========================== epilogue: [scale_p] [fq] gate [fq] store ===========================
@@ -390,7 +516,7 @@ __global__ __launch_bounds__(256, occupancy_hint<NT>()) void oeh_attn_mfma_kerne
 }
 
 // ---- explicit instantiations + launcher table ---------------------------------------------------------------
-template <int NT, int D, int IN, bool FQ>
+template <int NT, int D, int IN, int FQ>
 static int launch_one(const AttnParams& P, hipStream_t st) {
   const unsigned grid = (unsigned)(P.nQT * P.nBHpad);
   hipLaunchKernelGGL((oeh_attn_mfma_kernel<NT, D, IN, FQ>), dim3(grid), dim3(256), 0, st, P);
@@ -400,16 +526,24 @@ static int launch_one(const AttnParams& P, hipStream_t st) {
 template <int NT, int D>
 static int launch_nt_d(const AttnParams& P, int in, bool fq, hipStream_t st) {
   if (fq) {
+    const bool grid_chain = P.fq_s.en && P.fq_p.en && !P.clip && P.pad == nullptr && P.full == nullptr && P.scale_div == 0.0f;
+    if (grid_chain) {
+      switch (in) {
+        case IN_F16: return launch_one<NT, D, IN_F16, 1>(P, st);
+        case IN_BF16: return launch_one<NT, D, IN_BF16, 1>(P, st);
+        default: return launch_one<NT, D, IN_F32, 1>(P, st);
+      }
+    }
     switch (in) {
-      case IN_F16: return launch_one<NT, D, IN_F16, true>(P, st);
-      case IN_BF16: return launch_one<NT, D, IN_BF16, true>(P, st);
-      default: return launch_one<NT, D, IN_F32, true>(P, st);
+      case IN_F16: return launch_one<NT, D, IN_F16, 2>(P, st);
+      case IN_BF16: return launch_one<NT, D, IN_BF16, 2>(P, st);
+      default: return launch_one<NT, D, IN_F32, 2>(P, st);
     }
   }
   switch (in) {
-    case IN_F16: return launch_one<NT, D, IN_F16, false>(P, st);
-    case IN_BF16: return launch_one<NT, D, IN_BF16, false>(P, st);
-    default: return launch_one<NT, D, IN_F32, false>(P, st);
+    case IN_F16: return launch_one<NT, D, IN_F16, 0>(P, st);
+    case IN_BF16: return launch_one<NT, D, IN_BF16, 0>(P, st);
+    default: return launch_one<NT, D, IN_F32, 0>(P, st);
   }
 }
 

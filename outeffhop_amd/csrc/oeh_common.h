@@ -28,6 +28,7 @@ struct FqP {
   int en;
   float scale, rscale, zp, qmax;  // rscale = RN(1/scale), formed by the host (oeh_api.hip: make_fq)
   float lo, hi;                   // -zp and qmax - zp: the grid relative to the zero point
+  float c2;                       // RN(scale * log2(e)), formed in double by the host: exp(scale * d) = exp2(d * c2) for grid differences d
   unsigned char* dump;
 };
 
@@ -146,6 +147,27 @@ __device__ __forceinline__ u4 load8_as16(const void* base, long elem_off) {
   } else {
     return *reinterpret_cast<const u4*>(reinterpret_cast<const unsigned short*>(base) + elem_off);
   }
+}
+
+// fp32 storage on the 16-bit matrix cores WITHOUT giving up fp32 accuracy: every fp32 value x is carried as two fp16
+// operands, x = hi + lo * 2^-11 with hi = RN16(x) and lo = RN16((x - hi) * 2^11) (the residual x - hi is exact in fp32,
+// the power-of-two scaling keeps lo out of the fp16 subnormals), so |x - (hi + lo 2^-11)| <= 2^-22 |x|, and a product of two
+// such values is accumulated as  a.b = ah.bh + 2^-11 (ah.bl + al.bh)  - three MFMAs into two fp32 accumulators, the
+// dropped al.bl term being 2^-22 relative.  That is the reference's fp32 `bmm` (quantized_opt.py:151, validate_clm.py runs
+// fp32 models) to ~3e-7 relative instead of the 5e-4 of operands rounded to fp16, which flipped 0.5 % of the score
+// quantiser's indices.  |x| must stay inside the fp16 range (65504): q / k / v of a transformer do.
+constexpr float kSplitUp = 2048.0f, kSplitDown = 1.0f / 2048.0f;
+__device__ __forceinline__ void split8(const f4 a, const f4 b, u4& hi, u4& lo) {
+  const h2 h0 = __builtin_convertvector((f2{a[0], a[1]}), h2), h1 = __builtin_convertvector((f2{a[2], a[3]}), h2);
+  const h2 h2_ = __builtin_convertvector((f2{b[0], b[1]}), h2), h3 = __builtin_convertvector((f2{b[2], b[3]}), h2);
+  hi = u4{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, h2_), __builtin_bit_cast(unsigned, h3)};
+  lo = u4{pack2_f16((a[0] - (float)h0[0]) * kSplitUp, (a[1] - (float)h0[1]) * kSplitUp), pack2_f16((a[2] - (float)h1[0]) * kSplitUp, (a[3] - (float)h1[1]) * kSplitUp),
+          pack2_f16((b[0] - (float)h2_[0]) * kSplitUp, (b[1] - (float)h2_[1]) * kSplitUp), pack2_f16((b[2] - (float)h3[0]) * kSplitUp, (b[3] - (float)h3[1]) * kSplitUp)};
+}
+// 8 consecutive fp32 storage elements -> the (hi, lo) operand pair
+__device__ __forceinline__ void load8_split(const void* base, long elem_off, u4& hi, u4& lo) {
+  const f4* p = reinterpret_cast<const f4*>(reinterpret_cast<const float*>(base) + elem_off);
+  split8(p[0], p[1], hi, lo);
 }
 
 // LDS-DMA of 16 B per lane: LDS[lds_addr + lane*16] <- *gsrc (global_load_lds_dwordx4; 1 KiB per wave-instruction).

@@ -161,12 +161,12 @@ def test_gate_epilogue(ops):
     _check(ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), scale=0.125, gate=gh.cuda()), want, msg="per head")
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, dict(atol=1e-3, rtol=1e-3)), (torch.bfloat16, dict(atol=2e-2, rtol=2e-2))])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, dict(atol=5e-4, rtol=5e-4)), (torch.bfloat16, dict(atol=2e-2, rtol=2e-2))])
 def test_other_storage_dtypes(ops, dtype, tol):
     B, H, S, D = 2, 2, 144, 64
     q, k, v = _rand((B, H, S, D), 61, dtype=dtype), _rand((B, H, S, D), 62, dtype=dtype), _rand((B, H, S, D), 63, dtype=dtype)
-    if dtype == torch.float32:  # MFMA operands are fp16: define the oracle on the fp16-rounded values
-        q, k, v = q.half().float(), k.half().float(), v.half().float()
+    # fp32 storage: the oracle sees the fp32 values themselves (scores from fp16 operand PAIRS are fp32-accurate; what is left
+    # is the probability operand's rounding to fp16, <= 2^-12 relative per key)
     want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=0.125, causal=True, clamp_min=True, **SPECS["clippedsoftmax1(-.025:1)"])
     got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=_spec(ops, "clippedsoftmax1(-.025:1)"), scale=0.125, causal=True,
                        clamp_min=True, mask_min=float(np.finfo(np.float32).min))
@@ -574,7 +574,7 @@ def test_fp32_storage_is_read_in_place_by_the_16bit_operand_kernels(ops):
 
     fmin = float(np.finfo(np.float32).min)
     FQ = ops.FakeQuantSpec
-    tol32 = dict(atol=2e-3, rtol=2e-3)  # fp32 data, fp16 matrix-core operands: the general kernel's accuracy on fp32 storage
+    tol32 = dict(atol=5e-4, rtol=5e-4)  # fp32 data as fp16 operand pairs: fp32-accurate scores; the probability operand is rounded to fp16
     for n, (B, H, Sq, Sk, D, causal, sm) in enumerate([(2, 3, 300, 300, 64, True, "softmax1"), (1, 2, 77, 290, 32, False, "vanilla"),
                                                         (2, 2, 400, 400, 128, True, "clippedsoftmax1(-.025:1)"), (1, 4, 512, 512, 64, True, "softmax1"),
                                                         (3, 2, 100, 100, 64, False, "clippedsoftmax1(-.025:1)"), (1, 2, 700, 700, 64, True, "softmax1")]):
@@ -602,7 +602,7 @@ def test_fp32_storage_is_read_in_place_by_the_16bit_operand_kernels(ops):
         finally:
             _lib.load().oeh_debug_set_variant(0, 0)
         _check(got_gen, want, tol=tol32, msg=f"general kernel case {n}")
-        # INT8 chain: same bits from both kernels (same rounded operands, same per-element chain)
+        # INT8 chain: same bits from both kernels (same operand pairs, same per-element chain)
         fq = ops.AttnFakeQuant(FQ(0.05, 120.0), FQ(1.0 / 255.0, 0.0), FQ(0.01, 128.0), ctx_before_gate=bool(n & 1))
         a = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=fq, **kw)
         _lib.load().oeh_debug_set_variant((1 << 6) | (1 << 7), 0)
@@ -644,7 +644,7 @@ def test_randomised_sweep_fp32_storage(ops):
     lib = _lib.load()
     fmin = float(np.finfo(np.float32).min)
     rng = np.random.default_rng(424242)
-    tol32 = dict(atol=2e-3, rtol=2e-3)
+    tol32 = dict(atol=5e-4, rtol=5e-4)
     seen = set()
     try:
         for n in range(30):
@@ -680,3 +680,85 @@ def test_randomised_sweep_fp32_storage(ops):
     finally:
         lib.oeh_debug_set_variant(0, 0)
     assert {"flash16", "fast16", "mfma16"} <= seen
+
+
+def test_fp32_storage_indices_match_the_reference_capture(ops):
+    """VERDICT r1 J1 / north_star "bit-exact INT8 indices": the reference's validate path runs fp32 models
+    (accelerate_configs/1gpu_no_mp.yaml:14), `quantized_opt.py:151` is an fp32 bmm.  The reference's own captured fp32
+    projections (tests/golden/int8_attn.npz: q_lin / k_lin / v_lin, calibrated quantiser ranges) go through oeh_attn_fwd with
+    index dumps; the three index tensors are compared with the ones captured inside the reference modules.  Operands rounded
+    to fp16 (round 1) flipped 0.5-0.7 % of the score indices; carried as fp16 pairs (hi, lo) they must not flip more than
+    1e-4 of any tensor kind, and never by more than one step."""
+    g = load_golden("int8_attn.npz")
+    import json
+
+    fmin = float(np.finfo(np.float32).min)
+    B, T, H, D = 2, 32, 2, 64
+    FQ = ops.FakeQuantSpec.from_delta
+    totals = {"scores": [0, 0], "probs": [0, 0], "ctx": [0, 0]}
+    worst = 0
+
+    def heads(name):
+        return torch.from_numpy(g[name]).cuda().view(B, T, H, D).permute(0, 2, 1, 3)
+
+    def grids(pre, dumps):
+        out = []
+        for n, d in zip(("attn_scores_act_quantizer", "attn_probs_act_quantizer", "context_act_quantizer"), dumps):
+            out.append(FQ(float(g[f"{pre}.q.{n}.activation_quantizer.delta"]), float(g[f"{pre}.q.{n}.activation_quantizer.zero_float"]), dump=d))
+        return out
+
+    def tally(kind, got, want):
+        nonlocal worst
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        totals[kind][0] += int((d != 0).sum())
+        totals[kind][1] += d.size
+        worst = max(worst, int(d.max()))
+
+    for meta in json.loads(str(g["meta_json"])):
+        sm = _spec(ops, meta["softmax"])
+        gated = meta["gate"] != "nogate"
+        # ---- OPT order: q scaled after the projection (opt_attention.py:167), causal + padding mask tensor, context quantised before the gate
+        pre = f"opt{meta['tag']}"
+        q, k, v = heads(f"{pre}.q_lin") * (D ** -0.5), heads(f"{pre}.k_lin"), heads(f"{pre}.v_lin")
+        dumps = [torch.zeros((B, H, T, T), dtype=torch.uint8, device="cuda"), torch.zeros((B, H, T, T), dtype=torch.uint8, device="cuda"),
+                 torch.zeros((B, H, T, D), dtype=torch.uint8, device="cuda")]
+        fq = ops.AttnFakeQuant(*grids(pre, dumps), ctx_before_gate=True)
+        mask = torch.from_numpy(g["opt_mask"]).cuda()
+        out = ops.attn_fwd(q, k, v, softmax=sm, full_mask=mask, clamp_min=True, mask_min=fmin, fq=fq)
+        for kind, dmp in zip(("scores", "probs", "ctx"), dumps):
+            tally(kind, dmp.cpu().numpy().reshape(g[f"{pre}.{kind}.idx"].shape), g[f"{pre}.{kind}.idx"])
+        if not gated:  # the dequantised context is the kernel's output
+            ref = g[f"{pre}.ctx.out"].reshape(B, H, T, D)
+            step = float(np.float32(g[f"{pre}.q.context_act_quantizer.activation_quantizer.delta"]))
+            err = np.abs(_np32(out) - ref)
+            assert err.max() <= 1.01 * step and (err > 1e-6).mean() <= 2e-3, (pre, err.max(), step, (err > 1e-6).mean())
+        # the production kernels on the sample without padding (batch 0): analytic causal flag, fp32 forms of the full-row
+        # kernel (no dumps) and of the general kernel (dumps) - on the quantiser grid when the softmax is not clipped
+        q0, k0, v0 = q[:1], k[:1], v[:1]
+        d0 = [torch.zeros((1, H, T, T), dtype=torch.uint8, device="cuda"), torch.zeros((1, H, T, T), dtype=torch.uint8, device="cuda"),
+              torch.zeros((1, H, T, D), dtype=torch.uint8, device="cuda")]
+        kw = dict(softmax=sm, causal=True, clamp_min=True, mask_min=fmin)
+        o_dump = ops.attn_fwd(q0, k0, v0, fq=ops.AttnFakeQuant(*grids(pre, d0), ctx_before_gate=True), **kw)
+        o_prod = ops.attn_fwd(q0, k0, v0, fq=ops.AttnFakeQuant(*grids(pre, [None] * 3), ctx_before_gate=True), **kw)
+        assert torch.equal(o_dump, o_prod), pre + ": the production kernel and the index-dump run differ"
+        for kind, dmp in zip(("scores", "probs", "ctx"), d0):
+            want = g[f"{pre}.{kind}.idx"].reshape((B, H) + dmp.shape[2:])[:1]
+            tally(kind, dmp.cpu().numpy(), want)
+        # ---- BERT order: scores / sqrt(d), key-padding mask, context quantised AFTER the gate and the head merge
+        pre = f"bert{meta['tag']}"
+        q, k, v = heads(f"{pre}.q_lin"), heads(f"{pre}.k_lin"), heads(f"{pre}.v_lin")
+        dumps = [torch.zeros((B, H, T, T), dtype=torch.uint8, device="cuda"), torch.zeros((B, H, T, T), dtype=torch.uint8, device="cuda"),
+                 torch.zeros((B, H, T, D), dtype=torch.uint8, device="cuda")]
+        sp = grids(pre, dumps)
+        fq = ops.AttnFakeQuant(sp[0], sp[1], None if gated else sp[2], ctx_before_gate=False)  # (the gate values are not part of the capture)
+        pad = torch.from_numpy(g["bert_mask"]).cuda()
+        ops.attn_fwd(q, k, v, softmax=sm, scale_div=math.sqrt(D), key_pad_mask=pad, mask_min=fmin, fq=fq)
+        kinds = ("scores", "probs") if gated else ("scores", "probs", "ctx")
+        for kind, dmp in zip(kinds, dumps):
+            got = dmp.cpu().numpy()
+            if kind == "ctx":
+                got = got.transpose(0, 2, 1, 3).reshape(B, T, H * D)
+            tally(kind, got, g[f"{pre}.{kind}.idx"])
+    rates = {kind: n / max(tot, 1) for kind, (n, tot) in totals.items()}
+    print("fp32-storage index flips vs the reference capture:", {kind: f"{n}/{tot}" for kind, (n, tot) in totals.items()})
+    assert worst <= 1 and all(r <= 1e-4 for r in rates.values()), (totals, worst)
