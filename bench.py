@@ -42,6 +42,9 @@ WORKLOADS = {
                               desc="OPT-125m attention core B=16 H=12 S=512 d=64 fp32 storage causal softmax1"),
     "opt_int8_fp32": dict(B=16, H=12, S=512, d=64, order="opt", sm=(1, False, 0.0, 1.0), int8=True, gate=False, fp32=True,
                           desc="OPT-125m attention core B=16 H=12 S=512 d=64 fp32 storage causal softmax1 + 3 fused INT8 fake-quantisers"),
+    # STanHop's Association (cross_models/hopfield.py:42-51): B*data_dim = 32*7 series, L = S = 28 segments, H = 4, E = 64, fp32
+    "stanhop": dict(B=224, H=4, S=28, d=64, order="none", sm=(1, False, 0.0, 1.0), int8=False, gate=False, fp32=True, layers=48,
+                    desc="STanHop Association B*data_dim=224 L=S=28 H=4 E=64 fp32 softmax1, (B,L,H,E) layout: one wave per (batch, head)"),
     "bert_softmax1": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=False, gate=False,
                           desc="BERT-base attention core B=32 H=12 S=128 d=64 fp16 key-padding mask softmax1"),
     "bert_gated": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=False, gate=True,
@@ -56,7 +59,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="opt_softmax1", choices=sorted(WORKLOADS))
-    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--layers", type=int, default=None, help="launches (distinct buffer sets) per step; default 12 = OPT-125m's / BERT-base's "
+                    "attention layers (stanhop: 48, so that a step's buffers exceed the 256 MB Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-check", action="store_true", help="N > 1: skip the shard-parity check (all_gather of the ranks' layer-0 outputs "
@@ -81,11 +85,14 @@ def cpu_baseline(w, seconds):
     if w["order"] == "opt":
         q = (q * d ** -0.5).half().float()
         mask = E.causal_mask(Bs, S)
+    elif w["order"] == "none":
+        q = q * d ** -0.5  # Association scales the scores by 1/sqrt(E): the same multiply count, done on q here
+        mask = None
     else:
         mask = torch.zeros(Bs, 1, 1, S)
     fq = dict(scores=(0.08, 128.0, 255.0), probs=(1 / 255.0, 0.0, 255.0), ctx=(0.02, 128.0, 255.0)) if w["int8"] else None
     gate = torch.rand(Bs, H, S, 1, generator=g) if w["gate"] else None
-    run = lambda: E.attn_core_eager(q, k, v, order=w["order"], base=base, clip=clip, gamma=gamma, eta=eta, mask=mask, fq=fq, gate=gate)  # noqa: E731
+    run = lambda: E.attn_core_eager(q, k, v, order=("opt" if w["order"] == "none" else w["order"]), base=base, clip=clip, gamma=gamma, eta=eta, mask=mask, fq=fq, gate=gate)  # noqa: E731
     with torch.no_grad():
         # eager torch on many-core hosts is fastest well below the core count: pick the best thread count first
         best_t, best_dt = cores, float("inf")
@@ -247,7 +254,7 @@ def main():
 
     lib = _lib.load()
     w = WORKLOADS[a.workload]
-    B, H, S, d, L = w["B"], w["H"], w["S"], w["d"], a.layers
+    B, H, S, d, L = w["B"], w["H"], w["S"], w["d"], (a.layers or w.get("layers", 12))
     base, clip, gamma, eta = w["sm"]
     fmin = float(np.finfo(np.float32).min)
 
@@ -312,6 +319,8 @@ def main():
             getattr(dsc, name)[:] = [t.stride(0), t.stride(1), t.stride(2)]
         if w["order"] == "opt":
             dsc.scale, dsc.scale_div, dsc.causal, dsc.clamp_min = 1.0, 0.0, 1, 1
+        elif w["order"] == "none":  # Association: scale 1/sqrt(E), no mask
+            dsc.scale, dsc.scale_div = d ** -0.5, 0.0
         else:
             dsc.scale, dsc.scale_div = 1.0, 8.0
             dsc.key_pad_mask, dsc.key_pad_dtype, dsc.key_pad_stride = pad.data_ptr(), _lib.OEH_F32, pad.stride(0)
@@ -458,7 +467,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": w["desc"], "variant": ops.attn_variant(B, H, S, S, d, torch.float32 if w.get("fp32") else torch.float16, fq=w["int8"], clip=bool(w["sm"][1]),
-                                                                       causal=(w["order"] == "opt"), key_pad=(w["order"] == "bert"), scale_div=(8.0 if w["order"] == "bert" else 0.0)),
+                                                                       causal=(w["order"] == "opt"), key_pad=(w["order"] == "bert"), scale_div=(8.0 if w["order"] == "bert" else 0.0),
+                                                                       scale=(d ** -0.5 if w["order"] == "none" else 1.0)),
                 "batch_per_gpu": B, "seq_len": S, "heads": H, "head_dim": d, "layers_per_step": L,
                 "launches_per_step": L, "model_tokens_per_s": world * B * S * a.steps / wall,
                 "parallelism": f"batch-shard x{world}, no collective in the timed region",

@@ -19,6 +19,7 @@ int launch_attn_flash_d32(const AttnParams& P, int in, int mq, hipStream_t st);
 int launch_attn_flash_d64(const AttnParams& P, int in, int mq, hipStream_t st);
 int launch_attn_flash_d128(const AttnParams& P, int in, int mq, hipStream_t st);
 int launch_attn_generic(const AttnParams& P, int in, hipStream_t st);
+int launch_attn_small(const AttnParams& P, int in, hipStream_t st);
 int launch_softmax_rows(const void* x, void* y, long rows, int cols, int in, int base, int clip, float w, float g, hipStream_t st);
 int launch_fake_quant(const void* x, void* y, unsigned char* idx, long n, int in, FqP f, hipStream_t st);
 int launch_gate(const void* hidden, int in, int B, int T, int H, int d, long hs_b, long hs_t, const float* w1, const float* b1,
@@ -54,7 +55,7 @@ FqP make_fq(const oeh_fq* f) {
   return r;
 }
 
-enum Variant { V_NONE = 0, V_FLASH, V_FAST, V_MFMA, V_GENERIC };
+enum Variant { V_NONE = 0, V_FLASH, V_FAST, V_MFMA, V_GENERIC, V_SMALL };
 
 // rows must be 16-byte aligned for the MFMA path's 16-B loads / 8..16-B stores
 bool aligned16(const void* p, const int64_t* st, int eb) {
@@ -143,9 +144,30 @@ bool fast32_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
   return fast_eligible(&t, fq);
 }
 
+// The small-shape kernel (oeh_attn_small.hip: one wave per (batch, head), K and V in registers, fp32 matrix-core products):
+// many tiny problems - STanHop's Association (L, S ~ 28, H = 4, E in {16, 32, 64}, batch * data_dim problems).  No masks,
+// no fake-quant, no in-kernel gate predictor; rows of 4 elements must be 4-element aligned (16 B in fp32, 8 B in 16-bit).
+bool small_eligible(const oeh_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const oeh_fq_desc* fq) {
+  if (any_fq(fq) || d->key_pad_mask != nullptr || d->full_mask != nullptr || d->causal) return false;
+  if (d->gate == nullptr && d->gate_hidden != nullptr) return false;
+  if (!(d->D == 16 || d->D == 32 || d->D == 64) || d->Sk > 64 || d->Sq > 64) return false;
+  // a wave per problem only pays when there are enough problems to fill the chip (or no matrix-core kernel takes the shape)
+  if (!(d->D == 16 || (long)d->B * d->H >= 256)) return false;
+  const int ab = 4 * elem_bytes(d->dtype);
+  const int64_t* sts[4] = {d->q_stride, d->k_stride, d->v_stride, d->o_stride};
+  const void* ps[4] = {q, k, v, o};
+  for (int t = 0; t < 4; ++t) {
+    if (q != nullptr && (reinterpret_cast<uintptr_t>(ps[t]) % ab) != 0) return false;
+    for (int i = 0; i < 3; ++i)
+      if ((sts[t][i] & 3) != 0) return false;
+  }
+  return true;
+}
+
 unsigned long long* g_stamps = nullptr;  // tools/timeline.py only
 int g_variant_off = 0;                   // tools/microbench.py only: bit (1 << Variant) disables a variant
 int g_flash_mq = 0;                      // tools/microbench.py only: force query blocks per wave
+int g_prio = 0;                          // tools/microbench.py only: 1 = heavier causal workgroups at higher wave priority
 
 // query blocks (16 rows) per wave of the one-pass kernel: 2 (128-row workgroups) once that still gives every CU two
 // workgroups, else 1
@@ -164,6 +186,7 @@ Variant pick_variant(const oeh_attn_desc* d, const void* q, const void* k, const
   const bool al = (q == nullptr) || (aligned16(q, d->q_stride, eb) && aligned16(k, d->k_stride, eb) &&
                                      aligned16(v, d->v_stride, eb) && aligned16(o, d->o_stride, eb));
   const bool d_ok = d->D == 32 || d->D == 64 || d->D == 128;
+  if (small_eligible(d, q, k, v, o, fq) && !(g_variant_off & (1 << V_SMALL))) return V_SMALL;
   if (d_ok && al && flash_eligible(d, fq) && !(g_variant_off & (1 << V_FLASH))) return V_FLASH;
   if (d_ok && al && flash32_eligible(d, fq) && !(g_variant_off & ((1 << V_FLASH) | (1 << 6)))) return V_FLASH;
   if (shape_ok && p_exact && al && fast_eligible(d, fq) && !(g_variant_off & (1 << V_FAST))) return V_FAST;
@@ -202,6 +225,7 @@ void fill_params(AttnParams& P, const oeh_attn_desc* d, const void* q, const voi
     P.ctx_before_gate = fq->ctx_quant_before_gate ? 1 : 0;
   }
   P.stamps = g_stamps;
+  P.prio = (g_prio && d->causal) ? 1 : 0;
   P.nQT = (d->Sq + 63) / 64;
   P.nBH = d->B * d->H;
   P.nBHpad = (P.nBH + 7) & ~7;
@@ -218,6 +242,10 @@ void fill_params(AttnParams& P, const oeh_attn_desc* d, const void* q, const voi
 const char* variant_name(Variant v, const oeh_attn_desc* d, bool fq) {
   static thread_local char buf[64];
   if (v == V_GENERIC) return "generic";
+  if (v == V_SMALL) {
+    std::snprintf(buf, sizeof(buf), "small/ST%d/D%d/%s", d->Sk <= 32 ? 2 : 4, d->D, d->dtype == OEH_F16 ? "f16" : (d->dtype == OEH_BF16 ? "bf16" : "f32"));
+    return buf;
+  }
   if (v == V_NONE) return nullptr;
   const int nt = d->Sk <= 128 ? 8 : (d->Sk <= 256 ? 16 : 32);
   const char* dt = d->dtype == OEH_F16 ? "f16" : (d->dtype == OEH_BF16 ? "bf16" : "f32");
@@ -245,6 +273,7 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
   fill_params(P, desc, q, k, v, o, fq);
   P.src32 = (desc->dtype == OEH_F32 && (var == V_FLASH || var == V_FAST)) ? 1 : 0;  // fp32 storage read directly, fp32 output
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (var == V_SMALL) return oeh::launch_attn_small(P, desc->dtype, st);
   if (var == V_FLASH) {
     if (desc->scale_div != 0.0f) { P.scale = 1.0f / desc->scale_div; P.scale_div = 0.0f; }  // (fast_eligible: exact for a power of two)
     const int mq = flash_mq(desc);
@@ -323,14 +352,14 @@ int oeh_minmax(const void* x, int64_t n, int32_t dtype, float* out2, void* strea
 //  oeh_debug_set_stamps: device buffer of 32 u64 per wave that the one-pass kernel fills with s_memtime /
 //    s_memrealtime stamps when non-null (tools/timeline.py).
 void oeh_debug_set_variant(int off_mask, int flash_mq_force) {
-  g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force;
+  g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force; g_prio = (off_mask >> 9) & 1;
 }
 void oeh_debug_set_stamps(void* device_buffer) { g_stamps = static_cast<unsigned long long*>(device_buffer); }
 
 int oeh_abi_version(void) { return OEH_ABI_VERSION; }
 
 const char* oeh_build_info(void) {
-  return "liboeh_hip gfx950 (MI355X, CDNA4) v_mfma_f32_16x16x32_{f16,bf16}; built " __DATE__ " " __TIME__ " hipcc " __VERSION__;
+  return "liboeh_hip gfx950 (MI355X, CDNA4) v_mfma_f32_16x16x32_{f16,bf16} + v_mfma_f32_16x16x4_f32; built " __DATE__ " " __TIME__ " hipcc " __VERSION__;
 }
 
 const char* oeh_strerror(int code) {

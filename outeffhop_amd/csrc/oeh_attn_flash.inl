@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     tm0[j] = ((causal ? min(rb[j] + off, Sk - 1) : Sk - 1) + 1) >> 6;
   }
 
+  if (P.prio) set_wave_priority((qt * 4) / P.nQT);  // q tiles further down the causal triangle stream more keys
   unsigned long long* stamp = nullptr;  // diagnostic runs of tools/timeline.py only
   if (P.stamps != nullptr) stamp = P.stamps + ((long)bid * 4 + wave) * 32;
 #define OEH_STAMP(slot)                                                                \

@@ -238,6 +238,13 @@ __device__ __forceinline__ void barrier_mem() {
   asm volatile("" ::: "memory");
 }
 
+// s_setprio takes an immediate: level 0..3 from a wave-uniform value
+__device__ __forceinline__ void set_wave_priority(int level) {
+  if (level >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (level == 2) __builtin_amdgcn_s_setprio(2);
+  else if (level == 1) __builtin_amdgcn_s_setprio(1);
+}
+
 // byte offset of an LDS object inside the workgroup's allocation (what M0 / ds_* addresses are made of)
 __device__ __forceinline__ unsigned lds_offset(const void* p) {
   return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p;

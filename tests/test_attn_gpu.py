@@ -177,7 +177,7 @@ def test_other_storage_dtypes(ops, dtype, tol):
 def test_generic_kernel_shapes(ops):
     """Shapes outside the MFMA kernel (D=16/48, Sk>512) run the generic HIP kernel."""
     for (B, H, Sq, Sk, D) in [(3, 4, 7, 5, 16), (1, 2, 33, 33, 48), (1, 1, 20, 700, 64)]:
-        assert ops.attn_variant(B, H, Sq, Sk, D, clip=True) == "generic"
+        assert ops.attn_variant(B, H, Sq, Sk, D, clip=True) == ("generic" if D != 16 else "small/ST2/D16/f16")
         q, k, v = _rand((B, H, Sq, D), 71), _rand((B, H, Sk, D), 72), _rand((B, H, Sk, D), 73)
         want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=1 / math.sqrt(D), **SPECS["clippedsoftmax1(-.025:1)"])
         got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=_spec(ops, "clippedsoftmax1(-.025:1)"), scale=1 / math.sqrt(D))
@@ -762,3 +762,35 @@ def test_fp32_storage_indices_match_the_reference_capture(ops):
     rates = {kind: n / max(tot, 1) for kind, (n, tot) in totals.items()}
     print("fp32-storage index flips vs the reference capture:", {kind: f"{n}/{tot}" for kind, (n, tot) in totals.items()})
     assert worst <= 1 and all(r <= 1e-4 for r in rates.values()), (totals, worst)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_small_shape_kernel_stanhop(ops, dtype):
+    """SURVEY 8f-4 / VERDICT r1 #8: STanHop's Association (cross_models/hopfield.py:42-51) - B*data_dim problems of L, S ~ 28
+    rows, H = 4, E in {16, 32, 64}, (B,L,H,E) layout - one wave per (batch, head) with K and V in registers and fp32
+    matrix-core products.  All four modes, ragged L / S (cross attention between segment and router axes), a gate; against
+    the oracle.  fp32 storage: the products are exact fmaf chains, so the tolerance is fp32 rounding, not an fp16 contract."""
+    tol = {torch.float32: dict(atol=3e-6, rtol=1e-5), torch.float16: F16_TOL, torch.bfloat16: dict(atol=2e-2, rtol=2e-2)}[dtype]
+    modes = [("softmax1", 1.0), ("vanilla", 1.0), ("clippedsoftmax1(-.025:1)", 1.0), ("clipped(-.003:1.003)", 1.0)]
+    n = 0
+    for (B, L, S, H, E) in [(32 * 7, 28, 28, 4, 64), (70, 28, 10, 4, 32), (64, 10, 28, 4, 16), (300, 1, 64, 1, 16), (80, 64, 64, 4, 64), (96, 33, 17, 3, 32)]:
+        for sm, _ in modes[n % 2::2]:
+            n += 1
+            q, k, v = _rand((B, L, H, E), 900 + n, dtype=dtype), _rand((B, S, H, E), 950 + n, dtype=dtype), _rand((B, S, H, E), 990 + n, dtype=dtype)
+            qv, kv, vv = q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)  # (B,H,L,E) views of the (B,L,H,E) layout
+            assert ops.attn_variant(B, H, L, S, E, dtype, clip="clipped" in sm).startswith("small/"), (B, L, S, H, E)
+            scale = 1.0 / math.sqrt(E)
+            gate = torch.rand((B, H, L, 1), generator=torch.Generator().manual_seed(n)) if n % 3 == 0 else None
+            want = O.attn_core(_np32(qv), _np32(kv), _np32(vv), scale=scale, gate=None if gate is None else gate.numpy(), **SPECS[sm])
+            got = ops.attn_fwd(qv.cuda(), kv.cuda(), vv.cuda(), softmax=_spec(ops, sm), scale=scale, gate=None if gate is None else gate.cuda())
+            assert got.dtype == dtype and got.permute(0, 2, 1, 3).is_contiguous()
+            _check(got, want, tol, msg=f"{(B, L, S, H, E)} {sm} {dtype}")
+    # BERT-order division and a single problem with D = 16 (no other matrix-core kernel takes D = 16)
+    q, k, v = _rand((2, 3, 20, 16), 1, dtype=dtype), _rand((2, 3, 40, 16), 2, dtype=dtype), _rand((2, 3, 40, 16), 3, dtype=dtype)
+    want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=4.0, scale_is_divisor=True, **SPECS["softmax1"])
+    _check(ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), scale_div=4.0), want, tol, msg="divisor")
+    # unaligned rows (3-element offset) fall back to the any-shape kernel and still agree
+    buf = _rand((300, 28, 4 * 16 + 3), 4, dtype=dtype).cuda()
+    qu = buf[:, :, 3:].view(300, 28, 4, 16).permute(0, 2, 1, 3)
+    want = O.attn_core(_np32(qu), _np32(qu), _np32(qu), scale=0.25, **SPECS["softmax1"])
+    _check(ops.attn_fwd(qu, qu, qu, scale=0.25), want, tol, msg="unaligned")
