@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OEH_ABI_VERSION 2
+#define OEH_ABI_VERSION 3
 
 /* error codes (negative errno style) */
 #define OEH_OK 0
@@ -164,6 +164,27 @@ int oeh_gate_fwd(const void* hidden, int32_t dtype, int32_t B, int32_t T, int32_
 /* min and max of a dense array -> out[0], out[1] (fp32 device scalars): the CurrentMinMax / RunningMinMax
  * (no percentile) range statistics (range_estimators.py:71-72,96-97) without a device->host copy. */
 int oeh_minmax(const void* x, int64_t n, int32_t dtype, float* out2, void* stream);
+
+/* Percentile range statistics with the running average, entirely in device memory: RunningMinMaxEstimator with
+ * `percentile` (range_estimators.py:83-106; the --est_ranges_pct flow of validate_clm.py:450-454 through
+ * pass_data_for_range_estimation, transformers_language/utils.py:50-71), replacing the reference's device->host copy +
+ * np.percentile per quantiser and batch:
+ *   lo = np.percentile(x, q_lo), hi = np.percentile(x, q_hi)   (percents; "linear" interpolation between the two order
+ *        statistics around each rank, float64 - what numpy returns for float32 data; exact, by radix selection)
+ *   state[0..1] = first ? (lo, hi) : (1 - momentum) * (lo, hi) + momentum * state[0..1]
+ * state: device double[2].  work: device scratch of OEH_CALIB_WORK_BYTES (8-byte aligned; contents irrelevant before and
+ * after).  n < 2^32.  No host synchronisation. */
+#define OEH_CALIB_WORK_BYTES 36864
+int oeh_percentile_ema(const void* x, int64_t n, int32_t dtype, double q_lo, double q_hi, double momentum, int32_t first,
+                       double* state, void* work, void* stream);
+
+/* The activation quantiser's forward while ranges are still being estimated (QuantizationManager.forward in
+ * Qstates.estimate_ranges, quantization_manager.py:104-112): the grid is derived IN the kernel from the float64
+ * (x_min, x_max) pair in device memory exactly as set_quant_range does (uniform_quantizers.py:72-82:
+ * x_min <- min(x_min, 0), x_max <- max(x_max, eps), delta = (x_max - x_min) / (2^n_bits - 1), zero = -x_min / delta,
+ * scale = float32(max(delta, eps)), zero_point = clamp(rint(zero), 0, 2^n_bits - 1)), then y = scale * (idx - zero_point). */
+int oeh_fake_quant_range(const void* x, void* y, int64_t n, int32_t dtype, const double* xmin_xmax, int32_t n_bits, double eps,
+                         void* stream);
 
 /* library information (host side, no device work) */
 int oeh_abi_version(void);

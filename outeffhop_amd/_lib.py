@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OEH_LIB: explicit path of another build of the same library (A/B timing of compiler flags; tools/ only)
 LIB_PATH = os.environ.get("OEH_LIB") or os.path.join(_HERE, "lib", "liboeh_hip.so")
 
+ABI_VERSION = 3  # include/oeh.h: OEH_ABI_VERSION
+CALIB_WORK_BYTES = 36864  # include/oeh.h: OEH_CALIB_WORK_BYTES
 OEH_F16, OEH_BF16, OEH_F32 = 0, 1, 2
 OEH_SOFTMAX_VANILLA, OEH_SOFTMAX_ONE = 0, 1
 
@@ -53,7 +55,7 @@ class oeh_attn_desc(C.Structure):
 
 # every symbol include/oeh.h declares (tests/test_abi.py checks the .so exports exactly these)
 EXPORTS = (
-    "oeh_attn_fwd", "oeh_softmax_rows", "oeh_fake_quant", "oeh_gate_fwd", "oeh_minmax",
+    "oeh_attn_fwd", "oeh_softmax_rows", "oeh_fake_quant", "oeh_gate_fwd", "oeh_minmax", "oeh_percentile_ema", "oeh_fake_quant_range",
     "oeh_abi_version", "oeh_build_info", "oeh_strerror", "oeh_attn_variant",
 )
 
@@ -87,14 +89,19 @@ def load() -> C.CDLL:
     lib.oeh_gate_fwd.restype = C.c_int
     lib.oeh_minmax.argtypes = [vp, i64, i32, vp, vp]
     lib.oeh_minmax.restype = C.c_int
+    f64 = C.c_double
+    lib.oeh_percentile_ema.argtypes = [vp, i64, i32, f64, f64, f64, i32, vp, vp, vp]
+    lib.oeh_percentile_ema.restype = C.c_int
+    lib.oeh_fake_quant_range.argtypes = [vp, vp, i64, i32, vp, i32, f64, vp]
+    lib.oeh_fake_quant_range.restype = C.c_int
     lib.oeh_abi_version.restype = C.c_int
     lib.oeh_build_info.restype = C.c_char_p
     lib.oeh_strerror.argtypes = [C.c_int]
     lib.oeh_strerror.restype = C.c_char_p
     lib.oeh_attn_variant.argtypes = [C.POINTER(oeh_attn_desc), C.POINTER(oeh_fq_desc)]
     lib.oeh_attn_variant.restype = C.c_char_p
-    if lib.oeh_abi_version() != 2:
-        raise OehError(f"liboeh_hip.so ABI {lib.oeh_abi_version()} != 2 (stale build?)")
+    if lib.oeh_abi_version() != ABI_VERSION:
+        raise OehError(f"liboeh_hip.so ABI {lib.oeh_abi_version()} != {ABI_VERSION} (stale build?)")
     _lib = lib
     return lib
 

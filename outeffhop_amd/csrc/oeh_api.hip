@@ -25,6 +25,9 @@ int launch_fake_quant(const void* x, void* y, unsigned char* idx, long n, int in
 int launch_gate(const void* hidden, int in, int B, int T, int H, int d, long hs_b, long hs_t, const float* w1, const float* b1,
                 const float* w2, const float* b2, int m_units, int pool, float scaling, float* out, hipStream_t st);
 int launch_minmax(const void* x, long n, int in, float* out2, hipStream_t st);
+int launch_percentile_ema(const void* x, long n, int in, double q_lo, double q_hi, double momentum, int first, double* state, void* work,
+                          hipStream_t st);
+int launch_fake_quant_range(const void* x, void* y, long n, int in, const double* range, float qmax, double eps, hipStream_t st);
 }  // namespace oeh
 
 using oeh::AttnParams;
@@ -344,6 +347,21 @@ int oeh_gate_fwd(const void* hidden, int32_t dtype, int32_t B, int32_t T, int32_
 int oeh_minmax(const void* x, int64_t n, int32_t dtype, float* out2, void* stream) {
   if (x == nullptr || out2 == nullptr || n <= 0 || !dtype_ok(dtype)) return OEH_EINVAL;
   return oeh::launch_minmax(x, n, dtype, out2, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oeh_percentile_ema(const void* x, int64_t n, int32_t dtype, double q_lo, double q_hi, double momentum, int32_t first, double* state,
+                       void* work, void* stream) {
+  if (x == nullptr || state == nullptr || work == nullptr || n <= 0 || n >= (int64_t)1 << 32 || !dtype_ok(dtype)) return OEH_EINVAL;
+  if (!(q_lo >= 0.0 && q_lo <= 100.0 && q_hi >= 0.0 && q_hi <= 100.0) || !(momentum >= 0.0 && momentum <= 1.0)) return OEH_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(work) & 7) != 0 || (reinterpret_cast<uintptr_t>(state) & 7) != 0) return OEH_EALIGN;
+  return oeh::launch_percentile_ema(x, n, dtype, q_lo, q_hi, momentum, first ? 1 : 0, state, work, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oeh_fake_quant_range(const void* x, void* y, int64_t n, int32_t dtype, const double* xmin_xmax, int32_t n_bits, double eps,
+                         void* stream) {
+  if (x == nullptr || y == nullptr || xmin_xmax == nullptr || n < 0 || !dtype_ok(dtype) || n_bits < 1 || n_bits > 16 || !(eps > 0.0)) return OEH_EINVAL;
+  if (n == 0) return OEH_OK;
+  return oeh::launch_fake_quant_range(x, y, n, dtype, xmin_xmax, (float)((1 << n_bits) - 1), eps, reinterpret_cast<hipStream_t>(stream));
 }
 
 // Diagnostic hooks (NOT part of the ABI in include/oeh.h; process-global, not thread-safe; tools/ and tests only):

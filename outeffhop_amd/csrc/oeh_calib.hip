@@ -1,0 +1,221 @@
+// Calibration on the device: the RunningMinMaxEstimator with percentiles (range_estimators.py:83-106,
+// driven by pass_data_for_range_estimation, transformers_language/utils.py:50-71) without a device->host copy, a sort, or
+// a host synchronisation per quantiser and batch.
+//
+//   oeh_percentile_ema : lo = np.percentile(x, q_lo), hi = np.percentile(x, q_hi) - the two order statistics around each
+//                        rank by an exact radix selection (three histogram passes over the order-preserving integer image
+//                        of the floats: 12 + 12 + 8 bits, both tails in the same pass; a fourth pass finds the next larger
+//                        element), numpy's linear interpolation in float64, then the running average
+//                        state = first ? new : (1 - momentum) * new + momentum * state, all in device memory.
+//   oeh_fake_quant_range: the quantiser's forward in `estimate_ranges` mode: the grid (scale, zero point) is derived in the
+//                        kernel from the (x_min, x_max) pair in device memory exactly as set_quant_range does
+//                        (uniform_quantizers.py:72-82), so the host never reads the range while it is still moving.
+// The selection reads the tensor four times (a 50 M-element score tensor: ~0.2 ms) instead of sorting it.
+#include "oeh_common.h"
+
+namespace oeh {
+
+namespace {
+
+constexpr int kBins = 4096;
+// work buffer (uint32 words): [0, 4096) histogram of the low tail, [4096, 8192) of the high tail, then the selection state
+enum { W_HIST_LO = 0, W_HIST_HI = kBins, W_PREFIX_LO = 2 * kBins, W_PREFIX_HI, W_CNT_LE_LO, W_CNT_LE_HI, W_NEXT_LO, W_NEXT_HI, W_WORDS,
+       W_RANK = W_WORDS + (W_WORDS & 1) };  // two 64-bit remaining ranks behind the words (8-byte aligned)
+
+__device__ __forceinline__ unsigned f32_key(float v) {  // order-preserving: a < b  <=>  key(a) < key(b)
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(unsigned k) {
+  const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __builtin_bit_cast(float, u);
+}
+
+__global__ void calib_init_kernel(unsigned* work, unsigned long long rank_lo, unsigned long long rank_hi) {
+  for (int i = threadIdx.x; i < 2 * kBins; i += blockDim.x) work[i] = 0u;
+  if (threadIdx.x == 0) {
+    work[W_PREFIX_LO] = work[W_PREFIX_HI] = 0u;
+    work[W_CNT_LE_LO] = work[W_CNT_LE_HI] = 0u;
+    work[W_NEXT_LO] = work[W_NEXT_HI] = 0xffffffffu;
+    unsigned long long* rk = reinterpret_cast<unsigned long long*>(work + W_RANK);
+    rk[0] = rank_lo;
+    rk[1] = rank_hi;
+  }
+}
+
+// One histogram pass: digit = (key >> SHIFT) & (2^BITS - 1) of the elements whose higher bits equal the tail's prefix.
+template <int IN, int SHIFT, int BITS>
+__global__ __launch_bounds__(256) void calib_hist_kernel(const void* __restrict__ xin, long n, unsigned* work) {
+  typedef typename In<IN>::elem E;
+  const E* x = reinterpret_cast<const E*>(xin);
+  __shared__ unsigned h[2 * kBins];
+  constexpr unsigned MASK = (1u << BITS) - 1u;
+  constexpr bool FIRST = (SHIFT + BITS) >= 32;
+  for (int i = threadIdx.x; i < 2 * kBins; i += blockDim.x) h[i] = 0u;
+  __syncthreads();
+  const unsigned plo = work[W_PREFIX_LO], phi = work[W_PREFIX_HI];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const unsigned k = f32_key(In<IN>::to_f32(x[i]));
+    const unsigned d = (k >> SHIFT) & MASK;
+    if constexpr (FIRST) {
+      atomicAdd(&h[d], 1u);  // one histogram serves both tails in the first pass (no prefix yet)
+    } else {
+      const unsigned hi_bits = k >> (SHIFT + BITS);
+      if (hi_bits == plo) atomicAdd(&h[d], 1u);
+      if (hi_bits == phi) atomicAdd(&h[kBins + d], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (FIRST ? kBins : 2 * kBins); i += blockDim.x) {
+    const unsigned c = h[i];
+    if (c != 0u) {
+      atomicAdd(&work[i], c);
+      if (FIRST) atomicAdd(&work[kBins + i], c);
+    }
+  }
+}
+
+// One workgroup: walk each tail's histogram up to the remaining rank, extend the prefix by that digit, clear the histograms.
+template <int BITS>
+__global__ __launch_bounds__(256) void calib_scan_kernel(unsigned* work) {
+  __shared__ unsigned long long part[256];
+  constexpr int NB = 1 << BITS;
+  constexpr int PER = (NB + 255) / 256;
+  unsigned long long* rk = reinterpret_cast<unsigned long long*>(work + W_RANK);
+  for (int tail = 0; tail < 2; ++tail) {
+    unsigned* hist = work + (tail ? W_HIST_HI : W_HIST_LO);
+    unsigned long long mine = 0;
+    for (int j = 0; j < PER; ++j) {
+      const int bin = threadIdx.x * PER + j;
+      if (bin < NB) mine += hist[bin];
+    }
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long rank = rk[tail], cum = 0;
+      int t = 0;
+      while (t < 255 && cum + part[t] <= rank) cum += part[t++];
+      int bin = t * PER;
+      while (bin < NB - 1 && cum + hist[bin] <= rank) cum += hist[bin++];
+      work[tail ? W_PREFIX_HI : W_PREFIX_LO] = (work[tail ? W_PREFIX_HI : W_PREFIX_LO] << BITS) | (unsigned)bin;
+      rk[tail] = rank - cum;
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < 2 * kBins; i += blockDim.x) work[i] = 0u;
+}
+
+// With a = the selected element of each tail: how many elements are <= a, and the smallest element above a.
+template <int IN>
+__global__ __launch_bounds__(256) void calib_next_kernel(const void* __restrict__ xin, long n, unsigned* work) {
+  typedef typename In<IN>::elem E;
+  const E* x = reinterpret_cast<const E*>(xin);
+  const unsigned alo = work[W_PREFIX_LO], ahi = work[W_PREFIX_HI];
+  unsigned cle_lo = 0, cle_hi = 0, nx_lo = 0xffffffffu, nx_hi = 0xffffffffu;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const unsigned k = f32_key(In<IN>::to_f32(x[i]));
+    cle_lo += (k <= alo);
+    cle_hi += (k <= ahi);
+    if (k > alo) nx_lo = min(nx_lo, k);
+    if (k > ahi) nx_hi = min(nx_hi, k);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    cle_lo += __shfl_xor(cle_lo, o);
+    cle_hi += __shfl_xor(cle_hi, o);
+    nx_lo = min(nx_lo, (unsigned)__shfl_xor((int)nx_lo, o));
+    nx_hi = min(nx_hi, (unsigned)__shfl_xor((int)nx_hi, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (cle_lo) atomicAdd(&work[W_CNT_LE_LO], cle_lo);  // (counts fit 32 bits: n < 2^32 is checked by the host side)
+    if (cle_hi) atomicAdd(&work[W_CNT_LE_HI], cle_hi);
+    atomicMin(&work[W_NEXT_LO], nx_lo);
+    atomicMin(&work[W_NEXT_HI], nx_hi);
+  }
+}
+
+// numpy's linear interpolation between the order statistics a = x_(i), b = x_(i+1) of float32 data: the difference is
+// formed in float32, the interpolation in float64, anchored at b for frac >= 0.5 (numpy/lib/function_base.py: _lerp)
+__device__ double np_lerp(float a, float b, double frac) {
+  const double diff = (double)(b - a);
+  return frac >= 0.5 ? (double)b - diff * (1.0 - frac) : (double)a + diff * frac;
+}
+
+__global__ void calib_finish_kernel(const unsigned* work, unsigned long long i_lo, unsigned long long i_hi, double frac_lo, double frac_hi,
+                                    unsigned long long n, double momentum, int first, double* state) {
+  const float a_lo = key_f32(work[W_PREFIX_LO]), a_hi = key_f32(work[W_PREFIX_HI]);
+  // x_(i+1): still a when more than i + 1 elements are <= a; the next larger element otherwise (a itself at the very top)
+  const float b_lo = (i_lo + 1 >= n || (unsigned long long)work[W_CNT_LE_LO] >= i_lo + 2) ? a_lo : key_f32(work[W_NEXT_LO]);
+  const float b_hi = (i_hi + 1 >= n || (unsigned long long)work[W_CNT_LE_HI] >= i_hi + 2) ? a_hi : key_f32(work[W_NEXT_HI]);
+  const double lo = np_lerp(a_lo, b_lo, frac_lo), hi = np_lerp(a_hi, b_hi, frac_hi);
+  if (first) {
+    state[0] = lo;
+    state[1] = hi;
+  } else {  // range_estimators.py:101-104
+    state[0] = (1.0 - momentum) * lo + momentum * state[0];
+    state[1] = (1.0 - momentum) * hi + momentum * state[1];
+  }
+}
+
+template <int IN>
+void launch_passes(const void* x, long n, unsigned* work, unsigned blocks, hipStream_t st) {
+  hipLaunchKernelGGL((calib_hist_kernel<IN, 20, 12>), dim3(blocks), dim3(256), 0, st, x, n, work);
+  hipLaunchKernelGGL((calib_scan_kernel<12>), dim3(1), dim3(256), 0, st, work);
+  hipLaunchKernelGGL((calib_hist_kernel<IN, 8, 12>), dim3(blocks), dim3(256), 0, st, x, n, work);
+  hipLaunchKernelGGL((calib_scan_kernel<12>), dim3(1), dim3(256), 0, st, work);
+  hipLaunchKernelGGL((calib_hist_kernel<IN, 0, 8>), dim3(blocks), dim3(256), 0, st, x, n, work);
+  hipLaunchKernelGGL((calib_scan_kernel<8>), dim3(1), dim3(256), 0, st, work);
+  hipLaunchKernelGGL((calib_next_kernel<IN>), dim3(blocks), dim3(256), 0, st, x, n, work);
+}
+
+}  // namespace
+
+int launch_percentile_ema(const void* x, long n, int in, double q_lo, double q_hi, double momentum, int first, double* state, void* workv,
+                          hipStream_t st) {
+  unsigned* work = static_cast<unsigned*>(workv);
+  // np.percentile, method "linear": virtual index h = (n - 1) q / 100, i = floor(h), frac = h - i
+  const double h_lo = (double)(n - 1) * (q_lo / 100.0), h_hi = (double)(n - 1) * (q_hi / 100.0);
+  const unsigned long long i_lo = (unsigned long long)h_lo, i_hi = (unsigned long long)h_hi;
+  const double f_lo = h_lo - (double)i_lo, f_hi = h_hi - (double)i_hi;
+  const unsigned blocks = (unsigned)((n + 256L * 16 - 1) / (256L * 16) < 2048 ? (n + 256L * 16 - 1) / (256L * 16) : 2048);
+  hipLaunchKernelGGL(calib_init_kernel, dim3(1), dim3(256), 0, st, work, i_lo, i_hi);
+  switch (in) {
+    case IN_F16: launch_passes<IN_F16>(x, n, work, blocks, st); break;
+    case IN_BF16: launch_passes<IN_BF16>(x, n, work, blocks, st); break;
+    default: launch_passes<IN_F32>(x, n, work, blocks, st); break;
+  }
+  hipLaunchKernelGGL(calib_finish_kernel, dim3(1), dim3(1), 0, st, work, i_lo, i_hi, f_lo, f_hi, (unsigned long long)n, momentum, first, state);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// ---- fake-quant with the grid derived from a device-resident (x_min, x_max) pair
+template <int IN>
+__global__ __launch_bounds__(256) void fake_quant_range_kernel(const void* __restrict__ xin, void* __restrict__ yout, long n, const double* range,
+                                                               float qmax, double eps) {
+  typedef typename In<IN>::elem E;
+  // set_quant_range (uniform_quantizers.py:72-82): x_min <= 0 <= eps <= x_max, delta = (x_max - x_min) / qmax, zero = -x_min / delta
+  const double x_min = fmin(range[0], 0.0), x_max = fmax(range[1], eps);
+  const double delta = (x_max - x_min) / (double)qmax;
+  const double zero = -x_min / delta;
+  FqP f;
+  f.scale = (float)fmax(delta, eps);
+  f.rscale = 1.0f / f.scale;
+  f.zp = (float)fmin(fmax(rint(zero), 0.0), (double)qmax);
+  f.lo = -f.zp;
+  f.hi = qmax - f.zp;
+  const E* x = reinterpret_cast<const E*>(xin);
+  E* y = reinterpret_cast<E*>(yout);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = In<IN>::from_f32(f.scale * fq_rel(In<IN>::to_f32(x[i]), f));
+}
+
+int launch_fake_quant_range(const void* x, void* y, long n, int in, const double* range, float qmax, double eps, hipStream_t st) {
+  const unsigned blocks = (unsigned)((n + 256L * 8 - 1) / (256L * 8) < 4096 ? (n + 256L * 8 - 1) / (256L * 8) : 4096);
+  switch (in) {
+    case IN_F16: hipLaunchKernelGGL(fake_quant_range_kernel<IN_F16>, dim3(blocks), dim3(256), 0, st, x, y, n, range, qmax, eps); break;
+    case IN_BF16: hipLaunchKernelGGL(fake_quant_range_kernel<IN_BF16>, dim3(blocks), dim3(256), 0, st, x, y, n, range, qmax, eps); break;
+    default: hipLaunchKernelGGL(fake_quant_range_kernel<IN_F32>, dim3(blocks), dim3(256), 0, st, x, y, n, range, qmax, eps); break;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+}  // namespace oeh

@@ -324,6 +324,44 @@ def fake_quant(x: torch.Tensor, spec: FakeQuantSpec, want_idx: bool = False):
     return (y, idx) if want_idx else y
 
 
+_calib_work = {}  # device index -> scratch buffer of the on-device percentile selection
+
+
+def percentile_ema(x: torch.Tensor, q_lo: float, q_hi: float, state: torch.Tensor, momentum: float = 0.9, first: bool = False) -> torch.Tensor:
+    """(np.percentile(x, q_lo), np.percentile(x, q_hi)) blended into `state` (float64[2] on x's GPU) with the running average of
+    RunningMinMaxEstimator (range_estimators.py:101-104), without leaving the device: `include/oeh.h: oeh_percentile_ema`."""
+    dev = _need_gpu(x, state)
+    if x.dtype not in _DT:
+        raise ValueError(f"unsupported dtype {x.dtype}")
+    if state.dtype != torch.float64 or state.numel() != 2 or not state.is_contiguous():
+        raise ValueError("state must be a contiguous float64 tensor of 2 elements")
+    xc = x.detach().contiguous()
+    work = _calib_work.get(dev.index)
+    if work is None:
+        work = _calib_work[dev.index] = torch.empty(_lib.CALIB_WORK_BYTES // 8, dtype=torch.int64, device=dev)
+    with _on_device(dev):
+        rc = _lib.load().oeh_percentile_ema(_ptr(xc), xc.numel(), _DT[x.dtype], float(q_lo), float(q_hi), float(momentum), int(bool(first)),
+                                            _ptr(state), _ptr(work), _stream())
+    _lib.check(rc, "oeh_percentile_ema")
+    return state
+
+
+def fake_quant_range(x: torch.Tensor, xmin_xmax: torch.Tensor, n_bits: int = 8, eps: float = 1e-8) -> torch.Tensor:
+    """Fake-quant with the grid derived on the device from a float64 (x_min, x_max) pair (`oeh_fake_quant_range`): the
+    quantiser's forward while its range is still being estimated, without a host read of the range."""
+    dev = _need_gpu(x, xmin_xmax)
+    if x.dtype not in _DT:
+        raise ValueError(f"unsupported dtype {x.dtype}")
+    if xmin_xmax.dtype != torch.float64 or xmin_xmax.numel() != 2 or not xmin_xmax.is_contiguous():
+        raise ValueError("xmin_xmax must be a contiguous float64 tensor of 2 elements")
+    xc = x.contiguous()
+    y = torch.empty_like(xc)
+    with _on_device(dev):
+        rc = _lib.load().oeh_fake_quant_range(_ptr(xc), _ptr(y), xc.numel(), _DT[x.dtype], _ptr(xmin_xmax), int(n_bits), float(eps), _stream())
+    _lib.check(rc, "oeh_fake_quant_range")
+    return y
+
+
 def gate_fwd(hidden: torch.Tensor, H: int, w1: torch.Tensor, b1: torch.Tensor, w2: Optional[torch.Tensor] = None,
              b2: Optional[torch.Tensor] = None, per_head_pool: bool = False, scaling: float = 1.0) -> torch.Tensor:
     """Per-head gate predictors on the module input (bert_attention.py:301-327).  hidden (B,T,H*d);

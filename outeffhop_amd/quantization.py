@@ -242,10 +242,24 @@ class RangeEstimatorBase(nn.Module):
         self.register_buffer("current_xmax", None)
         self.per_channel = per_channel
         object.__setattr__(self, "quantizer", quantizer)  # not a submodule (keeps state-dict keys like the reference's repr)
+        # GPU tensors with a percentile: the (x_min, x_max) pair lives in ONE float64[2] device tensor that the HIP selection
+        # kernel updates in place (ops.percentile_ema); current_xmin / current_xmax are snapshots of it.  Not a buffer: the
+        # state dict keeps the reference's keys.
+        self.device_state = None
 
     def reset(self):
         self.current_xmin = None
         self.current_xmax = None
+        self.device_state = None
+
+    def _percentile_on_device(self, x, q_lo, q_hi, momentum):
+        """(np.percentile(x, q_lo), np.percentile(x, q_hi)) [+ running average] without leaving the GPU: no topk, no host sync."""
+        first = self.device_state is None or self.device_state.device != x.device
+        if first:
+            self.device_state = torch.empty(2, dtype=torch.float64, device=x.device)
+        ops.percentile_ema(x, q_lo, q_hi, self.device_state, momentum=momentum, first=first or momentum is None)
+        self.current_xmin, self.current_xmax = self.device_state[0].clone(), self.device_state[1].clone()
+        return self.current_xmin, self.current_xmax
 
 
 class CurrentMinMaxEstimator(RangeEstimatorBase):
@@ -254,6 +268,9 @@ class CurrentMinMaxEstimator(RangeEstimatorBase):
         super().__init__(*args, **kwargs)
 
     def forward(self, x):
+        if self.percentile and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16, torch.float32):
+            self.device_state = None  # no running average: every call starts over
+            return self._percentile_on_device(x, self.percentile, 100 - self.percentile, 0.0)
         if self.percentile:
             lo, hi = percentile_pair(x, self.percentile, 100 - self.percentile)
             self.current_xmin = torch.tensor(lo).to(x.device)
@@ -271,6 +288,9 @@ class RunningMinMaxEstimator(RangeEstimatorBase):
         super().__init__(*args, **kwargs)
 
     def forward(self, x):
+        if self.percentile and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16, torch.float32) and \
+                (self.current_xmin is None or self.device_state is not None):
+            return self._percentile_on_device(x, 100 - self.percentile, self.percentile, self.momentum)
         if self.percentile:
             lo, hi = percentile_pair(x, 100 - self.percentile, self.percentile)
             x_min, x_max = torch.tensor(lo).to(x.device), torch.tensor(hi).to(x.device)  # float64, like the reference
@@ -364,6 +384,11 @@ class QuantizationManager(nn.Module):
     def forward(self, x):
         if not self.is_fixed:
             self.set_quant_range(*self.range_estimator(x))
+            st = getattr(self.range_estimator, "device_state", None)
+            if st is not None and x.is_cuda and type(self.quantizer) is AsymmetricUniformQuantizer:
+                # the range is still moving: quantise with the grid derived on the device from the estimator's float64 pair
+                # (the same arithmetic as set_quant_range above) instead of reading it back for a host-side descriptor
+                return ops.fake_quant_range(x, st, self.quantizer.n_bits, self.quantizer.eps)
         return self.quantizer(x)
 
     def extra_repr(self):

@@ -36,7 +36,7 @@ def test_library_loads_and_exports_every_symbol():
     if out is not None and out.returncode == 0:
         exported = {ln.split()[-1] for ln in out.stdout.splitlines() if " T " in ln}
         assert set(_declared()) <= exported
-    assert lib.oeh_abi_version() == 2
+    assert lib.oeh_abi_version() == 3
     assert b"gfx950" in lib.oeh_build_info()
     assert lib.oeh_strerror(-22) == b"invalid argument"
 
@@ -56,6 +56,11 @@ def test_argument_validation_without_gpu():
     assert lib.oeh_softmax_rows(one, one, 4, 0, 0, 1, 0, 0.0, 1.0, None) == -22
     assert lib.oeh_fake_quant(one, one, None, 4, 0, 0.0, 0.0, 255.0, None) == -22  # scale must be > 0
     assert lib.oeh_fake_quant(one, one, one, 4, 0, 1.0, 0.0, 1023.0, None) == -95  # uint8 dump of a 10-bit grid
+    assert lib.oeh_percentile_ema(one, 0, 2, 0.001, 99.999, 0.9, 1, one, one, None) == -22  # empty tensor
+    assert lib.oeh_percentile_ema(one, 8, 2, 0.001, 100.5, 0.9, 1, one, one, None) == -22  # percent out of range
+    assert lib.oeh_percentile_ema(one, 8, 2, 0.001, 99.999, 0.9, 1, C.c_void_p(20), one, None) == -14  # state not 8-byte aligned
+    assert lib.oeh_fake_quant_range(one, one, 8, 2, None, 8, 1e-8, None) == -22
+    assert lib.oeh_fake_quant_range(one, one, 8, 2, one, 0, 1e-8, None) == -22  # n_bits
 
 
 def test_variant_selection_host_only():

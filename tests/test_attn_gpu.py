@@ -794,3 +794,156 @@ def test_small_shape_kernel_stanhop(ops, dtype):
     qu = buf[:, :, 3:].view(300, 28, 4, 16).permute(0, 2, 1, 3)
     want = O.attn_core(_np32(qu), _np32(qu), _np32(qu), scale=0.25, **SPECS["softmax1"])
     _check(ops.attn_fwd(qu, qu, qu, scale=0.25), want, tol, msg="unaligned")
+
+
+def _check_fp16_contract(got, want, msg):
+    """north_star: "within 1e-3 fp16".  Stated without a relative fudge: |hip - ref| <= 1e-3 wherever one fp16 ulp of the
+    reference value is below 1e-3 (|ref| < 2), and <= one fp16 ulp of the reference value above (the output is STORED in
+    fp16: ulp(2.0) = 1.95e-3 is the best any fp16 result can do there)."""
+    got = _np32(got) if hasattr(got, "detach") else got
+    ulp = np.spacing(np.abs(want).astype(np.float16)).astype(np.float32)
+    lim = np.maximum(np.float32(1e-3), ulp)
+    err = np.abs(got - want)
+    assert np.isfinite(got).all() and (err <= lim).all(), f"{msg}: max abs err {err.max():.3e}, worst excess {float((err - lim).max()):.3e}"
+    return float(err.max())
+
+
+def test_full_size_bert_softmax1_cfg2(ops):
+    """BASELINE config 2 at full size: BERT-base B=32 S=128 H=12 d=64 fp16, key-padding mask, softmax1.  Properties: a padded
+    key never matters (bitwise), a sample's rows do not depend on its batch neighbours (bitwise), row sums < 1; oracle slices."""
+    B, H, S, D = 32, 12, 128, 64
+    fmin = float(np.finfo(np.float32).min)
+    view = lambda t: t.cuda().view(B, S, H, D).permute(0, 2, 1, 3)  # noqa: E731
+    q, k, v = view(_rand((B, S, H * D), 1234)), view(_rand((B, S, H * D), 1235)), view(_rand((B, S, H * D), 1236))
+    lens = torch.randint(64, 129, (B,), generator=torch.Generator().manual_seed(1237)).tolist()
+    padm = _pad_mask(B, S, lens, fmin)
+    pad = torch.from_numpy(padm).cuda()
+    kw = dict(scale_div=8.0, key_pad_mask=pad, mask_min=fmin)
+    out = ops.attn_fwd(q, k, v, **kw)
+    k2, v2 = k.clone(), v.clone()
+    for b, n in enumerate(lens):
+        k2[b, :, n:] = 9.0
+        v2[b, :, n:] = -5.0
+    assert torch.equal(ops.attn_fwd(q, k2, v2, **kw), out)
+    assert torch.equal(ops.attn_fwd(q[5:9], k[5:9], v[5:9], scale_div=8.0, key_pad_mask=pad[5:9], mask_min=fmin), out[5:9])
+    rowsum = ops.attn_fwd(q, k, torch.ones_like(v), **kw).float()
+    assert 0.0 < float(rowsum.min()) and float(rowsum.max()) < 1.0 + 1e-3
+    worst = 0.0
+    for (b, h) in ((0, 0), (17, 5), (31, 11)):
+        want = O.attn_core(_np32(q[b:b + 1, h:h + 1]), _np32(k[b:b + 1, h:h + 1]), _np32(v[b:b + 1, h:h + 1]), scale=8.0, scale_is_divisor=True,
+                           pad_mask=padm[b:b + 1], **SPECS["softmax1"])
+        worst = max(worst, _check_fp16_contract(out[b:b + 1, h:h + 1], want, f"cfg2 slice {(b, h)}"))
+    print(f"cfg2 full size: max abs err on oracle slices {worst:.2e}")
+
+
+@pytest.mark.parametrize("sm", ["softmax1", "clippedsoftmax1(-.025:1)"])
+def test_full_size_opt_cfg3(ops, sm):
+    """BASELINE config 3 (and the headline) at full size: OPT-125m B=16 S=512 fp16 causal, clippedsoftmax1(-.025:1) / softmax1:
+    causality (bitwise), batch-shard invariance (bitwise), V = 1 gives row sums in [0, 1]; oracle slices under the stated
+    1e-3 fp16 contract (no relative term below |ref| = 2)."""
+    B, H, S, D = 16, 12, 512, 64
+    fmin = float(np.finfo(np.float32).min)
+    q = (_rand((B, H, S, D), 201).float() * 0.125).half().cuda()
+    k, v = _rand((B, H, S, D), 202).cuda(), _rand((B, H, S, D), 203).cuda()
+    kw = dict(softmax=_spec(ops, sm), causal=True, clamp_min=True, mask_min=fmin)
+    out = ops.attn_fwd(q, k, v, **kw)
+    k3, v3 = k.clone(), v.clone()
+    k3[:, :, 257:] = 7.0
+    v3[:, :, 257:] = -3.0
+    assert torch.equal(ops.attn_fwd(q, k3, v3, **kw)[:, :, :257], out[:, :, :257])
+    assert torch.equal(ops.attn_fwd(q[2:4], k[2:4], v[2:4], **kw), out[2:4])
+    rowsum = ops.attn_fwd(q, k, torch.ones_like(v), **kw).float()
+    assert float(rowsum.min()) >= 0.0 and float(rowsum.max()) < 1.0 + 2e-3
+    worst = 0.0
+    for (b, h) in ((0, 0), (7, 3), (15, 11)):
+        want = O.attn_core(_np32(q[b:b + 1, h:h + 1]), _np32(k[b:b + 1, h:h + 1]), _np32(v[b:b + 1, h:h + 1]), causal=True, clamp_min=True, **SPECS[sm])
+        worst = max(worst, _check_fp16_contract(out[b:b + 1, h:h + 1], want, f"cfg3 {sm} slice {(b, h)}"))
+    print(f"cfg3 {sm} full size: max abs err on oracle slices {worst:.2e}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_full_size_opt_int8_cfg4(ops, dtype):
+    """BASELINE config 4 at full size, fp16 and fp32 storage: OPT-125m softmax1 + the three 8-bit activation quantisers.
+    Properties: every output sits exactly on the context quantiser's grid and inside its range; causality and batch-shard
+    invariance bitwise; the production kernel equals the index-dump kernel bitwise on a slice; index dumps of that slice
+    against the oracle (<= 1 step, <= 1e-4 of a tensor)."""
+    B, H, S, D = 16, 12, 512, 64
+    fmin = float(np.finfo(np.float32).min)
+    q = (_rand((B, H, S, D), 301, dtype=torch.float32) * 0.125).to(dtype).cuda()
+    k, v = _rand((B, H, S, D), 302, dtype=torch.float32).to(dtype).cuda(), _rand((B, H, S, D), 303, dtype=torch.float32).to(dtype).cuda()
+    common = dict(base=1, causal=True, clamp_min=True)
+    sl = (slice(3, 4), slice(5, 7))  # calibrate on the oracle's FP intermediates of one slice (percentile 99.999, validate_clm.py:450-454)
+    qs, ks, vs = q[sl], k[sl], v[sl]
+    ctx_fp, fp = O.attn_core(_np32(qs), _np32(ks), _np32(vs), want=("scores", "probs"), **common)
+    d_s = O.quant_range_to_params(*np.percentile(fp["scores"], (0.001, 99.999)))
+    d_p = O.quant_range_to_params(*np.percentile(fp["probs"], (0.001, 99.999)))
+    d_c = O.quant_range_to_params(*np.percentile(ctx_fp, (0.001, 99.999)))
+    FQ = ops.FakeQuantSpec.from_delta
+    fq = ops.AttnFakeQuant(FQ(*d_s), FQ(*d_p), FQ(*d_c), ctx_before_gate=True)
+    kw = dict(causal=True, clamp_min=True, mask_min=fmin)
+    assert ops.attn_variant(B, H, S, S, D, dtype, fq=True, causal=True).startswith("fast16/")
+    out = ops.attn_fwd(q, k, v, fq=fq, **kw)
+    grid = FQ(*d_c)
+    idx = out.float() / grid.scale + grid.zero_point
+    assert float((idx - idx.round()).abs().max()) < 2e-2 if dtype == torch.float16 else float((idx - idx.round()).abs().max()) < 1e-4
+    assert float(idx.round().min()) >= 0.0 and float(idx.round().max()) <= 255.0
+    k3, v3 = k.clone(), v.clone()
+    k3[:, :, 300:] = 7.0
+    v3[:, :, 300:] = -3.0
+    assert torch.equal(ops.attn_fwd(q, k3, v3, fq=fq, **kw)[:, :, :300], out[:, :, :300])
+    assert torch.equal(ops.attn_fwd(q[8:10], k[8:10], v[8:10], fq=fq, **kw), out[8:10])
+    dumps = [torch.zeros((1, 2, S, S), dtype=torch.uint8, device="cuda"), torch.zeros((1, 2, S, S), dtype=torch.uint8, device="cuda"),
+             torch.zeros((1, 2, S, D), dtype=torch.uint8, device="cuda")]
+    fqd = ops.AttnFakeQuant(FQ(*d_s, dump=dumps[0]), FQ(*d_p, dump=dumps[1]), FQ(*d_c, dump=dumps[2]), ctx_before_gate=True)
+    assert torch.equal(ops.attn_fwd(qs, ks, vs, fq=fqd, **kw), out[sl])
+    want, ex = O.attn_core(_np32(qs), _np32(ks), _np32(vs), fq_scores=d_s, fq_probs=d_p, fq_ctx=d_c, ctx_quant_before_gate=True,
+                           want=("scores_idx", "probs_idx", "ctx_idx"), **common)
+    tri = np.tril(np.ones((S, S), dtype=bool))[None, None]
+    rates = {}
+    for name, dmp in zip(("scores", "probs", "ctx"), dumps):
+        a, b_ = dmp.cpu().numpy().astype(np.int32), ex[f"{name}_idx"].astype(np.int32)
+        sel = np.broadcast_to(tri, a.shape) if name != "ctx" else np.ones_like(a, dtype=bool)
+        d = np.abs(a[sel] - b_[sel])
+        rates[name] = float((d != 0).mean())
+        assert d.max() <= 1 and rates[name] <= 1e-4, f"{name}: max index diff {d.max()}, flip rate {rates[name]:.2e}"
+    err = np.abs(_np32(out[sl]) - want)
+    assert err.max() <= 1.01 * float(grid.scale) + 1e-3
+    print(f"cfg4 {dtype} full size: index flip rates vs the oracle {rates}, max abs err {err.max():.2e}")
+
+
+def test_full_size_bert_gated_cfg5(ops):
+    """BASELINE config 5, one GPU's share at full size: BERT-base gated (conditional per-token gate, per-head MLP 64->16->1 on
+    the layer input, evaluated inside the kernel), B=256 split 8 x 32: the shard of 32 samples.  Properties: a shard's rows
+    are bit-identical whichever batch they are computed in (what makes the 8-GPU split exact), the gate the kernel reports
+    is a probability and agrees with the stand-alone gate kernel; oracle slices with the oracle's own gate."""
+    B, H, S, D = 32, 12, 128, 64
+    fmin = float(np.finfo(np.float32).min)
+    view = lambda t: t.cuda().view(B, S, H, D).permute(0, 2, 1, 3)  # noqa: E731
+    q, k, v = view(_rand((B, S, H * D), 1240)), view(_rand((B, S, H * D), 1241)), view(_rand((B, S, H * D), 1242))
+    hidden = _rand((B, S, H * D), 1243).cuda()
+    g = torch.Generator().manual_seed(1244)
+    w1, b1 = (torch.randn((H, 16, D), generator=g) * 0.1).cuda(), (torch.randn((H, 16), generator=g) * 0.1).cuda()
+    w2, b2 = (torch.randn((H, 16), generator=g) * 0.5).cuda(), torch.full((H,), float(O.logit(0.25))).cuda()
+    lens = torch.randint(64, 129, (B,), generator=g).tolist()
+    padm = _pad_mask(B, S, lens, fmin)
+    pad = torch.from_numpy(padm).cuda()
+    gp = ops.GatePredictor(hidden, w1, b1, w2, b2, scaling=1.0, out=torch.empty((B, H, S), dtype=torch.float32, device="cuda"))
+    out = ops.attn_fwd(q, k, v, scale_div=8.0, key_pad_mask=pad, mask_min=fmin, gate_mlp=gp)
+    assert ops.fused_gate_ok(B, H, S, S, D, torch.float16, units=16, key_pad=True, scale_div=8.0)
+    gate = gp.out.clone()
+    assert 0.0 < float(gate.min()) and float(gate.max()) < 1.0
+    sep = ops.gate_fwd(hidden, H, w1, b1, w2, b2, scaling=1.0)[..., 0]
+    assert float((gate - sep).abs().max()) < 2e-3  # first layer on the matrix cores with fp16-rounded weights
+    # shard invariance: samples 8..15 computed alone
+    gp2 = ops.GatePredictor(hidden[8:16], w1, b1, w2, b2, scaling=1.0, out=torch.empty((8, H, S), dtype=torch.float32, device="cuda"))
+    out2 = ops.attn_fwd(q[8:16], k[8:16], v[8:16], scale_div=8.0, key_pad_mask=pad[8:16], mask_min=fmin, gate_mlp=gp2)
+    assert torch.equal(out2, out[8:16]) and torch.equal(gp2.out, gate[8:16])
+    params = dict(w1=w1.cpu().numpy(), b1=b1.cpu().numpy(), w2=w2.cpu().numpy(), b2=b2.cpu().numpy())
+    worst = 0.0
+    for (b, h) in ((0, 0), (20, 7)):
+        gv = gate[b:b + 1, h:h + 1].cpu().numpy()[..., None]  # the gate the kernel applied (its own accuracy is checked above)
+        want = O.attn_core(_np32(q[b:b + 1, h:h + 1]), _np32(k[b:b + 1, h:h + 1]), _np32(v[b:b + 1, h:h + 1]), scale=8.0, scale_is_divisor=True,
+                           pad_mask=padm[b:b + 1], gate=gv, **SPECS["softmax1"])
+        worst = max(worst, _check_fp16_contract(out[b:b + 1, h:h + 1], want, f"cfg5 slice {(b, h)}"))
+    del params
+    print(f"cfg5 full size (one GPU's 32 samples): max abs err on oracle slices {worst:.2e}")

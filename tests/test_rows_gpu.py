@@ -101,3 +101,44 @@ def test_minmax(ops):
     assert got[0] == -123.5 and got[1] == 77.25
     got = ops.minmax(x.half().cuda()).cpu().numpy()
     assert got[0] == -123.5 and got[1] == 77.25
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_percentile_ema_on_device_equals_numpy(ops, dtype):
+    """SURVEY 8f-2 / VERDICT r1 #9: the percentile range statistics (range_estimators.py:83-106) by exact radix selection on
+    the GPU, numpy's interpolation in float64, running average in device memory - against np.percentile itself, bit for bit,
+    on heavy ties, tiny tensors, all-equal data, negative-only data and ranks that fall between distinct values."""
+    g = torch.Generator().manual_seed(5)
+    cases = [torch.randn(1000003, generator=g) * 3.0, torch.randn(70001, generator=g).round(),  # heavy ties
+             torch.full((4097,), -2.5), -torch.rand(50000, generator=g) - 1.0, torch.randn(7, generator=g), torch.randn(1, generator=g),
+             torch.cat([torch.zeros(100000), torch.randn(33, generator=g) * 100.0]), torch.randn(2, 12, 256, 256, generator=g)]
+    for n, x in enumerate(cases):
+        x = x.to(dtype)
+        ref = x.float().numpy().reshape(-1)
+        for (qlo, qhi) in ((0.001, 99.999), (1.0, 99.0), (0.0, 100.0), (50.0, 50.0)):
+            want = np.percentile(ref, (qlo, qhi))
+            st = torch.zeros(2, dtype=torch.float64, device="cuda")
+            ops.percentile_ema(x.cuda(), qlo, qhi, st, first=True)
+            got = st.cpu().numpy()
+            assert got.dtype == np.float64 and np.array_equal(got, want), (n, dtype, qlo, qhi, got, want)
+    # the running average over four batches: the reference's trajectory (golden, float64)
+    gold = load_golden("range_estimators.npz")
+    st = torch.zeros(2, dtype=torch.float64, device="cuda")
+    for i in range(4):
+        ops.percentile_ema(torch.from_numpy(gold[f"batch{i}"]).cuda(), 100 - 99.999, 99.999, st, momentum=0.9, first=(i == 0))
+        np.testing.assert_allclose(st.cpu().numpy(), gold["running_pct_traj"][i][:2], rtol=1e-15, atol=0)
+
+
+def test_fake_quant_with_a_device_resident_range(ops):
+    """oeh_fake_quant_range derives the grid in the kernel from a float64 (x_min, x_max) pair exactly as set_quant_range does:
+    same bits as the host-descriptor path (FakeQuantSpec.from_delta of the same range)."""
+    g = torch.Generator().manual_seed(6)
+    for (lo, hi) in ((-3.2187, 4.000123), (0.0, 0.99871), (-7.5, -1.0), (0.25, 9.0), (-1e-12, 1e-12)):
+        for dtype in (torch.float32, torch.float16):
+            x = (torch.randn(100000, generator=g) * 3.0).to(dtype).cuda()
+            rng = torch.tensor([lo, hi], dtype=torch.float64, device="cuda")
+            got = ops.fake_quant_range(x, rng, 8, 1e-8)
+            x_min, x_max = min(lo, 0.0), max(hi, 1e-8)
+            delta = (x_max - x_min) / 255.0
+            want = ops.fake_quant(x, ops.FakeQuantSpec.from_delta(delta, -x_min / delta, 8, 1e-8))
+            assert torch.equal(got, want), (lo, hi, dtype)
