@@ -75,7 +75,9 @@ def test_variant_selection_host_only():
     assert ops.attn_variant(2, 6, 197, 197, 64, torch.bfloat16, clip=True) == "fast16/NT16/D64/bf16/clip"
     assert ops.attn_variant(16, 12, 512, 512, 64, fq=True) == "fast16/NT32/D64/f16/fq"
     assert ops.attn_variant(4, 1, 64, 64, 32, torch.float32, fq=True) == "fast16/NT8/D32/f32/fq"
-    assert ops.attn_variant(3, 4, 7, 5, 16) == "generic"
+    assert ops.attn_variant(3, 4, 7, 5, 16) == "small/ST2/D16/f16"          # STanHop-sized: one wave per (batch, head)
+    assert ops.attn_variant(224, 4, 28, 28, 64, torch.float32) == "small/ST2/D64/f32"
+    assert ops.attn_variant(3, 4, 7, 5, 48) == "generic"
     assert ops.attn_variant(1, 1, 8, 100000, 64, torch.float32) == "flash16/MQ1/D64/f32"  # fp32 rows of any length: one-pass kernel
     assert ops.attn_variant(1, 1, 8, 100000, 64, torch.float32, clip=True) is None
 
