@@ -42,6 +42,11 @@ WORKLOADS = {
                               desc="OPT-125m attention core B=16 H=12 S=512 d=64 fp32 storage causal softmax1"),
     "opt_int8_fp32": dict(B=16, H=12, S=512, d=64, order="opt", sm=(1, False, 0.0, 1.0), int8=True, gate=False, fp32=True,
                           desc="OPT-125m attention core B=16 H=12 S=512 d=64 fp32 storage causal softmax1 + 3 fused INT8 fake-quantisers"),
+    # the same INT8 configuration with q, k, v STORED as the 8-bit indices the reference's QuantLinear projections
+    # put them on (hijacker.py:78-127), v transposed: both products on the integer matrix cores, fp32 output (validate precision)
+    "opt_int8_i8": dict(B=16, H=12, S=512, d=64, order="opt", sm=(1, False, 0.0, 1.0), int8=True, gate=False, i8=True,
+                        desc="OPT-125m attention core B=16 H=12 S=512 d=64 causal softmax1, q/k/v as int8 indices of 8-bit grids (v transposed), "
+                             "both products on v_mfma_i32_16x16x64_i8, 3 fused INT8 quantisers, fp32 output"),
     # STanHop's Association (cross_models/hopfield.py:42-51): B*data_dim = 32*7 series, L = S = 28 segments, H = 4, E = 64, fp32
     "stanhop": dict(B=224, H=4, S=28, d=64, order="none", sm=(1, False, 0.0, 1.0), int8=False, gate=False, fp32=True, layers=48,
                     desc="STanHop Association B*data_dim=224 L=S=28 H=4 E=64 fp32 softmax1, (B,L,H,E) layout: one wave per (batch, head)"),
@@ -261,7 +266,7 @@ def main():
     # ---- synthetic inputs, resident in HBM before the timed region; one buffer set per layer.  Per-rank data come from a
     # generator seeded with the rank (so that rank 0 can regenerate any rank's shard for the parity check); the gate
     # predictor weights are replicated (one seed for all ranks).
-    sdt = torch.float32 if w.get("fp32") else torch.float16
+    sdt = torch.float32 if (w.get("fp32") or w.get("i8")) else torch.float16  # (i8: the dtype of o)
 
     def gen_layers(r, n_layers):
         """CPU tensors of rank r's first n_layers layers: [(q, k, v, gate_in | None)], (B,S,E) fp16 values."""
@@ -288,11 +293,21 @@ def main():
         return pad_
 
     view = lambda t: t.to(dev).to(sdt).view(B, S, H, d).permute(0, 2, 1, 3)  # noqa: E731  (B,H,S,d) view of (B,S,E)
+    I8_GRIDS = ((0.03 * d ** -0.5, 131.0), (0.035, 124.0), (0.03, 128.0))  # (scale, zero point) of q (OPT's scaling folded in), k, v
+
+    def view_i8(t, undo=1.0, transpose=False):
+        """Synthetic INT8 storage: the centred index idx - 128 a unit-variance projection lands on with a grid step of 0.03."""
+        c_ = torch.clamp(torch.round(t.float().to(dev) * (undo / 0.03)), -128, 127).to(torch.int8).view(B, S, H, d)
+        return c_.permute(0, 2, 3, 1).contiguous() if transpose else c_.permute(0, 2, 1, 3)  # v: (B,H,d,S), keys contiguous
+
     sets = []
     gate_in = [] if w["gate"] else None
     for q, k, v, gi in gen_layers(rank, L):
         o = torch.empty(B, S, H, d, dtype=sdt, device=dev).permute(0, 2, 1, 3)
-        sets.append((view(q), view(k), view(v), o))
+        if w.get("i8"):
+            sets.append((view_i8(q, undo=d ** 0.5), view_i8(k), view_i8(v, transpose=True), o))
+        else:
+            sets.append((view(q), view(k), view(v), o))
         if gi is not None:
             gate_in.append(gi.to(dev))
     pad = gen_pad(rank)
@@ -314,7 +329,11 @@ def main():
     # ---- prebuilt C-ABI descriptors: the timed loop is `oeh_attn_fwd` and nothing else
     def make_call(q, k, v, o, pad=pad, hd=None):
         dsc = _lib.oeh_attn_desc()
-        dsc.B, dsc.H, dsc.Sq, dsc.Sk, dsc.D, dsc.dtype = B, H, S, S, d, (_lib.OEH_F32 if w.get("fp32") else _lib.OEH_F16)
+        dsc.B, dsc.H, dsc.Sq, dsc.Sk, dsc.D, dsc.dtype = B, H, S, S, d, (_lib.OEH_I8 if w.get("i8") else _lib.OEH_F32 if w.get("fp32") else _lib.OEH_F16)
+        if w.get("i8"):
+            dsc.o_dtype = _lib.OEH_F32
+            for name, (sc_, zp_) in zip(("q_grid", "k_grid", "v_grid"), I8_GRIDS):
+                getattr(dsc, name).scale, getattr(dsc, name).zero_point = sc_, zp_
         for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", o)):
             getattr(dsc, name)[:] = [t.stride(0), t.stride(1), t.stride(2)]
         if w["order"] == "opt":
@@ -423,7 +442,10 @@ def main():
                     pr = None if pr is None else pr.to(dev)
                     o_ = torch.empty(B, S, H, d, dtype=sdt, device=dev).permute(0, 2, 1, 3)
                     hd_ = None if gi_ is None else gi_.to(dev)
-                    args_, keep_ = make_call(view(q_), view(k_), view(v_), o_, pad=pr, hd=hd_)
+                    if w.get("i8"):
+                        args_, keep_ = make_call(view_i8(q_, undo=d ** 0.5), view_i8(k_), view_i8(v_, transpose=True), o_, pad=pr, hd=hd_)
+                    else:
+                        args_, keep_ = make_call(view(q_), view(k_), view(v_), o_, pad=pr, hd=hd_)
                     if fwd(*args_, stream) != 0:
                         raise RuntimeError("oeh_attn_fwd (shard check)")
                     torch.cuda.synchronize()
@@ -439,7 +461,7 @@ def main():
         layer_tokens = world * B * S * L * a.steps
         kern_s = dev_ms * 1e-3 / launches
         elt = 4 if w.get("fp32") else 2
-        alg_bytes = 4 * B * H * S * d * elt + (B * S * 4 if pad is not None else 0) + (B * S * H * d * elt if gate is not None else 0)  # + gate input (hidden states)
+        alg_bytes = (3 * B * H * S * d * 1 + B * H * S * d * 4) if w.get("i8") else 4 * B * H * S * d * elt + (B * S * 4 if pad is not None else 0) + (B * S * H * d * elt if gate is not None else 0)  # + gate input (hidden states)
         achieved = alg_bytes / kern_s / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -463,12 +485,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("f32 storage, f16 (hi,lo) operand pairs on the matrix cores = f32-accurate products, f32 accumulate" if w.get("fp32") else "f16 storage, f32 accumulate") + (", 8-bit fake-quant grids" if w["int8"] else ""),
+            "dtype": "int8 index storage of q/k/v, i32 matrix-core accumulation, f32 output, 8-bit fake-quant grids" if w.get("i8") else ("f32 storage, f16 (hi,lo) operand pairs on the matrix cores = f32-accurate products, f32 accumulate" if w.get("fp32") else "f16 storage, f32 accumulate") + (", 8-bit fake-quant grids" if w["int8"] else ""),
             "data": "synthetic",
             "config": {
-                "workload": w["desc"], "variant": ops.attn_variant(B, H, S, S, d, torch.float32 if w.get("fp32") else torch.float16, fq=w["int8"], clip=bool(w["sm"][1]),
-                                                                       causal=(w["order"] == "opt"), key_pad=(w["order"] == "bert"), scale_div=(8.0 if w["order"] == "bert" else 0.0),
-                                                                       scale=(d ** -0.5 if w["order"] == "none" else 1.0)),
+                "workload": w["desc"], "variant": (lib.oeh_attn_variant(calls[0][0][0], calls[0][0][5]) or b"?").decode(),  # what the library picks for the timed descriptor
                 "batch_per_gpu": B, "seq_len": S, "heads": H, "head_dim": d, "layers_per_step": L,
                 "launches_per_step": L, "model_tokens_per_s": world * B * S * a.steps / wall,
                 "parallelism": f"batch-shard x{world}, no collective in the timed region",

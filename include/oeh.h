@@ -36,6 +36,7 @@ extern "C" {
 #define OEH_F16 0
 #define OEH_BF16 1
 #define OEH_F32 2
+#define OEH_I8 3 /* oeh_attn_fwd only: q, k, v are CENTRED 8-bit quantiser indices (see oeh_attn_desc.q_grid) */
 
 /* softmax base: softmax_n with n = 0 (torch softmax) or n = 1 (softmax_1) */
 #define OEH_SOFTMAX_VANILLA 0
@@ -129,6 +130,20 @@ typedef struct oeh_attn_desc {
   int32_t gate_units;
   float gate_scaling;
   float* gate_out;
+
+  /* dtype == OEH_I8 (ABI 3) - the INT8 configuration with q, k, v as the 8-bit indices the reference's QuantLinear
+   * projections put them on (hijacker.py:78-127; quantized_opt.py:67-75: q_proj / k_proj / v_proj are QuantLinear, their
+   * outputs fake-quantised per tensor before the bmm at :151), both products on the integer matrix cores:
+   *   an element is the int8 value c = idx - 128 of the index idx in [0, 255]; its value is grid.scale * (c + 128 - grid.zero_point)
+   *   (for q: AFTER OPT's `* scaling`, i.e. fold head_dim^-0.5 into q_grid.scale or pass it as `scale`);
+   *   q, k: (B,H,S,D) views as usual (strides in elements = bytes); v TRANSPOSED: a (B,H,D,Sk) view, keys contiguous,
+   *   v_stride = (batch, head, d row) - the second product sums over keys;
+   *   o has dtype o_dtype (OEH_F16 | OEH_BF16 | OEH_F32).
+   * Requires D == 64, Sk <= 512 and a multiple of 16, 16-byte aligned rows, masks none | causal, no clipping, and `fq`
+   * with scores and probabilities enabled (probabilities on a full 8-bit grid, qmax == 255): OEH_ENOTSUP otherwise (run
+   * the fake-quant variants on dequantised values). */
+  struct { float scale; float zero_point; } q_grid, k_grid, v_grid;
+  int32_t o_dtype;
 } oeh_attn_desc;
 
 /* QK^T -> scale -> [fq] -> mask -> softmax / softmax_1 -> [clip] -> [fq] -> PV -> [fq] -> gate -> [fq]

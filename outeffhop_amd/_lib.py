@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("OEH_LIB") or os.path.join(_HERE, "lib", "liboeh_hip.s
 
 ABI_VERSION = 3  # include/oeh.h: OEH_ABI_VERSION
 CALIB_WORK_BYTES = 36864  # include/oeh.h: OEH_CALIB_WORK_BYTES
-OEH_F16, OEH_BF16, OEH_F32 = 0, 1, 2
+OEH_F16, OEH_BF16, OEH_F32, OEH_I8 = 0, 1, 2, 3
 OEH_SOFTMAX_VANILLA, OEH_SOFTMAX_ONE = 0, 1
 
 
@@ -36,6 +36,10 @@ class oeh_fq_desc(C.Structure):
     _fields_ = [("scores", oeh_fq), ("probs", oeh_fq), ("ctx", oeh_fq), ("ctx_quant_before_gate", C.c_int32)]
 
 
+class oeh_grid(C.Structure):
+    _fields_ = [("scale", C.c_float), ("zero_point", C.c_float)]
+
+
 class oeh_attn_desc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("H", C.c_int32), ("Sq", C.c_int32), ("Sk", C.c_int32), ("D", C.c_int32),
@@ -50,6 +54,7 @@ class oeh_attn_desc(C.Structure):
         ("gate_hidden", C.c_void_p), ("gate_hidden_stride", C.c_int64 * 2),
         ("gate_w1", C.c_void_p), ("gate_b1", C.c_void_p), ("gate_w2", C.c_void_p), ("gate_b2", C.c_void_p),
         ("gate_units", C.c_int32), ("gate_scaling", C.c_float), ("gate_out", C.c_void_p),
+        ("q_grid", oeh_grid), ("k_grid", oeh_grid), ("v_grid", oeh_grid), ("o_dtype", C.c_int32),
     ]
 
 

@@ -20,6 +20,7 @@ int launch_attn_flash_d64(const AttnParams& P, int in, int mq, hipStream_t st);
 int launch_attn_flash_d128(const AttnParams& P, int in, int mq, hipStream_t st);
 int launch_attn_generic(const AttnParams& P, int in, hipStream_t st);
 int launch_attn_small(const AttnParams& P, int in, hipStream_t st);
+int launch_attn_i8(const AttnParams& P, int out, hipStream_t st);
 int launch_softmax_rows(const void* x, void* y, long rows, int cols, int in, int base, int clip, float w, float g, hipStream_t st);
 int launch_fake_quant(const void* x, void* y, unsigned char* idx, long n, int in, FqP f, hipStream_t st);
 int launch_gate(const void* hidden, int in, int B, int T, int H, int d, long hs_b, long hs_t, const float* w1, const float* b1,
@@ -58,7 +59,7 @@ FqP make_fq(const oeh_fq* f) {
   return r;
 }
 
-enum Variant { V_NONE = 0, V_FLASH, V_FAST, V_MFMA, V_GENERIC, V_SMALL };
+enum Variant { V_NONE = 0, V_FLASH, V_FAST, V_MFMA, V_GENERIC, V_SMALL, V_I8 };
 
 // rows must be 16-byte aligned for the MFMA path's 16-B loads / 8..16-B stores
 bool aligned16(const void* p, const int64_t* st, int eb) {
@@ -71,7 +72,14 @@ bool aligned16(const void* p, const int64_t* st, int eb) {
 int validate(const oeh_attn_desc* d, const void* q, const void* k, const void* v, void* o, const oeh_fq_desc* fq) {
   if (d == nullptr || q == nullptr || k == nullptr || v == nullptr || o == nullptr) return OEH_EINVAL;
   if (d->B <= 0 || d->H <= 0 || d->Sq <= 0 || d->Sk <= 0 || d->D <= 0) return OEH_EINVAL;
-  if (!dtype_ok(d->dtype)) return OEH_EINVAL;
+  if (!dtype_ok(d->dtype) && d->dtype != OEH_I8) return OEH_EINVAL;
+  if (d->dtype == OEH_I8) {
+    if (!dtype_ok(d->o_dtype)) return OEH_EINVAL;
+    const float zs[3] = {d->q_grid.zero_point, d->k_grid.zero_point, d->v_grid.zero_point};
+    const float ss[3] = {d->q_grid.scale, d->k_grid.scale, d->v_grid.scale};
+    for (int i = 0; i < 3; ++i)
+      if (!(ss[i] > 0.0f) || !(zs[i] >= 0.0f && zs[i] <= 255.0f) || zs[i] != std::nearbyint(zs[i])) return OEH_EINVAL;
+  }
   if (d->softmax_base != OEH_SOFTMAX_VANILLA && d->softmax_base != OEH_SOFTMAX_ONE) return OEH_EINVAL;
   if (d->key_pad_mask != nullptr && d->key_pad_dtype != OEH_F16 && d->key_pad_dtype != OEH_F32) return OEH_EINVAL;
   if (d->full_mask != nullptr && d->full_mask_dtype != OEH_F16 && d->full_mask_dtype != OEH_F32) return OEH_EINVAL;
@@ -180,7 +188,23 @@ int flash_mq(const oeh_attn_desc* d) {
   return (d->Sq > 64 && wg2 >= 512) ? 2 : 1;
 }
 
+// INT8 storage (oeh_attn_i8.hip): see include/oeh.h, oeh_attn_desc.q_grid
+bool i8_eligible(const oeh_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const oeh_fq_desc* fq) {
+  if (d->dtype != OEH_I8 || d->D != 64 || d->Sk > 512 || (d->Sk & 15) != 0) return false;
+  if (fq == nullptr || !fq->scores.enable || !fq->probs.enable || fq->probs.qmax != 255.0f) return false;
+  if (fq->scores.dump_idx != nullptr || fq->probs.dump_idx != nullptr || fq->ctx.dump_idx != nullptr) return false;
+  if (d->clip || d->key_pad_mask != nullptr || d->full_mask != nullptr || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
+  if (d->scale_div != 0.0f ? !(d->scale_div > 0.0f && std::isfinite(d->scale_div)) : !(d->scale > 0.0f && std::isfinite(d->scale))) return false;
+  if (d->causal && (d->Sq > d->Sk || !(d->mask_min < -1.0e4f))) return false;
+  if (q != nullptr) {
+    const int ob = elem_bytes(d->o_dtype);
+    if (!aligned16(q, d->q_stride, 1) || !aligned16(k, d->k_stride, 1) || !aligned16(v, d->v_stride, 1) || !aligned16(o, d->o_stride, ob)) return false;
+  }
+  return true;
+}
+
 Variant pick_variant(const oeh_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const oeh_fq_desc* fq) {
+  if (d->dtype == OEH_I8) return i8_eligible(d, q, k, v, o, fq) ? V_I8 : V_NONE;
   const int eb = elem_bytes(d->dtype);
   const bool shape_ok = (d->D == 32 || d->D == 64 || d->D == 128) && d->Sk <= 512;
   // integer-valued (idx - zp) must be exact in the 16-bit P operand: |.| <= 2048 (f16) / 256 (bf16)
@@ -228,7 +252,8 @@ void fill_params(AttnParams& P, const oeh_attn_desc* d, const void* q, const voi
     P.ctx_before_gate = fq->ctx_quant_before_gate ? 1 : 0;
   }
   P.stamps = g_stamps;
-  P.prio = (g_prio && d->causal) ? 1 : 0;
+  P.prio = (g_prio && d->causal) ? g_prio : 0;
+  if (P.prio == 2 && (((d->Sq + 63) / 64) & 1)) P.prio = 0;  // slab pairing needs an even slab count
   P.nQT = (d->Sq + 63) / 64;
   P.nBH = d->B * d->H;
   P.nBHpad = (P.nBH + 7) & ~7;
@@ -245,6 +270,11 @@ void fill_params(AttnParams& P, const oeh_attn_desc* d, const void* q, const voi
 const char* variant_name(Variant v, const oeh_attn_desc* d, bool fq) {
   static thread_local char buf[64];
   if (v == V_GENERIC) return "generic";
+  if (v == V_I8) {
+    std::snprintf(buf, sizeof(buf), "i8mfma/NT%d/D64/%s", d->Sk <= 128 ? 8 : (d->Sk <= 256 ? 16 : 32),
+                  d->o_dtype == OEH_F16 ? "f16" : (d->o_dtype == OEH_BF16 ? "bf16" : "f32"));
+    return buf;
+  }
   if (v == V_SMALL) {
     std::snprintf(buf, sizeof(buf), "small/ST%d/D%d/%s", d->Sk <= 32 ? 2 : 4, d->D, d->dtype == OEH_F16 ? "f16" : (d->dtype == OEH_BF16 ? "bf16" : "f32"));
     return buf;
@@ -277,6 +307,14 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
   P.src32 = (desc->dtype == OEH_F32 && (var == V_FLASH || var == V_FAST)) ? 1 : 0;  // fp32 storage read directly, fp32 output
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (var == V_SMALL) return oeh::launch_attn_small(P, desc->dtype, st);
+  if (var == V_I8) {
+    const double mult = desc->scale_div != 0.0f ? 1.0 / (double)desc->scale_div : (double)desc->scale;
+    P.i8_cq = 128 - (int)desc->q_grid.zero_point; P.i8_ck = 128 - (int)desc->k_grid.zero_point;
+    P.i8_cv = 128 - (int)desc->v_grid.zero_point; P.i8_cp = 128 - (int)fq->probs.zero_point;
+    P.i8_k1 = (float)((double)desc->q_grid.scale * (double)desc->k_grid.scale * mult / (double)fq->scores.scale);
+    P.i8_so = (float)((double)fq->probs.scale * (double)desc->v_grid.scale);
+    return oeh::launch_attn_i8(P, desc->o_dtype, st);
+  }
   if (var == V_FLASH) {
     if (desc->scale_div != 0.0f) { P.scale = 1.0f / desc->scale_div; P.scale_div = 0.0f; }  // (fast_eligible: exact for a power of two)
     const int mq = flash_mq(desc);
@@ -306,7 +344,7 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
 }
 
 const char* oeh_attn_variant(const oeh_attn_desc* desc, const oeh_fq_desc* fq) {
-  if (desc == nullptr || desc->B <= 0 || desc->H <= 0 || desc->Sq <= 0 || desc->Sk <= 0 || desc->D <= 0 || !dtype_ok(desc->dtype))
+  if (desc == nullptr || desc->B <= 0 || desc->H <= 0 || desc->Sq <= 0 || desc->Sk <= 0 || desc->D <= 0 || (!dtype_ok(desc->dtype) && desc->dtype != OEH_I8))
     return nullptr;
   return variant_name(pick_variant(desc, nullptr, nullptr, nullptr, nullptr, fq), desc, any_fq(fq));
 }
@@ -370,14 +408,14 @@ int oeh_fake_quant_range(const void* x, void* y, int64_t n, int32_t dtype, const
 //  oeh_debug_set_stamps: device buffer of 32 u64 per wave that the one-pass kernel fills with s_memtime /
 //    s_memrealtime stamps when non-null (tools/timeline.py).
 void oeh_debug_set_variant(int off_mask, int flash_mq_force) {
-  g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force; g_prio = (off_mask >> 9) & 1;
+  g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force; g_prio = (off_mask >> 9) & 3;
 }
 void oeh_debug_set_stamps(void* device_buffer) { g_stamps = static_cast<unsigned long long*>(device_buffer); }
 
 int oeh_abi_version(void) { return OEH_ABI_VERSION; }
 
 const char* oeh_build_info(void) {
-  return "liboeh_hip gfx950 (MI355X, CDNA4) v_mfma_f32_16x16x32_{f16,bf16} + v_mfma_f32_16x16x4_f32; built " __DATE__ " " __TIME__ " hipcc " __VERSION__;
+  return "liboeh_hip gfx950 (MI355X, CDNA4) v_mfma_f32_16x16x32_{f16,bf16} + v_mfma_f32_16x16x4_f32 + v_mfma_i32_16x16x64_i8; built " __DATE__ " " __TIME__ " hipcc " __VERSION__;
 }
 
 const char* oeh_strerror(int code) {

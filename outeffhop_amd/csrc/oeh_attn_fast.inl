@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
     }
   };
 
-  if (P.prio) set_wave_priority((qt * 4) / P.nQT);  // q tiles further down the causal triangle stream more keys
+  if (P.prio == 1) set_wave_priority((qt * 4) / P.nQT);  // q tiles further down the causal triangle stream more keys
   unsigned long long* stamp = nullptr;  // diagnostic builds of tools/timeline.py only
   if (P.stamps != nullptr) stamp = P.stamps + ((long)bid * 4 + wave) * 32;
 #define OEH_STAMP(slot)                                                                               \

@@ -1,0 +1,284 @@
+// The INT8 attention core on the INTEGER matrix cores: q, k, v arrive as 8-bit quantiser indices - what the
+// reference's QuantLinear projections really produce (hijacker.py:78-127: the q_proj / k_proj / v_proj outputs are fake-quantised
+// onto per-tensor 8-bit grids before quantized_opt.py:151 multiplies them) - both contractions run on v_mfma_i32_16x16x64_i8
+// with exact i32 accumulation, and the three activation quantisers of the attention class (scores, probabilities, context)
+// are the chain on the quantiser grid of oeh_attn_fast.inl.  Head dim 64: one MFMA k-step is a whole score.
+//
+// Storage (dtype OEH_I8): an element is the CENTRED index c = idx - 128 (int8), its value x = scale * (c + 128 - zp).
+// The integer matrix cores are signed 8 x 8 bit; an asymmetric grid's idx - zp does not fit (zp is data dependent), so the
+// products are formed on the centred indices and the offsets cq = 128 - zp_q (...) are put back exactly:
+//     sum_d (a + cq)(b + ck) = sum_d a b + ck sum_d a + cq sum_d b + D cq ck
+// with sum_d b (per key) from one more MFMA of the same K fragment against a ones operand - it lands in the accumulator
+// layout the scores have - and sum_d a (per query) from the lane's own Q registers.  The same identity, with the sums over
+// keys, serves P V; the probabilities' indices are formed, rounded (RNE) and saturated to [0, 255] by v_cvt_pk_u8_f32,
+// four to a register, and ARE the second product's operand.
+//
+// Layouts: q, k (B,H,S,64) views as everywhere; v TRANSPOSED, (B,H,64,Sk) with the keys contiguous (v_stride = batch, head,
+// d row): the second product sums over keys, so its operand wants 16 consecutive keys of one d per lane, and an LDS-DMA
+// cannot transpose.  LDS: K tiles [64 keys][64 B] and V^T tiles [64 d][64 B], 3 + 3 slots of 4 KB, fed by LDS-DMA exactly
+// like the 16-bit kernels; the 16-B chunk of a row is XOR-swizzled with {0,3,2,1}[row group] so that ds_read_b128 of either
+// operand is conflict-free (the row groups differ: keys are dealt to MFMA rows as key = 16 (row >> 2) + 4 t + (row & 3) so
+// that a lane ends up with 16 CONSECUTIVE keys of its query - the k order the V^T operand has).
+// Masks: none | analytic causal.  Everything else of the INT8 configuration (key padding, clipping, other head dims) runs
+// the fake-quant variants of the 16-bit / fp32 kernels on dequantised values.
+#include "oeh_attn_fast.inl"
+
+namespace oeh {
+
+typedef int i4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int perm4(int x) { return (0x6C >> ((x & 3) * 2)) & 3; }  // {0,3,2,1}
+
+template <int NT, int OUT>
+__global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P) {
+  constexpr int D = 64, KT = NT / 4, TILEB = 64 * 64, R = 3, DT = 4;
+  constexpr float RELMASK = -1.0e30f;
+  constexpr bool OUT32 = (OUT == IN_F32);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * R * TILEB];
+
+  const int bid = blockIdx.x;
+  const int qt_rev = bid / P.nBHpad;
+  const int bh = bid - qt_rev * P.nBHpad;
+  if (bh >= P.nBH) return;
+  const int qt = P.nQT - 1 - qt_rev;
+  const int b = bh / P.H, h = bh - b * P.H;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int q0 = qt * 64 + wave * 16, qrow = q0 + c;
+  const bool qvalid = qrow < P.Sq;
+  const int Sk = P.Sk, off = P.Sk - P.Sq, causal = P.causal;
+
+  int kend_wg = Sk;
+  if (P.skip_ok) kend_wg = min(Sk, max(0, qt * 64 + 64 + off));
+  const int n_kt = (kend_wg + 63) >> 6;
+  const int T = 2 * n_kt;
+
+  // ---- LDS-DMA stream, K tiles then V^T tiles, one 1-KiB piece per wave and tile: lane -> (row of the piece, 16-B chunk)
+  const signed char* kbase = reinterpret_cast<const signed char*>(P.k) + (long)b * P.ks_b + (long)h * P.ks_h;
+  const signed char* vbase = reinterpret_cast<const signed char*>(P.v) + (long)b * P.vs_b + (long)h * P.vs_h;
+  const int prow = wave * 16 + (lane >> 2), pch = lane & 3;
+  const unsigned lds_base = lds_offset(lds);
+  const int last_chunk = (Sk >> 4) - 1;  // (Sk is a multiple of 16: host)
+  int nx = 0;
+  auto issue_next = [&]() {
+    const bool isv = nx >= n_kt;
+    const int t = isv ? nx - n_kt : nx;
+    const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(((isv ? R : 0) + t % R) * TILEB + wave * 1024));
+    const signed char* src;
+    if (isv) {  // V^T: row = d, chunk = 16 keys; chunks past Sk are redirected to the last one (finite data, probability 0)
+      src = vbase + (long)prow * P.vs_s + (long)min(4 * t + (pch ^ perm4(prow >> 2)), last_chunk) * 16;
+    } else {    // K: row = key, chunk = 16 of the 64 head dims; rows past Sk are redirected to row Sk - 1
+      src = kbase + (long)min(64 * t + prow, Sk - 1) * P.ks_s + (pch ^ perm4(prow >> 4)) * 16;
+    }
+    glds16(src, slot);
+    ++nx;
+  };
+  issue_next();
+  if (1 < T) issue_next();
+
+  // ---- Q: global -> registers in the B-operand layout (query q0 + c, head dims 16 g ..), and its row sum
+  i4 qf;
+  {
+    const signed char* qp = reinterpret_cast<const signed char*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h + (long)min(qrow, P.Sq - 1) * P.qs_s + 16 * g;
+    qf = *reinterpret_cast<const i4*>(qp);
+  }
+  const int ones = 0x01010101;
+  const i4 ones4 = i4{ones, ones, ones, ones};
+  int asum = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) asum = __builtin_amdgcn_sdot4(qf[j], ones, asum, false);
+  asum += __shfl_xor(asum, 16);
+  asum += __shfl_xor(asum, 32);
+  const int cq = P.i8_cq, ck = P.i8_ck, cv = P.i8_cv, cp = P.i8_cp;   // 128 - zero point of q, k, v and of the probabilities
+  const bool corr = (cq | ck) != 0;
+  // y = (quotient of the score by the score grid's step) = k1 * (sum a b + cq ksum) + rq
+  const float k1 = P.i8_k1;
+  const float rq = (float)(ck * asum + D * cq * ck) * k1;
+
+  // =========================== phase 1: S^T = K Q^T (i32), kept as integer-valued floats ===========================
+  f4 s[NT];
+  const int krow_base = 16 * (c >> 2) + (c & 3);                 // MFMA row c of sub-tile t holds key krow_base + 4 t
+  const int kswz = (g ^ perm4(c >> 2)) << 4;                     // perm4((key >> 4) & 3), key >> 4 == c >> 2
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt < n_kt) {
+      wait_tiles_in_flight<1>(min(1, T - 1 - kt));
+      barrier_mem();
+      if (kt + 2 < T) issue_next();
+      const unsigned char* tb = lds + (kt % R) * TILEB;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const i4 kf = *reinterpret_cast<const i4*>(tb + (krow_base + 4 * t) * 64 + kswz);
+        i4 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, qf, i4{0, 0, 0, 0}, 0, 0, 0);
+        if (corr) {
+          const i4 ks = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, ones4, i4{0, 0, 0, 0}, 0, 0, 0);  // sum_d b of the lane's four keys
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] += __mul24(cq, ks[r]);  // |ksum| <= 64 * 128
+        }
+        s[kt * 4 + t] = f4{(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
+      }
+    }
+  }
+
+  // =========================== phase 2: the chain on the quantiser grid ===========================
+  // element (kt, t, r) of lane (c, g) is key 64 kt + 16 g + 4 t + r of query q0 + c
+  const int klimc = qrow + off;
+  const int klime = causal ? min(klimc, Sk - 1) : Sk - 1;
+  const int kt_causal = causal ? (max(0, q0 + off + 1) >> 6) : KT;
+  const int kt_tail = Sk >> 6;
+  const float slo = P.fq_s.lo, shi = P.fq_s.hi;
+  float mr = RELMASK;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt < n_kt) {
+      const bool open_tile = kt < kt_causal && kt < kt_tail;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int key0 = 64 * kt + 16 * g + 4 * t;
+        f4 rel;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rel[r] = __builtin_amdgcn_fmed3f(__builtin_rintf(__builtin_fmaf(s[kt * 4 + t][r], k1, rq)), slo, shi);
+        if (!open_tile) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + r > klime) rel[r] = RELMASK;
+        }
+        s[kt * 4 + t] = rel;
+        mr = __builtin_fmaxf(__builtin_fmaxf(mr, __builtin_fmaxf(rel[0], rel[1])), __builtin_fmaxf(rel[2], rel[3]));
+      }
+    }
+  }
+  mr = __builtin_fmaxf(mr, __shfl_xor(mr, 16));
+  mr = __builtin_fmaxf(mr, __shfl_xor(mr, 32));
+  const float m = mr * P.fq_s.scale;
+  const float c2 = P.fq_s.c2;
+  f4 sum4 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt < n_kt) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f4 e;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f((s[kt * 4 + t][r] - mr) * c2);
+        s[kt * 4 + t] = e;
+        sum4 = sum4 + e;
+      }
+    }
+  }
+  float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  float den = sum;
+  if (P.base != 0) den = sum + exp_acc(m * -1.0f);
+  const float cinv = (1.0f / den) * P.fq_p.rscale, pzp = P.fq_p.zp;
+  // probabilities: index = sat_u8(rne(e * cinv + zp)) by v_cvt_pk_u8_f32, four keys to a register, centred by the XOR;
+  // a masked key has e == 0, index zp, value 0.  The centred indices' row sum goes with them.
+  int psum = 0;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt < n_kt) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        unsigned w = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(s[kt * 4 + t][r], cinv, pzp), r, w);
+        w ^= 0x80808080u;
+        psum = __builtin_amdgcn_sdot4((int)w, ones, psum, false);
+        s[kt * 4 + t][0] = bits_f32(w);
+      }
+    }
+  }
+  psum += __shfl_xor(psum, 16);
+  psum += __shfl_xor(psum, 32);
+
+  // =========================== phase 3: O^T = V^T P^T (i32) and the key sums of V^T ===========================
+  i4 o[DT], vs[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) o[dt] = vs[dt] = i4{0, 0, 0, 0};
+  const int vswz = (g ^ perm4(c >> 2)) << 4;                      // perm4((d >> 2) & 3), d = 16 dt + c
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt < n_kt) {
+      const int i = n_kt + kt;
+      wait_tiles_in_flight<1>(min(1, T - 1 - i));
+      barrier_mem();
+      if (i + 2 < T) issue_next();
+      const unsigned char* tb = lds + (R + kt % R) * TILEB;
+      const i4 pb = i4{(int)f32_bits(s[kt * 4 + 0][0]), (int)f32_bits(s[kt * 4 + 1][0]), (int)f32_bits(s[kt * 4 + 2][0]), (int)f32_bits(s[kt * 4 + 3][0])};
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const i4 vf = *reinterpret_cast<const i4*>(tb + (16 * dt + c) * 64 + vswz);
+        o[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pb, o[dt], 0, 0, 0);
+        vs[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, ones4, vs[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  // =========================== epilogue: offsets back, [fq] gate [fq], store ===========================
+  // lane (c, g) holds O[q0 + c][16 dt + 4 g + r];  sum_k (v + cv)(p + cp) = o + cp vsum + cv psum + n cv cp
+  const int nkeys = 64 * n_kt;
+  const int rowc = cv * psum + nkeys * cv * cp;
+  const float so = P.i8_so;  // scale_p * scale_v
+  float gatev = 1.0f;
+  if (P.gate != nullptr && qvalid) gatev = P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int ce = lane_e & 15, ge = lane_e >> 4;
+  constexpr int ROWB = 2 * D;
+  unsigned char* ebase = lds + wave * (16 * ROWB);  // 16-bit output: staged through the (idle) K ring, whole rows stored
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    float ov[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x = so * (float)(o[dt][r] + __mul24(cp, vs[dt][r]) + rowc);  // |vsum| <= 512 * 128
+      if (P.fq_c.en && P.ctx_before_gate) x = fq_dequant(fq_index(x, P.fq_c), P.fq_c);
+      if (P.gate != nullptr) x = x * gatev;
+      if (P.fq_c.en && !P.ctx_before_gate) x = fq_dequant(fq_index(x, P.fq_c), P.fq_c);
+      ov[r] = x;
+    }
+    if constexpr (OUT32) {
+      if (q0 + ce < P.Sq)
+        store_wt16(reinterpret_cast<float*>(P.o) + (long)b * P.os_b + (long)h * P.os_h + (long)(q0 + ce) * P.os_s + 16 * dt + 4 * ge,
+                   u4{f32_bits(ov[0]), f32_bits(ov[1]), f32_bits(ov[2]), f32_bits(ov[3])});
+    } else {
+      u2 w;
+      if constexpr (OUT == IN_BF16) { w.x = pack2_bf16(ov[0], ov[1]); w.y = pack2_bf16(ov[2], ov[3]); }
+      else { w.x = pack2_f16(ov[0], ov[1]); w.y = pack2_f16(ov[2], ov[3]); }
+      *reinterpret_cast<u2*>(ebase + ce * ROWB + ((((2 * dt + (ge >> 1)) ^ (ce & 7)) << 4) | ((ge & 1) << 3))) = w;
+    }
+  }
+  if constexpr (!OUT32) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    unsigned short* obase = reinterpret_cast<unsigned short*>(P.o) + (long)b * P.os_b + (long)h * P.os_h;
+    const int lr = lane_e >> 3, lc = lane_e & 7;  // 8 chunks of 16 B per 128-B row, 8 rows per pass
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = pass * 8 + lr;
+      const u4 w = *reinterpret_cast<const u4*>(ebase + row * ROWB + ((lc ^ (row & 7)) << 4));
+      if (q0 + row < P.Sq) store_wt16(obase + (long)(q0 + row) * P.os_s + lc * 8, w);
+    }
+  }
+}
+
+template <int NT>
+static int launch_i8_nt(const AttnParams& P, int out, hipStream_t st) {
+  const unsigned grid = (unsigned)(P.nQT * P.nBHpad);
+  switch (out) {
+    case IN_F16: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F16>), dim3(grid), dim3(256), 0, st, P); break;
+    case IN_BF16: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_BF16>), dim3(grid), dim3(256), 0, st, P); break;
+    default: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F32>), dim3(grid), dim3(256), 0, st, P); break;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// D == 64, Sk <= 512 and a multiple of 16, scores and probabilities on 8-bit grids (oeh_api.hip: i8_eligible)
+int launch_attn_i8(const AttnParams& P, int out, hipStream_t st) {
+  if (P.Sk <= 128) return launch_i8_nt<8>(P, out, st);
+  if (P.Sk <= 256) return launch_i8_nt<16>(P, out, st);
+  return launch_i8_nt<32>(P, out, st);
+}
+
+}  // namespace oeh

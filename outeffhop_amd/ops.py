@@ -228,6 +228,78 @@ def attn_fwd(
     return out
 
 
+@dataclass(frozen=True)
+class QuantGrid:
+    """A per-tensor 8-bit grid of one of q / k / v in INT8 storage: value = scale * (index - zero_point)."""
+
+    scale: float
+    zero_point: float
+
+    @staticmethod
+    def of(spec: "FakeQuantSpec") -> "QuantGrid":
+        if spec.qmax != 255.0:
+            raise ValueError("INT8 storage needs 8-bit grids")
+        return QuantGrid(float(spec.scale), float(spec.zero_point))
+
+
+def centre_indices(idx: torch.Tensor) -> torch.Tensor:
+    """uint8 quantiser indices -> the int8 storage of the INT8 attention path (index - 128): one XOR, no copy of another kind."""
+    if idx.dtype != torch.uint8:
+        raise ValueError("indices must be uint8")
+    return (idx ^ 128).view(torch.int8)
+
+
+def attn_fwd_i8(q: torch.Tensor, k: torch.Tensor, v_t: torch.Tensor, grids, *, fq: AttnFakeQuant, out_dtype=torch.float16,
+                softmax: SoftmaxSpec = SoftmaxSpec(), scale: float = 1.0, scale_div: float = 0.0, causal: bool = False, clamp_min: bool = False,
+                mask_min: Optional[float] = None, gate: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The INT8 configuration on the integer matrix cores (`include/oeh.h`: dtype OEH_I8): q, k logical (B,H,S,64) int8 views of
+    centred indices (`centre_indices`), v_t the TRANSPOSED values, a (B,H,64,Sk) int8 view with contiguous keys; `grids` =
+    (q, k, v) QuantGrid; `fq` with scores and probabilities (8-bit) [and context].  Returns the logical (B,H,Sq,64) result in
+    `out_dtype`, stored (B,Sq,H,64)-contiguous.  Raises OehError(-95) for what this path does not take (key padding, clipping,
+    other head dims ...): the caller then runs `attn_fwd(..., fq=...)` on the dequantised values."""
+    dev = _need_gpu(q, k, v_t, gate, out)
+    if q.dtype != torch.int8 or k.dtype != torch.int8 or v_t.dtype != torch.int8:
+        raise ValueError("q, k, v_t must be int8 (centred indices)")
+    B, H, Sq, D = q.shape
+    Sk = k.shape[2]
+    if k.shape != (B, H, Sk, D) or v_t.shape != (B, H, D, Sk):
+        raise ValueError(f"shape mismatch: q {tuple(q.shape)} k {tuple(k.shape)} v_t {tuple(v_t.shape)} (v_t is (B,H,D,Sk))")
+    if q.stride(3) != 1 or k.stride(3) != 1 or v_t.stride(3) != 1:
+        raise ValueError("q, k need a contiguous head dim and v_t contiguous keys")
+    if out is None:
+        out = torch.empty((B, Sq, H, D), dtype=out_dtype, device=q.device).permute(0, 2, 1, 3)
+    elif out.shape != (B, H, Sq, D) or out.dtype != out_dtype or out.stride(3) != 1:
+        raise ValueError("out must be a (B,H,Sq,D) view with unit head-dim stride and dtype out_dtype")
+    d = oeh_attn_desc()
+    d.B, d.H, d.Sq, d.Sk, d.D, d.dtype, d.o_dtype = B, H, Sq, Sk, D, _lib.OEH_I8, _DT[out_dtype]
+    for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v_t), ("o_stride", out)):
+        getattr(d, name)[:] = [t.stride(0), t.stride(1), t.stride(2)]
+    for name, gr in zip(("q_grid", "k_grid", "v_grid"), grids):
+        getattr(d, name).scale, getattr(d, name).zero_point = float(gr.scale), float(gr.zero_point)
+    d.scale, d.scale_div = float(scale), float(scale_div)
+    d.softmax_base, d.clip, d.gamma, d.eta = int(softmax.base), int(bool(softmax.clip)), float(softmax.gamma), float(softmax.eta)
+    d.causal, d.clamp_min = int(bool(causal)), int(bool(clamp_min))
+    d.mask_min = float(torch.finfo(torch.float32).min if mask_min is None else mask_min)
+    keep = []
+    if gate is not None:
+        g = gate.to(torch.float32)
+        while g.dim() < 4:
+            g = g.unsqueeze(0)
+        g = g.expand(B, H, Sq, 1)
+        keep.append(g)
+        d.gate = g.data_ptr()
+        d.gate_stride[:] = [g.stride(0), g.stride(1), g.stride(2)]
+    fqd = oeh_fq_desc()
+    _fill_fq(fqd.scores, fq.scores)
+    _fill_fq(fqd.probs, fq.probs)
+    _fill_fq(fqd.ctx, fq.ctx)
+    fqd.ctx_quant_before_gate = int(bool(fq.ctx_before_gate))
+    with _on_device(dev):
+        rc = _lib.load().oeh_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v_t), _ptr(out), C.byref(fqd), _stream())
+    _lib.check(rc, "oeh_attn_fwd (INT8 storage)")
+    return out
+
+
 @dataclass
 class GatePredictor:
     """The conditional per-token gate evaluated INSIDE the attention kernel (include/oeh.h: gate_hidden ...): the layer

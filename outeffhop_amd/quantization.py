@@ -26,7 +26,8 @@ import torch
 from torch import nn
 
 from . import ops
-from .attention import AttentionGateType, BaseEnumOptions, GateState, attention_core, unfused_core
+from ._lib import OehError as _OehError
+from .attention import AttentionGateType, BaseEnumOptions, GateState, attention_core, classify_causal, unfused_core
 from .ops import AttnFakeQuant, FakeQuantSpec
 from .softmax import spec_of
 
@@ -701,9 +702,61 @@ class QuantizedOPTAttentionWithExtras(_QuantAttnBase):
     def _shape(self, tensor, seq_len, bsz):
         return tensor.view(bsz, seq_len, self.num_heads, self.head_dim).transpose(1, 2).contiguous()
 
+    def _int8_storage_core(self, hidden_states, attention_mask, gate, fq):
+        """the q/k/v projections are QuantLinear - their outputs ARE 8-bit indices on calibrated grids
+        (hijacker.py:78-127) - so the attention core can take the indices themselves and run both products on the integer
+        matrix cores (`ops.attn_fwd_i8`, include/oeh.h dtype OEH_I8).  Applies when the three output quantisers are 8-bit with
+        frozen ranges, head_dim = 64, the softmax is not clipped and the mask is None or purely causal (no padded keys);
+        returns (merged context, (k, v) floats for the cache) or None -> the caller runs the fake-quant path on floats."""
+        if not INT8_STORAGE or not hidden_states.is_cuda or self.head_dim != 64:
+            return None
+        spec = spec_of(self.softmax_fn)
+        bsz, tgt_len, _ = hidden_states.shape
+        if spec is None or spec.clip or tgt_len % 16 != 0 or tgt_len > 512 or fq.probs is None or fq.probs.qmax != 255.0 or fq.scores is None:
+            return None
+        lins = (self.q_proj, self.k_proj, self.v_proj)
+        if not all(isinstance(m, QuantLinear) and m._qa and m.activation_quantizer.is_fixed and m.activation_quantizer.quantizer.n_bits == 8
+                   and m.activation_function is None for m in lins):
+            return None
+        causal = False
+        if attention_mask is not None:
+            causal, padvec = classify_causal(attention_mask)
+            if not causal or padvec is not None:
+                return None
+        ys, idxs, grids = [], [], []
+        for m in lins:
+            w, b = m.get_params()
+            res = nn.functional.linear(hidden_states.contiguous(), w.contiguous(), bias=b)
+            sp = m.activation_quantizer.quantizer.spec()
+            y, idx = ops.fake_quant(res, sp, want_idx=True)  # the dequantised values (cache / fallback) and the indices, one pass
+            ys.append(y), idxs.append(idx), grids.append(ops.QuantGrid.of(sp))
+        H, d = self.num_heads, self.head_dim
+        qc = ops.centre_indices(idxs[0]).view(bsz, tgt_len, H, d).permute(0, 2, 1, 3)
+        kc = ops.centre_indices(idxs[1]).view(bsz, tgt_len, H, d).permute(0, 2, 1, 3)
+        vt = ops.centre_indices(idxs[2]).view(bsz, tgt_len, H, d).permute(0, 2, 3, 1).contiguous()  # (B,H,d,S): keys contiguous
+        mdt = attention_mask.dtype if attention_mask is not None and attention_mask.is_floating_point() else hidden_states.dtype
+        try:
+            out = ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, out_dtype=hidden_states.dtype, softmax=spec, scale=self.scaling, causal=causal,
+                                  clamp_min=attention_mask is not None, mask_min=float(torch.finfo(mdt).min), gate=gate)
+        except _OehError as e:
+            if e.code != -95:
+                raise
+            return None
+        return out.permute(0, 2, 1, 3).reshape(bsz, tgt_len, self.embed_dim), (self._heads(ys[1], bsz), self._heads(ys[2], bsz))
+
     def forward(self, hidden_states, key_value_states=None, past_key_value=None, attention_mask=None, layer_head_mask=None,
                 output_attentions=False):
         bsz, tgt_len, _ = hidden_states.size()
+        if key_value_states is None and past_key_value is None and layer_head_mask is None and not output_attentions and not self.training:
+            fq8 = self._fq(ctx_before_gate=True)
+            if fq8 is not None:
+                if attention_mask is not None and attention_mask.size() != (bsz, 1, tgt_len, tgt_len):
+                    raise ValueError(f"Attention mask should be of size {(bsz, 1, tgt_len, tgt_len)}, but is {attention_mask.size()}")
+                gate8 = GateState.evaluate(self, hidden_states, self.num_heads)
+                done = self._int8_storage_core(hidden_states, attention_mask, gate8, fq8)
+                if done is not None:
+                    merged, kv = done
+                    return self.out_proj(merged), None, (kv if self.is_decoder else past_key_value)
         q = self._heads(self.q_proj(hidden_states) * self.scaling, bsz)
         if key_value_states is not None and past_key_value is not None:
             k, v = past_key_value[0], past_key_value[1]
@@ -736,6 +789,11 @@ class QuantizedOPTAttentionWithExtras(_QuantAttnBase):
                 ctx = ctx * gate.to(ctx.dtype)
             merged = ctx.transpose(1, 2).reshape(bsz, tgt_len, self.embed_dim)
         return self.out_proj(merged), weights, new_past
+
+
+# The INT8-storage attention core (integer matrix cores) is used by QuantizedOPTAttentionWithExtras whenever it applies;
+# False: always the fake-quant kernels on float values (tests compare the two).
+INT8_STORAGE = True
 
 
 # ------------------------------------------------------------------------------------------------------------

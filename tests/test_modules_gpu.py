@@ -405,3 +405,42 @@ def test_fused_gate_falls_back_when_the_library_refuses(oa, monkeypatch):
     gate = ops.gate_fwd(hidden, H, w1, b1, scaling=1.0)
     want = A.attention_core(q, k, v, softmax_fn=sm, scale_div=8.0, attention_mask=pad, gate=gate * 2.0)
     assert torch.equal(got, want) and torch.equal(gp.out, gate[..., 0])
+
+
+def test_quantised_opt_uses_the_int8_storage_core(oa, monkeypatch):
+    """QuantizedOPTAttentionWithExtras on a purely causal mask (and without one): the q/k/v QuantLinear outputs go to the
+    attention core as 8-bit indices (integer matrix cores); same module output as the fake-quant kernels on the float values
+    up to rare single steps of the output grid, and the (k, v) cache it returns is the dequantised projections."""
+    from outeffhop_amd import ops, quantization as Q
+
+    torch.manual_seed(21)
+    dev = torch.device("cuda:0")
+    B, T, E, H = 3, 96, 256, 4
+    org = oa.OPTAttentionWithExtras(E, H, is_decoder=True, softmax_fn=oa.SOFTMAX_MAPPING["softmax1"]).to(dev).eval()
+    qm = oa.QuantizedOPTAttentionWithExtras(org, **_qparams(oa)).to(dev).eval()
+    qm.set_quant_state(weight_quant=True, act_quant=True)
+    mask = _decoder_mask(B, T, [T] * B, torch.float32, dev)
+    with torch.no_grad():
+        for _ in range(3):
+            qm(torch.randn(B, T, E, device=dev), attention_mask=mask)
+        qm.fix_ranges()
+        x = torch.randn(B, T, E, device=dev)
+        calls = []
+        real = ops.attn_fwd_i8
+        monkeypatch.setattr(ops, "attn_fwd_i8", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        out8, w8, past8 = qm(x, attention_mask=mask)
+        out8n, _, _ = qm(x)
+        assert len(calls) == 2 and w8 is None
+        monkeypatch.setattr(Q, "INT8_STORAGE", False)
+        outf, _, pastf = qm(x, attention_mask=mask)
+        outfn, _, _ = qm(x)
+        assert len(calls) == 2
+    step = float(qm.out_proj.activation_quantizer.quantizer.delta)
+    for a, b_ in ((out8, outf), (out8n, outfn)):
+        err = (a - b_).abs()
+        assert float(err.max()) <= 2.05 * step and float((err > 0.5 * step).float().mean()) < 5e-3, (float(err.max()), step)
+    assert torch.equal(past8[0], pastf[0]) and torch.equal(past8[1], pastf[1])
+    # a mask with padded keys is not the integer path's: the fake-quant kernels run (no call)
+    with torch.no_grad():
+        qm(x, attention_mask=_decoder_mask(B, T, [T, T - 5, T], torch.float32, dev))
+    assert len(calls) == 2
