@@ -252,7 +252,7 @@ void fill_params(AttnParams& P, const oeh_attn_desc* d, const void* q, const voi
     P.ctx_before_gate = fq->ctx_quant_before_gate ? 1 : 0;
   }
   P.stamps = g_stamps;
-  P.prio = (g_prio && d->causal) ? g_prio : 0;
+  P.prio = (g_prio == 3 || (g_prio && d->causal)) ? g_prio : 0;
   if (P.prio == 2 && (((d->Sq + 63) / 64) & 1)) P.prio = 0;  // slab pairing needs an even slab count
   P.nQT = (d->Sq + 63) / 64;
   P.nBH = d->B * d->H;
