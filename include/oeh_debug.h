@@ -1,0 +1,28 @@
+/*
+ * oeh_debug.h - diagnostic hooks of liboeh_hip.so.  NOT part of the product ABI (include/oeh.h): process-global, not
+ * thread-safe, they change which kernel variant oeh_attn_fwd launches for the whole process.  They exist for the A/B timing
+ * tools under tools/ and for the tests that force a second kernel over the same problem (tests/test_attn_gpu.py).
+ *
+ * They do nothing unless the environment variable OEH_DEBUG_HOOKS=1 was set when the library was first used; otherwise
+ * they return OEH_ENOTSUP (-95) and leave the library's behaviour untouched.
+ */
+#ifndef OEH_DEBUG_H_
+#define OEH_DEBUG_H_
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* off_mask: bit (1 << v) disables kernel variant v (1 one-pass, 2 full-row, 3 general, 4 any-shape, 5 small-shape; 6 / 7 the
+ * fp32-storage forms of the one-pass / full-row kernels); bit 8 lets the one-pass kernel take rows of <= 128 keys too;
+ * bits 9-10: causal workgroups' wave priority experiments.  flash_mq_force != 0 fixes the one-pass kernel's query blocks per
+ * wave.  (0, 0) restores the defaults.  Returns 0, or -95 when the hooks are not enabled. */
+int oeh_debug_set_variant(int off_mask, int flash_mq_force);
+
+/* device buffer of 32 u64 per wave that the one-pass / full-row kernels fill with s_memtime / s_memrealtime stamps
+ * (tools/timeline.py); NULL switches the stamps off.  Returns 0, or -95 when the hooks are not enabled. */
+int oeh_debug_set_stamps(void* device_buffer);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OEH_DEBUG_H_ */

@@ -1,6 +1,7 @@
 // extern "C" entry points of liboeh_hip.so (declared in include/oeh.h): argument validation, kernel
 // variant selection and launch.  No allocation, no synchronisation: safe under hipGraph capture.
 #include "../../include/oeh.h"
+#include "../../include/oeh_debug.h"
 #include "oeh_attn_params.h"
 
 #include <cmath>
@@ -313,6 +314,7 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
     P.i8_cv = 128 - (int)desc->v_grid.zero_point; P.i8_cp = 128 - (int)fq->probs.zero_point;
     P.i8_k1 = (float)((double)desc->q_grid.scale * (double)desc->k_grid.scale * mult / (double)fq->scores.scale);
     P.i8_so = (float)((double)fq->probs.scale * (double)desc->v_grid.scale);
+    P.nBHpad = (P.nBH + 15) & ~15;  // head pairs on one XCD (oeh_attn_i8.hip)
     return oeh::launch_attn_i8(P, desc->o_dtype, st);
   }
   if (var == V_FLASH) {
@@ -402,15 +404,21 @@ int oeh_fake_quant_range(const void* x, void* y, int64_t n, int32_t dtype, const
   return oeh::launch_fake_quant_range(x, y, n, dtype, xmin_xmax, (float)((1 << n_bits) - 1), eps, reinterpret_cast<hipStream_t>(stream));
 }
 
-// Diagnostic hooks (NOT part of the ABI in include/oeh.h; process-global, not thread-safe; tools/ and tests only):
-//  oeh_debug_set_variant: bit (1 << Variant) of off_mask disables a kernel variant, bit 8 lets the one-pass kernel take
-//    rows of <= 128 keys too, flash_mq_force != 0 fixes its query blocks per wave (A/B timing, forced-variant tests);
-//  oeh_debug_set_stamps: device buffer of 32 u64 per wave that the one-pass kernel fills with s_memtime /
-//    s_memrealtime stamps when non-null (tools/timeline.py).
-void oeh_debug_set_variant(int off_mask, int flash_mq_force) {
-  g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force; g_prio = (off_mask >> 9) & 3;
+// Diagnostic hooks: include/oeh_debug.h (NOT part of the product ABI; inert unless OEH_DEBUG_HOOKS=1 in the environment)
+static bool debug_hooks_on() {
+  static const bool on = [] { const char* e = std::getenv("OEH_DEBUG_HOOKS"); return e != nullptr && e[0] == '1'; }();
+  return on;
 }
-void oeh_debug_set_stamps(void* device_buffer) { g_stamps = static_cast<unsigned long long*>(device_buffer); }
+int oeh_debug_set_variant(int off_mask, int flash_mq_force) {
+  if (!debug_hooks_on()) return OEH_ENOTSUP;
+  g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force; g_prio = (off_mask >> 9) & 3;
+  return OEH_OK;
+}
+int oeh_debug_set_stamps(void* device_buffer) {
+  if (!debug_hooks_on()) return OEH_ENOTSUP;
+  g_stamps = static_cast<unsigned long long*>(device_buffer);
+  return OEH_OK;
+}
 
 int oeh_abi_version(void) { return OEH_ABI_VERSION; }
 

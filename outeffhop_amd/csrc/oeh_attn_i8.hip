@@ -15,7 +15,7 @@
 //
 // Layouts: q, k (B,H,S,64) views as everywhere; v TRANSPOSED, (B,H,64,Sk) with the keys contiguous (v_stride = batch, head,
 // d row): the second product sums over keys, so its operand wants 16 consecutive keys of one d per lane, and an LDS-DMA
-// cannot transpose.  LDS: K tiles [64 keys][64 B] and V^T tiles [64 d][64 B], 3 + 3 slots of 4 KB, fed by LDS-DMA exactly
+// cannot transpose.  LDS: K tiles [64 keys][64 B] and V^T tiles [64 d][64 B], 6 + 6 slots of 4 KB, fed by LDS-DMA exactly
 // like the 16-bit kernels; the 16-B chunk of a row is XOR-swizzled with {0,3,2,1}[row group] so that ds_read_b128 of either
 // operand is conflict-free (the row groups differ: keys are dealt to MFMA rows as key = 16 (row >> 2) + 4 t + (row & 3) so
 // that a lane ends up with 16 CONSECUTIVE keys of its query - the k order the V^T operand has).
@@ -31,14 +31,22 @@ __device__ __forceinline__ int perm4(int x) { return (0x6C >> ((x & 3) * 2)) & 3
 
 template <int NT, int OUT>
 __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P) {
-  constexpr int D = 64, KT = NT / 4, TILEB = 64 * 64, R = 3, DT = 4;
+  constexpr int D = 64, KT = NT / 4, TILEB = 64 * 64, DT = 4;
+  // The K and the V^T phases have eight MFMAs per wave and tile between two barriers: they run at the pace the tiles ARRIVE.
+  // Tiles are 4 KB here, so the rings are deep - R slots, PF tiles requested ahead (PF <= R - 1: a slot is refilled only
+  // after the barrier that follows its last readers).
+  constexpr int R = 6, PF = 4;
   constexpr float RELMASK = -1.0e30f;
   constexpr bool OUT32 = (OUT == IN_F32);
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * R * TILEB];
 
   const int bid = blockIdx.x;
   const int qt_rev = bid / P.nBHpad;
-  const int bh = bid - qt_rev * P.nBHpad;
+  // Blocks b and b + 8 run on one XCD.  In the (B,S,H*64) int8 layout two neighbouring heads share every 128-byte line
+  // of q and k, so heads 2i and 2i+1 are given block ids 8 apart (nBHpad is a multiple of 16): the second half of a line is
+  // an L2 hit instead of a second HBM fetch (57 -> 4x MB per launch on the OPT shape against 44 MB algorithmic).
+  const int bhr = bid - qt_rev * P.nBHpad;
+  const int bh = (bhr & ~15) | ((bhr & 7) << 1) | ((bhr >> 3) & 1);
   if (bh >= P.nBH) return;
   const int qt = P.nQT - 1 - qt_rev;
   const int b = bh / P.H, h = bh - b * P.H;
@@ -74,8 +82,17 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
     glds16(src, slot);
     ++nx;
   };
-  issue_next();
-  if (1 < T) issue_next();
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+    if (p < T) issue_next();
+  auto wait_tile = [&](const int i) {  // tile i of the stream has landed: all but the min(PF - 1, T - 1 - i) younger requests of this wave
+    const int younger = min(PF - 1, T - 1 - i);
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  static_assert(PF == 4 && PF <= R - 1, "wait_tile's immediates");
 
   // ---- Q: global -> registers in the B-operand layout (query q0 + c, head dims 16 g ..), and its row sum
   i4 qf;
@@ -84,14 +101,14 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
     qf = *reinterpret_cast<const i4*>(qp);
   }
   const int ones = 0x01010101;
-  const i4 ones4 = i4{ones, ones, ones, ones};
+  i4 ones4 = i4{ones, ones, ones, ones};
+  asm volatile("" : "+v"(ones4));  // one register quad for the whole kernel (the compiler would rebuild the constant before every use)
   int asum = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) asum = __builtin_amdgcn_sdot4(qf[j], ones, asum, false);
   asum += __shfl_xor(asum, 16);
   asum += __shfl_xor(asum, 32);
   const int cq = P.i8_cq, ck = P.i8_ck, cv = P.i8_cv, cp = P.i8_cp;   // 128 - zero point of q, k, v and of the probabilities
-  const bool corr = (cq | ck) != 0;
   // y = (quotient of the score by the score grid's step) = k1 * (sum a b + cq ksum) + rq
   const float k1 = P.i8_k1;
   const float rq = (float)(ck * asum + D * cq * ck) * k1;
@@ -103,20 +120,24 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     if (kt < n_kt) {
-      wait_tiles_in_flight<1>(min(1, T - 1 - kt));
+      wait_tile(kt);
       barrier_mem();
-      if (kt + 2 < T) issue_next();
+      if (kt + PF < T) issue_next();
       const unsigned char* tb = lds + (kt % R) * TILEB;
+      i4 kf[4], acc[4], ks[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) kf[t] = *reinterpret_cast<const i4*>(tb + (krow_base + 4 * t) * 64 + kswz);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const i4 kf = *reinterpret_cast<const i4*>(tb + (krow_base + 4 * t) * 64 + kswz);
-        i4 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, qf, i4{0, 0, 0, 0}, 0, 0, 0);
-        if (corr) {
-          const i4 ks = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf, ones4, i4{0, 0, 0, 0}, 0, 0, 0);  // sum_d b of the lane's four keys
+        acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf[t], qf, i4{0, 0, 0, 0}, 0, 0, 0);
+        ks[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf[t], ones4, i4{0, 0, 0, 0}, 0, 0, 0);  // sum_d b of the lane's four keys (always: the
+      }                                                                                         // matrix pipe idles here, a branch per sub-tile costs more)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] += __mul24(cq, ks[r]);  // |ksum| <= 64 * 128
-        }
-        s[kt * 4 + t] = f4{(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
+      for (int t = 0; t < 4; ++t) {
+        f4 f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f[r] = (float)(acc[t][r] + __mul24(cq, ks[t][r]));  // |ksum| <= 64 * 128
+        s[kt * 4 + t] = f;
       }
     }
   }
@@ -202,16 +223,18 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   for (int kt = 0; kt < KT; ++kt) {
     if (kt < n_kt) {
       const int i = n_kt + kt;
-      wait_tiles_in_flight<1>(min(1, T - 1 - i));
+      wait_tile(i);
       barrier_mem();
-      if (i + 2 < T) issue_next();
+      if (i + PF < T) issue_next();
       const unsigned char* tb = lds + (R + kt % R) * TILEB;
       const i4 pb = i4{(int)f32_bits(s[kt * 4 + 0][0]), (int)f32_bits(s[kt * 4 + 1][0]), (int)f32_bits(s[kt * 4 + 2][0]), (int)f32_bits(s[kt * 4 + 3][0])};
+      i4 vf[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) vf[dt] = *reinterpret_cast<const i4*>(tb + (16 * dt + c) * 64 + vswz);
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const i4 vf = *reinterpret_cast<const i4*>(tb + (16 * dt + c) * 64 + vswz);
-        o[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, pb, o[dt], 0, 0, 0);
-        vs[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf, ones4, vs[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf[dt], pb, o[dt], 0, 0, 0);
+        vs[dt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vf[dt], ones4, vs[dt], 0, 0, 0);
       }
     }
   }

@@ -5,7 +5,8 @@ theory_verification/layers.py:90-178.  Layout (B,L,H,E) / (B,S,H,E) / (B,S,H,D) 
 
 Modes: 'softmax1' | 'softmax' | 'clip' | 'clip_softmax1' run on the GPU kernel.  The reference's
 ClipSoftmax_1.__init__ calls super(ClipSoftmax, self) (clip_softmax.py:46) so mode='clip_softmax1' raises TypeError
-there; here it works.  'entmax' / 'sparsemax' are sort-based activations outside the HIP hot path.
+there; here it works.  'entmax' (the constructor default: alpha-entmax with a learnable alpha) and 'sparsemax' are sort /
+bisection based activations outside the HIP hot path: torch ops (sparse_activations.py) around two library GEMMs.
 """
 from __future__ import annotations
 
@@ -17,6 +18,7 @@ from torch import nn
 from .attention import unfused_core
 from .ops import SoftmaxSpec, attn_fwd
 from .softmax import SoftmaxFn
+from .sparse_activations import EntmaxAlpha, Sparsemax
 
 _MODES = {
     "softmax1": lambda eta, gamma: SoftmaxSpec(1, False, 0.0, 1.0),
@@ -32,14 +34,22 @@ class Association(nn.Module):
         self.scale = scale
         self.dropout = nn.Dropout(attention_dropout)
         self.mode = mode
-        if mode not in _MODES:
-            raise NotImplementedError(f"Association mode {mode!r}: only {sorted(_MODES)} are on the MI355X hot path")
-        self.softmax = SoftmaxFn(mode, _MODES[mode](eta, gamma))
+        if mode in _MODES:
+            self.softmax = SoftmaxFn(mode, _MODES[mode](eta, gamma))
+        elif mode == "entmax":
+            self.softmax = EntmaxAlpha()
+        elif mode == "sparsemax":
+            self.softmax = Sparsemax()
+        else:
+            raise ValueError(f"Association mode {mode!r}: one of {sorted(_MODES) + ['entmax', 'sparsemax']}")
 
     def forward(self, queries, keys, values):
         B, L, H, E = queries.shape
         scale = self.scale or 1.0 / sqrt(E)
         q, k, v = queries.permute(0, 2, 1, 3), keys.permute(0, 2, 1, 3), values.permute(0, 2, 1, 3)
+        if not isinstance(self.softmax, SoftmaxFn):  # sparse activations: scores materialised, torch ops (outside the HIP path)
+            probs = self.dropout(self.softmax(scale * torch.matmul(q, k.transpose(-1, -2))))
+            return torch.matmul(probs, v).permute(0, 2, 1, 3).contiguous()
         if self.training and self.dropout.p > 0.0:
             ctx, _, _ = unfused_core(q, k, v, softmax_fn=self.softmax, scale=scale, dropout=self.dropout)
             return ctx.permute(0, 2, 1, 3).contiguous()

@@ -8,7 +8,7 @@ Mirrors the reference's SOFTMAX_MAPPING (OutEffHop/transformers_language/models/
 Error behaviour kept from the reference: the softmax_1 family takes no `dtype=` keyword
 (vutils/softmax_1.py:24 -> TypeError, the failure OPT hits under fp16); the vanilla family
 forwards `dtype=` like torch.nn.functional.softmax (the input is cast first).
-"entmax" is registered for completeness but is outside the HIP hot path.
+"entmax" (entmax-1.5) is a torch-ops callable outside the HIP hot path (sparse_activations.py).
 """
 from __future__ import annotations
 
@@ -47,8 +47,12 @@ def _num(tok: str) -> float:
     return float(tok.replace("-.", "-0.") if tok.startswith("-.") else tok)
 
 
-def _entmax_unavailable(*a, **k):
-    raise NotImplementedError("'entmax' (sort-based entmax-1.5) is not part of the MI355X hot path; see SURVEY.md section 2, row 18")
+def _entmax15(data, dim=-1, **kw):
+    """`entmax15` of the reference's registry (models/softmax.py:25): torch ops on the tensor's device, outside the HIP hot
+    path (sparse_activations.py); the attention modules run it through their observable path (`spec_of` gives None)."""
+    from .sparse_activations import entmax15
+
+    return entmax15(data, dim=dim)
 
 
 def _build() -> Dict[str, object]:
@@ -67,7 +71,7 @@ def _build() -> Dict[str, object]:
         elif k == "softmax1":
             table[k] = SoftmaxFn(k, SoftmaxSpec(1, False, 0.0, 1.0))
         elif k == "entmax":
-            table[k] = _entmax_unavailable
+            table[k] = _entmax15
         else:
             fam, g, e = re.fullmatch(r"(clipped|clippedsoftmax1)\(([^:]+):([^)]+)\)", k).groups()
             gamma, eta = _num(g), _num(e)
@@ -83,6 +87,27 @@ def _build() -> Dict[str, object]:
 SOFTMAX_MAPPING: Dict[str, object] = _build()
 
 softmax_1 = SOFTMAX_MAPPING["softmax1"]
+
+
+class Softmax_1(torch.nn.Module):
+    """`nn.Module` form of softmax_1 (vutils/softmax_1.py:30-50; STanHop's cross_models/softmax_1.py): runs the HIP row kernel."""
+
+    __constants__ = ["dim"]
+
+    def __init__(self, dim: int = -1):
+        super().__init__()
+        self.dim = dim
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        if not hasattr(self, "dim"):
+            self.dim = None
+
+    def forward(self, input):
+        return softmax_1(input, self.dim)
+
+    def extra_repr(self):
+        return f"dim={self.dim}"
 
 
 def clipped_softmax(gamma: float, eta: float) -> SoftmaxFn:

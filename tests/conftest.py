@@ -9,6 +9,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the tests force alternative kernel variants over the same problems through include/oeh_debug.h; the hooks are inert
+# unless this is set before the library is first used
+os.environ.setdefault("OEH_DEBUG_HOOKS", "1")
 
 
 def pytest_configure(config):

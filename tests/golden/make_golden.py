@@ -666,13 +666,44 @@ def gen_core_cases():
     save("core_attn.npz", **arrays)
 
 
+def gen_sparse_acts():
+    """The sort / bisection based activations of the reference's registries (outside the HIP path; torch ops on this side):
+    SOFTMAX_MAPPING["entmax"] = entmax15 (vutils/entmax.py), Sparsemax (vutils/sparse_max.py), and STanHop's default
+    Association activation EntmaxAlpha (cross_models/entmax.py) incl. the Association output with mode='entmax'/'sparsemax'."""
+    from vutils.entmax import entmax15
+    from vutils.sparse_max import Sparsemax
+
+    sys.path.insert(0, os.path.join(REF, "STanHop_time_seeries"))
+    from cross_models.entmax import EntmaxAlpha, entmax_bisect
+    from cross_models.hopfield import Association
+
+    g = torch.Generator().manual_seed(1011)
+    x = torch.randn(4, 3, 9, 21, generator=g) * 2.5
+    x[0, 0, 0] = 0.0          # a uniform row
+    x[0, 0, 1, :3] = 50.0     # a three-way tie far above the rest
+    arrays = {"x": _np(x), "entmax15": _np(entmax15(x, dim=-1)), "entmax15_dim1": _np(entmax15(x, dim=1)),
+              "sparsemax": _np(Sparsemax(dim=-1)(x)), "bisect_1p3": _np(entmax_bisect(x, 1.3)), "bisect_2p0": _np(entmax_bisect(x, 2.0))}
+    ea = EntmaxAlpha().eval()
+    with torch.no_grad():
+        ea.alpha.fill_(0.37)
+        arrays["entmax_alpha_param"] = _np(ea.alpha)
+        arrays["entmax_alpha_out"] = _np(ea(x))
+        q, k, v = torch.randn(3, 7, 4, 16, generator=g), torch.randn(3, 5, 4, 16, generator=g), torch.randn(3, 5, 4, 16, generator=g)
+        arrays.update(q=_np(q), k=_np(k), v=_np(v))
+        m = Association(mode="entmax").eval()
+        m.softmax.alpha.fill_(0.37)
+        arrays["assoc[entmax]"] = _np(m(q, k, v))
+        arrays["assoc[sparsemax]"] = _np(Association(mode="sparsemax").eval()(q, k, v))
+    save("sparse_acts.npz", **arrays)
+
+
 def main():
     only = set(sys.argv[1:])
     assert os.path.isdir(REF), "reference not mounted: golden fixtures can only be generated in the build container"
     torch.set_num_threads(1)  # deterministic reduction order for the captured outputs
     _shim()
     gens = [gen_softmax_rows, gen_fakequant, gen_range_estimators, gen_bert_fp, gen_opt_fp, gen_int8, gen_vit, gen_core_cases,
-            gen_stanhop, gen_theory_cfg1]
+            gen_stanhop, gen_theory_cfg1, gen_sparse_acts]
     sys.path.insert(0, os.path.join(REF, "OutEffHop"))
     for fn in gens:  # `make_golden.py gen_vit` regenerates one file
         if not only or fn.__name__ in only:

@@ -104,3 +104,22 @@ def test_fp32_storage_variants():
     assert ops.attn_variant(16, 12, 512, 512, 64, torch.float32, fq=True) == "fast16/NT32/D64/f32/fq"
     assert ops.attn_variant(32, 12, 128, 128, 64, torch.float32) == "flash16/MQ1/D64/f32"
     assert ops.attn_variant(2, 2, 40, 40, 48, torch.float32) == "generic"
+
+
+def test_debug_hooks_are_inert_unless_enabled():
+    """include/oeh_debug.h: the process-global diagnostic hooks change nothing - and say so - unless
+    OEH_DEBUG_HOOKS=1 is in the environment when the library is first used."""
+    import sys
+
+    code = ("import ctypes, sys; lib = ctypes.CDLL(sys.argv[1]); "
+            "print(lib.oeh_debug_set_variant(4, 0), lib.oeh_debug_set_stamps(None))")
+    from outeffhop_amd import _lib
+
+    env = {k: v for k, v in os.environ.items() if k != "OEH_DEBUG_HOOKS"}
+    off = subprocess.run([sys.executable, "-c", code, _lib.LIB_PATH], env=env, capture_output=True, text=True)
+    on = subprocess.run([sys.executable, "-c", code, _lib.LIB_PATH], env={**env, "OEH_DEBUG_HOOKS": "1"}, capture_output=True, text=True)
+    assert off.stdout.split() == ["-95", "-95"], off.stdout + off.stderr
+    assert on.stdout.split() == ["0", "0"], on.stdout + on.stderr
+    hdr = open(os.path.join(ROOT, "include", "oeh_debug.h")).read()
+    assert "oeh_debug_set_variant" in hdr and "oeh_debug_set_stamps" in hdr
+    assert "oeh_debug" not in open(os.path.join(ROOT, "include", "oeh.h")).read()

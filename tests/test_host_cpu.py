@@ -46,8 +46,7 @@ def test_registry_matches_reference_keys_and_parameters():
     for k, b, ga, et in zip(g["keys"], g["key_base"], g["key_gamma"], g["key_eta"]):
         s = oa.SOFTMAX_MAPPING[str(k)].spec
         assert (s.base, s.gamma if s.clip else 0.0, s.eta if s.clip else 1.0) == (int(b), float(ga), float(et)), k
-    with pytest.raises(NotImplementedError):
-        oa.SOFTMAX_MAPPING["entmax"](torch.zeros(2, 2))
+    assert torch.allclose(oa.SOFTMAX_MAPPING["entmax"](torch.zeros(2, 2)), torch.full((2, 2), 0.5))  # entmax-1.5: torch ops, outside the HIP path
     with pytest.raises(TypeError, match="unexpected keyword argument 'dtype'"):
         oa.SOFTMAX_MAPPING["softmax1"](torch.zeros(2, 2), dim=-1, dtype=torch.float32)  # vutils/softmax_1.py:24
     with pytest.raises(TypeError):
@@ -109,8 +108,7 @@ def test_constructor_semantics_and_errors():
     assert not m(x)[0].any() and m(x)[0].shape == x.shape  # skip_attn needs no GPU
     m = oa.BertSelfAttentionWithExtras(Cfg(), attn_gate_type=oa.AttentionGateType.conditional_per_token, attn_gate_init=0.25)
     assert abs(float(m.alpha[0].bias) - oa.logit(0.25)) < 1e-6
-    with pytest.raises(NotImplementedError):
-        oa.Association(mode="entmax")
+    assert oa.Association().mode == "entmax"  # the reference's default constructs (torch-op activation outside the HIP path)
     oa.Association(mode="clip_softmax1")  # TypeError in the reference (clip_softmax.py:46), works here
     o = oa.OPTAttentionWithExtras(128, 2)
     with pytest.raises(ValueError, match="Attention mask should be of size"):
@@ -245,3 +243,39 @@ def test_attn_variant_describes_the_real_problem():
     assert not ops.fused_gate_ok(2, 4, 96, 64, 64, f16, causal=True)            # Sq > Sk causal: general kernel
     assert not ops.fused_gate_ok(2, 4, 64, 64, 64, f16, full_mask=True)
     assert ops.fused_gate_ok(2, 4, 64, 64, 64, f16) and not ops.fused_gate_ok(2, 4, 64, 64, 64, f16, units=64)
+
+
+def test_sparse_activations_match_the_reference():
+    """VERDICT r1 missing #8: every registry key and constructor default of the reference constructs and runs: entmax-1.5
+    (SOFTMAX_MAPPING["entmax"]), sparsemax, STanHop's EntmaxAlpha (Association's DEFAULT mode) and the `Softmax_1` module.
+    Torch-op implementations outside the HIP path, against values captured from the reference (tests/golden/sparse_acts.npz)."""
+    from outeffhop_amd import sparse_activations as SA
+
+    g = load_golden("sparse_acts.npz")
+    x = torch.from_numpy(g["x"])
+    tol = dict(rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(oa.SOFTMAX_MAPPING["entmax"](x, dim=-1).numpy(), g["entmax15"], **tol)
+    np.testing.assert_allclose(SA.entmax15(x, dim=1).numpy(), g["entmax15_dim1"], **tol)
+    np.testing.assert_allclose(SA.Sparsemax()(x).numpy(), g["sparsemax"], **tol)
+    np.testing.assert_allclose(SA.entmax_bisect(x, 1.3).numpy(), g["bisect_1p3"], **tol)
+    np.testing.assert_allclose(SA.entmax_bisect(x, 2.0).numpy(), g["bisect_2p0"], **tol)
+    np.testing.assert_allclose(SA.sparsemax(x).numpy(), g["bisect_2p0"], rtol=1e-5, atol=1e-6)  # alpha = 2 IS sparsemax
+    for p in (SA.entmax15(x), SA.sparsemax(x), SA.entmax_bisect(x, 1.3)):
+        assert float((p.sum(-1) - 1).abs().max()) < 1e-5 and float(p.min()) >= 0.0
+    ea = SA.EntmaxAlpha()
+    assert {"alpha", "alpha_chooser"} == set(dict(ea.named_parameters()))
+    with torch.no_grad():
+        ea.alpha.copy_(torch.from_numpy(g["entmax_alpha_param"]))
+        np.testing.assert_allclose(ea(x).numpy(), g["entmax_alpha_out"], **tol)
+    # Association(): the reference's constructor default is mode='entmax'
+    q, k, v = (torch.from_numpy(g[n]) for n in ("q", "k", "v"))
+    m = oa.Association().eval()
+    assert isinstance(m.softmax, SA.EntmaxAlpha)
+    with torch.no_grad():
+        m.softmax.alpha.copy_(torch.from_numpy(g["entmax_alpha_param"]))
+        np.testing.assert_allclose(m(q, k, v).numpy(), g["assoc[entmax]"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(oa.Association(mode="sparsemax").eval()(q, k, v).numpy(), g["assoc[sparsemax]"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        oa.Association(mode="nope")
+    sm = oa.Softmax_1(dim=-1)
+    assert sm.extra_repr() == "dim=-1" and oa.Hopfield(32, 2).inner_attention.mode == "entmax"

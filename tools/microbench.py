@@ -8,6 +8,8 @@ keys: B H S D causal pad clip int8 dtype(f16|bf16|f32) full iters reps gate base
 """
 import ctypes as C
 import sys
+import os as _os
+_os.environ.setdefault("OEH_DEBUG_HOOKS", "1")  # include/oeh_debug.h
 import os
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

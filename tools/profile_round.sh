@@ -23,3 +23,5 @@ for w in $WLS; do
   esac
 done
 python3 "$ROOT/tools/profile_summary.py" "$ROUND" "$OUT"
+# keep only the summary (gpurun copies back at most 64 MiB)
+for w in $WLS; do rm -rf "$OUT/$w"; done

@@ -4,6 +4,8 @@ Never quote run times from this build path: the stamps perturb the schedule; rea
 import ctypes as C
 import os
 import sys
+import os as _os
+_os.environ.setdefault("OEH_DEBUG_HOOKS", "1")  # include/oeh_debug.h
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
