@@ -119,7 +119,7 @@ typedef struct oeh_attn_desc {
    * The first layer runs on the matrix cores with the weights rounded to the storage dtype and fp32 accumulation -
    * what the reference's own Linear does in a 16-bit model - so values agree with oeh_gate_fwd (fp32 weights) to
    * ~1e-4, not bit for bit.  gate_out (B,H,Sq) fp32, optional, receives sigmoid(logit) without the scaling (the
-   * modules' last_gate_all_probs bookkeeping).  At most 16 hidden units, 16-bit MFMA variants only
+   * modules' last_gate_all_probs bookkeeping).  At most 64 hidden units (attn_gate_mlp2: head_dim), 16-bit MFMA variants only
    * ("fast16/...", "flash16/..."): OEH_ENOTSUP otherwise (use oeh_gate_fwd + `gate`). */
   const void* gate_hidden;
   int64_t gate_hidden_stride[2]; /* elements: batch, token */

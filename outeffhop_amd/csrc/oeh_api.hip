@@ -300,7 +300,7 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
   const Variant var = pick_variant(desc, q, k, v, o, fq);
   if (var == V_NONE) return OEH_ENOTSUP;
   if (desc->gate == nullptr && desc->gate_hidden != nullptr) {  // fused gate predictor: 16-bit MFMA variants, 16-B aligned rows
-    if ((var != V_FAST && var != V_FLASH) || desc->gate_units > 16 || desc->dtype == OEH_F32) return OEH_ENOTSUP;  // one 16-unit MFMA tile of hidden units
+    if ((var != V_FAST && var != V_FLASH) || desc->gate_units > 64 || desc->dtype == OEH_F32) return OEH_ENOTSUP;  // up to four 16-unit MFMA tiles of hidden units
     if (((reinterpret_cast<uintptr_t>(desc->gate_hidden) | (uintptr_t)(desc->gate_hidden_stride[0] * 2) | (uintptr_t)(desc->gate_hidden_stride[1] * 2)) & 15) != 0) return OEH_EALIGN;
   }
   AttnParams P;

@@ -219,8 +219,10 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
   // K tile R-1, issued after the gate has been formed); and the lane's share of the predictor weights (hidden unit c,
   // inputs 8g.. of each 32-wide k-step; first-layer bias and second-layer weights of units 4g..4g+3), requested in the
   // same round as everything else
-  f4 gw[KS][2];
-  f4 gb1v = f4{0.f, 0.f, 0.f, 0.f}, gw2v = f4{0.f, 0.f, 0.f, 0.f};
+  constexpr int GT = GATE ? 4 : 1;       // 16-unit MFMA tiles of predictor hidden units (<= 64 units: attn_gate_mlp2 has head_dim of them)
+  u4 gwf[GT][KS];                         // GATE: the lane's share of the first-layer weights, rounded to the storage dtype
+  f4 gb1v[GT], gw2v[GT];
+  int g_mt = 1;
   if constexpr (GATE) {
     const unsigned short* xbase = reinterpret_cast<const unsigned short*>(P.gh) + (long)b * P.ghs_b + (long)h * D;
     const unsigned xslot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((R - 1) * TILEB + wave * G * 1024));
@@ -238,21 +240,32 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
     if (1 < T) issue_next();
   }
   if constexpr (GATE) {
-    const int mm = P.g_units > 0 ? P.g_units : 1;  // <= 16 (host)
-    const bool uv = c < mm;
-    const float* wr = P.gw1 + ((long)h * mm + (uv ? c : 0)) * D + 8 * g;
+    const int mm = P.g_units > 0 ? P.g_units : 1;  // <= 64 (host)
+    g_mt = (mm + 15) >> 4;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      gw[ks][0] = *reinterpret_cast<const f4*>(wr + 32 * ks);
-      gw[ks][1] = *reinterpret_cast<const f4*>(wr + 32 * ks + 4);
-      if (!uv) gw[ks][0] = gw[ks][1] = f4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int tau = 0; tau < GT; ++tau) {
+      gb1v[tau] = gw2v[tau] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int u = 4 * g + r;
-      if (u < mm) {
-        gb1v[r] = P.gb1[(long)h * mm + u];
-        gw2v[r] = P.g_units > 0 ? P.gw2[(long)h * mm + u] : 1.0f;
+      for (int ks = 0; ks < KS; ++ks) gwf[tau][ks] = u4{0u, 0u, 0u, 0u};
+      if (tau < g_mt) {  // hidden unit 16 tau + c, inputs 8g.. of each 32-wide k-step; first-layer bias and second-layer weights of units 16 tau + 4g..4g+3
+        const int u = 16 * tau + c;
+        const bool uv = u < mm;
+        const float* wr = P.gw1 + ((long)h * mm + (uv ? u : 0)) * D + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          f4 w0 = *reinterpret_cast<const f4*>(wr + 32 * ks), w1 = *reinterpret_cast<const f4*>(wr + 32 * ks + 4);
+          if (!uv) w0 = w1 = f4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (IN == IN_BF16) gwf[tau][ks] = u4{pack2_bf16(w0[0], w0[1]), pack2_bf16(w0[2], w0[3]), pack2_bf16(w1[0], w1[1]), pack2_bf16(w1[2], w1[3])};
+          else gwf[tau][ks] = u4{pack2_f16(w0[0], w0[1]), pack2_f16(w0[2], w0[3]), pack2_f16(w1[0], w1[1]), pack2_f16(w1[2], w1[3])};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ur = 16 * tau + 4 * g + r;
+          if (ur < mm) {
+            gb1v[tau][r] = P.gb1[(long)h * mm + ur];
+            gw2v[tau][r] = P.g_units > 0 ? P.gw2[(long)h * mm + ur] : 1.0f;
+          }
+        }
       }
     }
   }
@@ -272,21 +285,23 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
   }
   float gate_row = 1.0f;  // GATE: sigmoid(logit) * scaling of this lane's query row
   if constexpr (GATE) {
-    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    u4 xf[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const u4 xf = *reinterpret_cast<const u4*>(kaddr[ks] + (R - 1) * TILEB + wave * 16 * ROWB);
-      u4 wf;
-      if constexpr (IN == IN_BF16) wf = u4{pack2_bf16(gw[ks][0][0], gw[ks][0][1]), pack2_bf16(gw[ks][0][2], gw[ks][0][3]), pack2_bf16(gw[ks][1][0], gw[ks][1][1]), pack2_bf16(gw[ks][1][2], gw[ks][1][3])};
-      else wf = u4{pack2_f16(gw[ks][0][0], gw[ks][0][1]), pack2_f16(gw[ks][0][2], gw[ks][0][3]), pack2_f16(gw[ks][1][0], gw[ks][1][1]), pack2_f16(gw[ks][1][2], gw[ks][1][3])};
-      acc = mfma16<IN>(wf, xf, acc);  // rows = hidden units 4g+r, column = token c
-    }
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const u4*>(kaddr[ks] + (R - 1) * TILEB + wave * 16 * ROWB);
     float a = 0.0f;
-    if (P.g_units > 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) a = __builtin_fmaf(__builtin_fmaxf(acc[r] + gb1v[r], 0.0f), gw2v[r], a);  // padded units: w2 = 0
-    } else {
-      a = (g == 0) ? acc[0] + gb1v[0] : 0.0f;  // Linear(D,1): unit 0 only
+    for (int tau = 0; tau < GT; ++tau) {
+      if (tau < g_mt) {
+        f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = mfma16<IN>(gwf[tau][ks], xf[ks], acc);  // rows = hidden units 16 tau + 4g + r, column = token c
+        if (P.g_units > 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a = __builtin_fmaf(__builtin_fmaxf(acc[r] + gb1v[tau][r], 0.0f), gw2v[tau][r], a);  // padded units: w2 = 0
+        } else {
+          a = (g == 0) ? acc[0] + gb1v[0][0] : 0.0f;  // Linear(D,1): unit 0 only
+        }
+      }
     }
     {  // sum over the 4 lanes (c, c+16, c+32, c+48) of the row
       auto s1 = __builtin_amdgcn_permlane16_swap(f32_bits(a), f32_bits(a), false, false);

@@ -223,8 +223,10 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       }
     }
   }
-  f4 gw[MQ][KS][2];                      // GATE: the lane's share of the predictor weights, per block (same for both: one head)
-  f4 gb1v = f4{0.f, 0.f, 0.f, 0.f}, gw2v = f4{0.f, 0.f, 0.f, 0.f};
+  constexpr int GT = GATE ? 4 : 1;       // 16-unit MFMA tiles of predictor hidden units (<= 64 units)
+  u4 gwf[GT][KS];                        // GATE: the lane's share of the first-layer weights, rounded to the storage dtype
+  f4 gb1v[GT], gw2v[GT];
+  int g_mt = 1;
   if constexpr (GATE) {  // the workgroup's layer-input rows, head h's slice, slab t as a K-shaped tile at t*TILEB of stage 1
     const unsigned char* xbase = reinterpret_cast<const unsigned char*>(P.gh) + 2 * ((long)b * P.ghs_b + (long)h * D);
     const unsigned xslot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(1 * STAGEB + wave * G * 1024));
@@ -243,22 +245,33 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     issue_next();
     if (!GATE && 1 < n_kt) issue_next();
   }
-  if constexpr (GATE) {  // weights: hidden unit c, inputs 8g.. of each 32-wide k-step; b1 / w2 of units 4g..4g+3
-    const int mm = P.g_units > 0 ? P.g_units : 1;  // <= 16 (host)
-    const bool uv = c < mm;
-    const float* wr = P.gw1 + ((long)h * mm + (uv ? c : 0)) * D + 8 * g;
+  if constexpr (GATE) {  // weights: hidden unit 16 tau + c, inputs 8g.. of each 32-wide k-step; b1 / w2 of units 16 tau + 4g..4g+3
+    const int mm = P.g_units > 0 ? P.g_units : 1;  // <= 64 (host)
+    g_mt = (mm + 15) >> 4;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      gw[0][ks][0] = *reinterpret_cast<const f4*>(wr + 32 * ks);
-      gw[0][ks][1] = *reinterpret_cast<const f4*>(wr + 32 * ks + 4);
-      if (!uv) gw[0][ks][0] = gw[0][ks][1] = f4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int tau = 0; tau < GT; ++tau) {
+      gb1v[tau] = gw2v[tau] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int u = 4 * g + r;
-      if (u < mm) {
-        gb1v[r] = P.gb1[(long)h * mm + u];
-        gw2v[r] = P.g_units > 0 ? P.gw2[(long)h * mm + u] : 1.0f;
+      for (int ks = 0; ks < KS; ++ks) gwf[tau][ks] = u4{0u, 0u, 0u, 0u};
+      if (tau < g_mt) {
+        const int u = 16 * tau + c;
+        const bool uv = u < mm;
+        const float* wr = P.gw1 + ((long)h * mm + (uv ? u : 0)) * D + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          f4 w0 = *reinterpret_cast<const f4*>(wr + 32 * ks), w1 = *reinterpret_cast<const f4*>(wr + 32 * ks + 4);
+          if (!uv) w0 = w1 = f4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (IN == IN_BF16) gwf[tau][ks] = u4{pack2_bf16(w0[0], w0[1]), pack2_bf16(w0[2], w0[3]), pack2_bf16(w1[0], w1[1]), pack2_bf16(w1[2], w1[3])};
+          else gwf[tau][ks] = u4{pack2_f16(w0[0], w0[1]), pack2_f16(w0[2], w0[3]), pack2_f16(w1[0], w1[1]), pack2_f16(w1[2], w1[3])};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ur = 16 * tau + 4 * g + r;
+          if (ur < mm) {
+            gb1v[tau][r] = P.gb1[(long)h * mm + ur];
+            gw2v[tau][r] = P.g_units > 0 ? P.gw2[(long)h * mm + ur] : 1.0f;
+          }
+        }
       }
     }
   }
@@ -323,27 +336,25 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
 #pragma unroll
   for (int j = 0; j < MQ; ++j) gate_row[j] = 1.0f;
   if constexpr (GATE) {
-    u4 wf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const f4 w0 = gw[0][ks][0], w1 = gw[0][ks][1];
-      if constexpr (IN == IN_BF16) wf[ks] = u4{pack2_bf16(w0[0], w0[1]), pack2_bf16(w0[2], w0[3]), pack2_bf16(w1[0], w1[1]), pack2_bf16(w1[2], w1[3])};
-      else wf[ks] = u4{pack2_f16(w0[0], w0[1]), pack2_f16(w0[2], w0[3]), pack2_f16(w1[0], w1[1]), pack2_f16(w1[2], w1[3])};
-    }
 #pragma unroll
     for (int j = 0; j < MQ; ++j) {
-      f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+      u4 xf[KS];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const u4 xf = *reinterpret_cast<const u4*>(kaddr[ks] + 1 * STAGEB + j * TILEB + wave * 16 * ROWB);
-        acc = mfma16<IN>(wf[ks], xf, acc);  // rows = hidden units 4g+r, column = token c
-      }
+      for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const u4*>(kaddr[ks] + 1 * STAGEB + j * TILEB + wave * 16 * ROWB);
       float a = 0.0f;
-      if (P.g_units > 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a = __builtin_fmaf(__builtin_fmaxf(acc[r] + gb1v[r], 0.0f), gw2v[r], a);  // padded units: w2 = 0
-      } else {
-        a = (g == 0) ? acc[0] + gb1v[0] : 0.0f;  // Linear(D,1): unit 0 only
+      for (int tau = 0; tau < GT; ++tau) {
+        if (tau < g_mt) {
+          f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) acc = mfma16<IN>(gwf[tau][ks], xf[ks], acc);  // rows = hidden units 16 tau + 4g + r, column = token c
+          if (P.g_units > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a = __builtin_fmaf(__builtin_fmaxf(acc[r] + gb1v[tau][r], 0.0f), gw2v[tau][r], a);  // padded units: w2 = 0
+          } else {
+            a = (g == 0) ? acc[0] + gb1v[0][0] : 0.0f;  // Linear(D,1): unit 0 only
+          }
+        }
       }
       {  // sum over the 4 lanes (c, c+16, c+32, c+48) of the row
         auto s1 = __builtin_amdgcn_permlane16_swap(f32_bits(a), f32_bits(a), false, false);

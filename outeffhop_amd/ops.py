@@ -341,7 +341,7 @@ def fused_gate_ok(B, H, Sq, Sk, D, dtype, clip: bool = False, fq: bool = False, 
     """True when `attn_fwd(..., gate_mlp=...)` is supported for this problem (else: `gate_fwd` + `gate=`).  `problem`: the
     remaining descriptor fields that decide the kernel variant (`attn_variant`'s keywords: base, gamma, key_pad, causal,
     scale, scale_div, mask_min) - the probe must describe the real call, not a default one."""
-    if dtype not in (torch.float16, torch.bfloat16) or fq or int(units) > 16:
+    if dtype not in (torch.float16, torch.bfloat16) or fq or int(units) > 64:
         return False
     v = attn_variant(B, H, Sq, Sk, D, dtype, clip=clip, **problem)
     return v is not None and (v.startswith("fast16/") or v.startswith("flash16/"))

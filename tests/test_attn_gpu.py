@@ -410,11 +410,12 @@ def test_one_pass_padding_trim_and_long_rows(ops):
         _check(got, want, msg=f"case {n}")
 
 
-@pytest.mark.parametrize("units,dtype", [(16, torch.float16), (0, torch.float16), (7, torch.bfloat16), (64, torch.float16)])
+@pytest.mark.parametrize("units,dtype", [(16, torch.float16), (0, torch.float16), (7, torch.bfloat16), (64, torch.float16), (40, torch.bfloat16), (65, torch.float16)])
 def test_gate_predictor_fused_in_kernel(ops, units, dtype):
     """The conditional per-token gate evaluated inside the full-row kernel (include/oeh.h: gate_hidden ...): first layer on
     the matrix cores with weights rounded to the storage dtype, so it agrees with oeh_gate_fwd (fp32 weights) to ~1e-4 in
-    the gate and to the usual output tolerance; > 16 hidden units are refused (callers fall back to gate_fwd)."""
+    the gate and to the usual output tolerance; up to 64 hidden units (attn_gate_mlp2: head_dim of them) as four 16-unit MFMA
+    tiles, more are refused (callers fall back to gate_fwd)."""
     B, H, S, D = 3, 4, 100, 64
     fmin = float(np.finfo(np.float32).min)
     q, k, v = _rand((B, S, H * D), 5001, dtype=dtype), _rand((B, S, H * D), 5002, dtype=dtype), _rand((B, S, H * D), 5003, dtype=dtype)
@@ -428,7 +429,7 @@ def test_gate_predictor_fused_in_kernel(ops, units, dtype):
     b2 = torch.randn((H,), generator=g).cuda() if units else None
     pad = torch.from_numpy(_pad_mask(B, S, [100, 63, 1], fmin)).cuda()
     gp = ops.GatePredictor(hidden, w1, b1, w2, b2, scaling=4.0, out=torch.empty((B, H, S), dtype=torch.float32, device="cuda"))
-    if units > 16:
+    if units > 64:
         from outeffhop_amd._lib import OehError
         assert not ops.fused_gate_ok(B, H, S, S, D, dtype, units=units)
         with pytest.raises(OehError) as ei:
@@ -450,7 +451,7 @@ def test_gate_predictor_fused_in_kernel(ops, units, dtype):
 
 
 @pytest.mark.parametrize("mq", [1, 2])
-@pytest.mark.parametrize("units", [0, 12])
+@pytest.mark.parametrize("units", [0, 12, 48])
 def test_gate_predictor_fused_one_pass(ops, mq, units):
     """The in-kernel gate predictor on the one-pass kernel (both workgroup shapes): causal rows longer than one tile, with
     and without key padding, against gate_fwd + the `gate` argument and against the oracle."""

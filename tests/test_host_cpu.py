@@ -242,7 +242,7 @@ def test_attn_variant_describes_the_real_problem():
     assert not ops.fused_gate_ok(2, 4, 64, 64, 64, f16, clip=True, gamma=0.01)   # gamma > 0: general kernel
     assert not ops.fused_gate_ok(2, 4, 96, 64, 64, f16, causal=True)            # Sq > Sk causal: general kernel
     assert not ops.fused_gate_ok(2, 4, 64, 64, 64, f16, full_mask=True)
-    assert ops.fused_gate_ok(2, 4, 64, 64, 64, f16) and not ops.fused_gate_ok(2, 4, 64, 64, 64, f16, units=64)
+    assert ops.fused_gate_ok(2, 4, 64, 64, 64, f16) and ops.fused_gate_ok(2, 4, 64, 64, 64, f16, units=64) and not ops.fused_gate_ok(2, 4, 64, 64, 64, f16, units=65)
 
 
 def test_sparse_activations_match_the_reference():
