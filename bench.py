@@ -27,6 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# OEH_BENCH_SHARE_ONE_GPU=1: run the N > 1 code path (own launcher, barriers, max-over-ranks, shard check) with every rank on
+# cuda:0 and gloo collectives - a plumbing test for boxes with one GPU (tests/test_multi_gpu.py); its line says so.
+SHARE_ONE_GPU = os.environ.get("OEH_BENCH_SHARE_ONE_GPU") == "1"
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 WORKLOADS = {
@@ -235,7 +238,7 @@ def main():
         from outeffhop_amd.dist import launch_ranks
 
         have = torch.cuda.device_count()  # counting devices does not initialise the GPU
-        if have < a.gpus:
+        if have < a.gpus and not SHARE_ONE_GPU:
             print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible; refusing to report a {a.gpus}-GPU line", file=sys.stderr)
             sys.exit(2)
         sys.exit(launch_ranks(os.path.abspath(__file__), a.gpus, sys.argv[1:]))
@@ -250,8 +253,13 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if SHARE_ONE_GPU:  # plumbing test on a 1-GPU box: every rank on cuda:0, collectives over gloo (never a measurement)
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -493,7 +501,7 @@ def main():
                 "workload": w["desc"], "variant": (lib.oeh_attn_variant(calls[0][0][0], calls[0][0][5]) or b"?").decode(),  # what the library picks for the timed descriptor
                 "batch_per_gpu": B, "seq_len": S, "heads": H, "head_dim": d, "layers_per_step": L,
                 "launches_per_step": L, "model_tokens_per_s": world * B * S * a.steps / wall,
-                "parallelism": f"batch-shard x{world}, no collective in the timed region",
+                "parallelism": f"batch-shard x{world}, no collective in the timed region" + (" [PLUMBING TEST: all ranks share cuda:0, gloo]" if SHARE_ONE_GPU and world > 1 else ""),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
