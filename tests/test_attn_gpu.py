@@ -1024,3 +1024,51 @@ def test_int8_storage_on_the_integer_matrix_cores(ops, S, causal, base, out_dtyp
     assert ei.value.code == -95
     with pytest.raises(OehError):
         ops.attn_fwd_i8(qc, kc, vt, grids, fq=ops.AttnFakeQuant(FQ(*d_s), ops.FakeQuantSpec(1 / 127.0, 0.0, 127.0), None), scale=scaling)
+
+
+def test_int8_storage_randomised_sweep(ops):
+    """The integer-matrix-core kernel over ragged shapes: key counts that are not multiples of 64 (multiples of 16: its
+    alignment), cross attention (Sq != Sk, causal with a key/value cache offset), all three row-length variants (NT 8/16/32),
+    zero points on both sides of 128 (and exactly 128: no offsets), context quantiser before / after the gate / off, bf16
+    output, strided (B,S,H*64) layouts.  Against the fake-quant kernels on the dequantised fp32 values (pinned to the oracle
+    and to the reference capture by the tests above): equal up to rare single steps of the output grid."""
+    rng = np.random.default_rng(2024)
+    fmin = float(np.finfo(np.float32).min)
+    for n in range(14):
+        B, H = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+        Sk = int(rng.choice([16, 48, 64, 112, 128, 144, 256, 272, 400, 512]))
+        causal = bool(rng.integers(0, 2))
+        Sq = Sk if (causal and rng.integers(0, 2)) else int(rng.integers(1, Sk + 1)) if causal else int(rng.integers(1, 300))
+        base = int(rng.integers(0, 2))
+        out_dtype = [torch.float32, torch.float16, torch.bfloat16][n % 3]
+        g = torch.Generator().manual_seed(5000 + n)
+        zq, zk, zv = (float(z) for z in rng.choice([128.0, 97.0, 131.0, 160.0, 120.0], 3))
+        sq, sk_, sv = 0.031, 0.027, 0.035
+        # centred indices, strided (B,S,H*D) storage
+        qi = torch.randint(0, 256, (B, Sq, H * 64), generator=g, dtype=torch.int64).to(torch.uint8)
+        ki = torch.randint(0, 256, (B, Sk, H * 64), generator=g, dtype=torch.int64).to(torch.uint8)
+        vi = torch.randint(0, 256, (B, Sk, H * 64), generator=g, dtype=torch.int64).to(torch.uint8)
+        deq = lambda idx, s_, z_: ((idx.float() - z_) * s_)  # noqa: E731
+        hv = lambda t, S_: t.view(B, S_, H, 64).permute(0, 2, 1, 3)  # noqa: E731
+        scaling = 0.125
+        qd, kd, vd = hv(deq(qi, sq, zq), Sq) * scaling, hv(deq(ki, sk_, zk), Sk), hv(deq(vi, sv, zv), Sk)
+        FQ = ops.FakeQuantSpec
+        before = bool(n & 1)
+        fq = ops.AttnFakeQuant(FQ(0.09, float(rng.choice([128.0, 100.0, 140.0]))), FQ(1.0 / 255.0, 0.0),
+                               None if n % 5 == 4 else FQ(0.03, 126.0), ctx_before_gate=before)
+        gate = torch.rand((B, H, Sq, 1), generator=g).cuda() if n % 3 != 2 else None
+        sm = ops.SoftmaxSpec(base, False, 0.0, 1.0)
+        kw = dict(softmax=sm, causal=causal, clamp_min=causal, mask_min=fmin, gate=gate, fq=fq)
+        ref = ops.attn_fwd(qd.cuda(), kd.cuda(), vd.cuda(), **kw)
+        qc = hv(ops.centre_indices(qi.cuda()), Sq)
+        kc = hv(ops.centre_indices(ki.cuda()), Sk)
+        vt = ops.centre_indices(vi.cuda()).view(B, Sk, H, 64).permute(0, 2, 3, 1).contiguous()
+        got = ops.attn_fwd_i8(qc, kc, vt, (ops.QuantGrid(sq, zq), ops.QuantGrid(sk_, zk), ops.QuantGrid(sv, zv)), out_dtype=out_dtype, scale=scaling, **kw)
+        assert got.dtype == out_dtype
+        step = 0.03 * (float(gate.max()) if gate is not None else 1.0) if fq.ctx is not None else 0.0
+        tol = {torch.float32: 2e-5, torch.float16: 2e-3, torch.bfloat16: 2e-2}[out_dtype]
+        d = (got.float() - ref).abs()
+        lim = tol + tol * ref.abs()
+        frac_off = float((d > lim).float().mean())
+        assert float(d.max()) <= 1.05 * step + float(lim.max()) and frac_off <= 2e-3, \\
+            f"case {n} {(B, H, Sq, Sk, causal, base, out_dtype)}: max diff {float(d.max()):.3e} (step {step:.3e}), {frac_off:.2e} off"
