@@ -1070,5 +1070,5 @@ def test_int8_storage_randomised_sweep(ops):
         d = (got.float() - ref).abs()
         lim = tol + tol * ref.abs()
         frac_off = float((d > lim).float().mean())
-        assert float(d.max()) <= 1.05 * step + float(lim.max()) and frac_off <= 2e-3, \\
+        assert float(d.max()) <= 1.05 * step + float(lim.max()) and frac_off <= 2e-3, \
             f"case {n} {(B, H, Sq, Sk, causal, base, out_dtype)}: max diff {float(d.max()):.3e} (step {step:.3e}), {frac_off:.2e} off"
