@@ -201,6 +201,19 @@ int oeh_percentile_ema(const void* x, int64_t n, int32_t dtype, double q_lo, dou
 int oeh_fake_quant_range(const void* x, void* y, int64_t n, int32_t dtype, const double* xmin_xmax, int32_t n_bits, double eps,
                          void* stream);
 
+/* The producer side of the INT8-storage attention core (oeh_attn_fwd with dtype OEH_I8): a QuantLinear projection's output
+ * quantiser (hijacker.py:78-127; AsymmetricUniformQuantizer.forward, uniform_quantizers.py:119-148) that writes what the core
+ * consumes - the centred int8 index c = clamp(rint(x / scale) + zero_point, 0, 255) - 128 - instead of a fake-quantised
+ * float tensor, split into heads of 64:
+ *   x: (B, S, H*64) values in `dtype`, last dim contiguous, x_stride = (batch, row) in elements;
+ *   transpose == 0: out is (B, S, H*64) int8 in x's element order (q, k; needs x_stride[0] == S * x_stride[1]);
+ *   transpose == 1: out is (B, H, 64, S) int8, keys contiguous (v: the layout the second product wants; S % 16 == 0);
+ *   y (optional, may be NULL): the dequantised values scale * (idx - zero_point) in `dtype`, y_stride like x_stride - what a
+ *   decoder keeps as its (k, v) cache - in the same pass.
+ * One launch per projection instead of fake-quant + index conversion + transpose copy. */
+int oeh_quantize_heads_i8(const void* x, int8_t* out, void* y, int64_t B, int32_t S, int32_t H, const int64_t x_stride[2],
+                          const int64_t y_stride[2], int32_t dtype, float scale, float zero_point, int32_t transpose, void* stream);
+
 /* library information (host side, no device work) */
 int oeh_abi_version(void);
 const char* oeh_build_info(void);       /* "gfx950 hipcc <version> ..." */

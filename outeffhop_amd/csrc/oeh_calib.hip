@@ -219,3 +219,102 @@ int launch_fake_quant_range(const void* x, void* y, long n, int in, const double
 }
 
 }  // namespace oeh
+
+// ---- The producer side of the INT8-storage attention core (include/oeh.h: dtype OEH_I8): a QuantLinear projection's
+// output quantiser (hijacker.py:78-127; AsymmetricUniformQuantizer.forward) that writes what the core consumes - the
+// centred int8 index idx - 128 - directly, for V already transposed to (B,H,64,S), and optionally the dequantised values
+// (a decoder's (k, v) cache) in the same pass.  Replaces fake-quant + index XOR + transpose copy per projection.
+namespace oeh {
+
+// layout 0: out (B, S, H*64) int8, same element order as x
+template <int IN, bool WANT_Y>
+__global__ __launch_bounds__(256) void quantize_rows_kernel(const void* __restrict__ xin, signed char* __restrict__ out, void* __restrict__ yout,
+                                                            long rows, int E_, long x_sr, long y_sr, FqP f) {
+  typedef typename In<IN>::elem E;
+  const long chunks_per_row = E_ / 16;
+  const long total = rows * chunks_per_row;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / chunks_per_row;
+    const int c0 = (int)(i - r * chunks_per_row) * 16;
+    const E* xp = reinterpret_cast<const E*>(xin) + r * x_sr + c0;
+    unsigned int w[4];
+    float yv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float rel = fq_rel(In<IN>::to_f32(xp[k]), f);
+      const unsigned int idx = (unsigned int)(rel + f.zp);
+      if ((k & 3) == 0) w[k >> 2] = 0u;
+      w[k >> 2] |= (idx ^ 0x80u) << (8 * (k & 3));
+      yv[k] = f.scale * rel;
+    }
+    *reinterpret_cast<u4*>(out + r * E_ + c0) = u4{w[0], w[1], w[2], w[3]};
+    if constexpr (WANT_Y) {
+      E* yp = reinterpret_cast<E*>(yout) + r * y_sr + c0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) yp[k] = In<IN>::from_f32(yv[k]);
+    }
+  }
+}
+
+// layout 1: out (B, H, 64, S) int8 (keys contiguous): a 64 x 64 byte tile per workgroup goes through LDS
+template <int IN, bool WANT_Y>
+__global__ __launch_bounds__(256) void quantize_heads_t_kernel(const void* __restrict__ xin, signed char* __restrict__ out, void* __restrict__ yout,
+                                                               int S, int H, long x_sb, long x_ss, long y_sb, long y_ss, FqP f) {
+  typedef typename In<IN>::elem E;
+  __shared__ unsigned char tile[64][64 + 16];  // [d][key], rows padded to keep the 16-B row reads aligned and spread over banks
+  const int tiles = (S + 63) >> 6;
+  const int kt = blockIdx.x % tiles, bh = blockIdx.x / tiles;
+  const int b = bh / H, h = bh - b * H;
+  const int t = threadIdx.x, row = t >> 2, d0 = (t & 3) * 16;
+  const int s = kt * 64 + row;
+  if (s < S) {
+    const E* xp = reinterpret_cast<const E*>(xin) + (long)b * x_sb + (long)s * x_ss + h * 64 + d0;
+    E* yp = WANT_Y ? reinterpret_cast<E*>(yout) + (long)b * y_sb + (long)s * y_ss + h * 64 + d0 : nullptr;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float rel = fq_rel(In<IN>::to_f32(xp[k]), f);
+      tile[d0 + k][row] = (unsigned char)(((unsigned int)(rel + f.zp)) ^ 0x80u);
+      if constexpr (WANT_Y) yp[k] = In<IN>::from_f32(f.scale * rel);
+    }
+  }
+  __syncthreads();
+  const int d = t >> 2, k0 = (t & 3) * 16;          // 16 consecutive keys of d row `d`
+  const int s0 = kt * 64 + k0;
+  if (s0 < S) {                                      // (S is a multiple of 16 on this path: whole 16-B pieces)
+    const u4 v = *reinterpret_cast<const u4*>(&tile[d][k0]);
+    *reinterpret_cast<u4*>(out + (((long)b * H + h) * 64 + d) * S + s0) = v;
+  }
+}
+
+int launch_quantize_heads_i8(const void* x, signed char* out, void* y, long B, int S, int H, long x_sb, long x_ss, long y_sb, long y_ss, int in,
+                             FqP f, int transpose, hipStream_t st) {
+  const bool wy = y != nullptr;
+  if (!transpose) {
+    const long rows = B * S;  // requires x_sb == S * x_ss (checked by the caller)
+    const long total = rows * (H * 64 / 16);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+#define OEH_QR(IN_) \
+    if (wy) hipLaunchKernelGGL((quantize_rows_kernel<IN_, true>), dim3(blocks), dim3(256), 0, st, x, out, y, rows, H * 64, x_ss, y_ss, f); \
+    else hipLaunchKernelGGL((quantize_rows_kernel<IN_, false>), dim3(blocks), dim3(256), 0, st, x, out, y, rows, H * 64, x_ss, y_ss, f)
+    switch (in) {
+      case IN_F16: OEH_QR(IN_F16); break;
+      case IN_BF16: OEH_QR(IN_BF16); break;
+      default: OEH_QR(IN_F32); break;
+    }
+#undef OEH_QR
+  } else {
+    const unsigned blocks = (unsigned)(B * H * ((S + 63) / 64));
+#define OEH_QT(IN_) \
+    if (wy) hipLaunchKernelGGL((quantize_heads_t_kernel<IN_, true>), dim3(blocks), dim3(256), 0, st, x, out, y, S, H, x_sb, x_ss, y_sb, y_ss, f); \
+    else hipLaunchKernelGGL((quantize_heads_t_kernel<IN_, false>), dim3(blocks), dim3(256), 0, st, x, out, y, S, H, x_sb, x_ss, y_sb, y_ss, f)
+    switch (in) {
+      case IN_F16: OEH_QT(IN_F16); break;
+      case IN_BF16: OEH_QT(IN_BF16); break;
+      default: OEH_QT(IN_F32); break;
+    }
+#undef OEH_QT
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+}  // namespace oeh

@@ -272,6 +272,27 @@ def centre_indices(idx: torch.Tensor) -> torch.Tensor:
     return (idx ^ 128).view(torch.int8)
 
 
+def quantize_heads_i8(x: torch.Tensor, spec: "FakeQuantSpec", H: int, transpose: bool = False, want_values: bool = False):
+    """A projection's output quantiser for the INT8-storage core (`oeh_quantize_heads_i8`): x (B,S,H*64) -> centred int8 indices,
+    as a logical (B,H,S,64) view of a (B,S,H*64) tensor, or with `transpose` as the contiguous (B,H,64,S) tensor `attn_fwd_i8`
+    wants for v; `want_values`: also the dequantised values (B,S,H*64) in x's dtype (a decoder's cache), same pass."""
+    dev = _need_gpu(x)
+    if x.dim() != 3 or x.shape[2] != H * 64 or x.dtype not in _DT or spec.qmax != 255.0:
+        raise ValueError("x must be (B,S,H*64) fp16/bf16/fp32 and the grid 8-bit")
+    xc = x if x.stride(2) == 1 else x.contiguous()
+    B, S, E = xc.shape
+    out = torch.empty((B, H, 64, S) if transpose else (B, S, E), dtype=torch.int8, device=x.device)
+    y = torch.empty((B, S, E), dtype=x.dtype, device=x.device) if want_values else None
+    xs = (C.c_int64 * 2)(xc.stride(0), xc.stride(1))
+    ys = (C.c_int64 * 2)(S * E, E)
+    with _on_device(dev):
+        rc = _lib.load().oeh_quantize_heads_i8(_ptr(xc), _ptr(out), _ptr(y), B, S, H, xs, ys, _DT[x.dtype], float(spec.scale), float(spec.zero_point),
+                                               int(bool(transpose)), _stream())
+    _lib.check(rc, "oeh_quantize_heads_i8")
+    idx = out if transpose else out.view(B, S, H, 64).permute(0, 2, 1, 3)
+    return (idx, y) if want_values else idx
+
+
 def attn_fwd_i8(q: torch.Tensor, k: torch.Tensor, v_t: torch.Tensor, grids, *, fq: AttnFakeQuant, out_dtype=torch.float16,
                 softmax: SoftmaxSpec = SoftmaxSpec(), scale: float = 1.0, scale_div: float = 0.0, causal: bool = False, clamp_min: bool = False,
                 mask_min: Optional[float] = None, gate: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:

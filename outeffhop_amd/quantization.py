@@ -723,17 +723,17 @@ class QuantizedOPTAttentionWithExtras(_QuantAttnBase):
             causal, padvec = classify_causal(attention_mask)
             if not causal or padvec is not None:
                 return None
-        ys, idxs, grids = [], [], []
-        for m in lins:
+        H = self.num_heads
+        outs, grids = [], []
+        for n_, m in enumerate(lins):  # GEMM, then ONE kernel: centred int8 indices in the core's layout (v transposed) [+ the cache's floats]
             w, b = m.get_params()
             res = nn.functional.linear(hidden_states.contiguous(), w.contiguous(), bias=b)
             sp = m.activation_quantizer.quantizer.spec()
-            y, idx = ops.fake_quant(res, sp, want_idx=True)  # the dequantised values (cache / fallback) and the indices, one pass
-            ys.append(y), idxs.append(idx), grids.append(ops.QuantGrid.of(sp))
-        H, d = self.num_heads, self.head_dim
-        qc = ops.centre_indices(idxs[0]).view(bsz, tgt_len, H, d).permute(0, 2, 1, 3)
-        kc = ops.centre_indices(idxs[1]).view(bsz, tgt_len, H, d).permute(0, 2, 1, 3)
-        vt = ops.centre_indices(idxs[2]).view(bsz, tgt_len, H, d).permute(0, 2, 3, 1).contiguous()  # (B,H,d,S): keys contiguous
+            outs.append(ops.quantize_heads_i8(res, sp, H, transpose=(n_ == 2), want_values=(n_ > 0 and self.is_decoder)))
+            grids.append(ops.QuantGrid.of(sp))
+        qc = outs[0]
+        kc, yk = outs[1] if self.is_decoder else (outs[1], None)
+        vt, yv = outs[2] if self.is_decoder else (outs[2], None)
         mdt = attention_mask.dtype if attention_mask is not None and attention_mask.is_floating_point() else hidden_states.dtype
         try:
             out = ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, out_dtype=hidden_states.dtype, softmax=spec, scale=self.scaling, causal=causal,
@@ -742,7 +742,8 @@ class QuantizedOPTAttentionWithExtras(_QuantAttnBase):
             if e.code != -95:
                 raise
             return None
-        return out.permute(0, 2, 1, 3).reshape(bsz, tgt_len, self.embed_dim), (self._heads(ys[1], bsz), self._heads(ys[2], bsz))
+        cache = (self._heads(yk, bsz), self._heads(yv, bsz)) if self.is_decoder else None
+        return out.permute(0, 2, 1, 3).reshape(bsz, tgt_len, self.embed_dim), cache
 
     def forward(self, hidden_states, key_value_states=None, past_key_value=None, attention_mask=None, layer_head_mask=None,
                 output_attentions=False):

@@ -142,3 +142,23 @@ def test_fake_quant_with_a_device_resident_range(ops):
             delta = (x_max - x_min) / 255.0
             want = ops.fake_quant(x, ops.FakeQuantSpec.from_delta(delta, -x_min / delta, 8, 1e-8))
             assert torch.equal(got, want), (lo, hi, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_quantize_heads_i8_equals_fake_quant_indices(ops, dtype):
+    """oeh_quantize_heads_i8 (the producer side of the INT8-storage attention core): the centred indices idx - 128 and the
+    dequantised values equal oeh_fake_quant's (bit-exact quantiser, pinned to the reference by tests/golden/fakequant.npz), in
+    the (B,S,H*64) layout and transposed per head to (B,H,64,S); strided input rows (a slice of a fused q/k/v GEMM output)."""
+    g = torch.Generator().manual_seed(9)
+    B, S, H = 3, 112, 5
+    big = (torch.randn(B, S, 3 * H * 64, generator=g) * 2.0).to(dtype).cuda()
+    for n, (scale, zp) in enumerate(((0.031, 131.0), (0.02, 0.0), (0.05, 255.0))):
+        x = big[..., n * H * 64:(n + 1) * H * 64]  # strided rows
+        spec = ops.FakeQuantSpec(scale, zp)
+        want_y, want_idx = ops.fake_quant(x, spec, want_idx=True)
+        want_c = (want_idx.to(torch.int16) - 128).to(torch.int8)
+        got, y = ops.quantize_heads_i8(x, spec, H, transpose=False, want_values=True)
+        assert got.shape == (B, H, S, 64) and torch.equal(got, want_c.view(B, S, H, 64).permute(0, 2, 1, 3)) and torch.equal(y, want_y)
+        got_t = ops.quantize_heads_i8(x, spec, H, transpose=True)
+        assert got_t.shape == (B, H, 64, S) and got_t.is_contiguous()
+        assert torch.equal(got_t, want_c.view(B, S, H, 64).permute(0, 2, 3, 1))

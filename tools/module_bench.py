@@ -66,5 +66,46 @@ def main():
             print(f"BERT-base module {dt} fused_qkv={fused}: {t_mod:8.1f} us  {B * S / t_mod:8.1f} M tokens/s")
 
 
+def quantised():
+    """The INT8 validate configuration of the OPT-125m layer at the reference's precision (fp32 model): QuantizedOPTAttention-
+    WithExtras with frozen 8-bit ranges, attention core on the integer matrix cores (INT8 storage) vs the fake-quant kernels."""
+    import outeffhop_amd as oa
+    from outeffhop_amd import quantization as Q
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    fmin = torch.finfo(torch.float32).min
+    B, S, E, H = 16, 512, 768, 12
+    cfg = oa.get_quant_config()
+    cfg.quant.percentile = 99.999
+    cfg.act_quant.options = dict(percentile=99.999)
+    with torch.no_grad():
+        org = OPTAttentionWithExtras(E, H, is_decoder=True, softmax_fn=SOFTMAX_MAPPING["softmax1"]).to(dev).eval()
+        qm = oa.QuantizedOPTAttentionWithExtras(org, **{**oa.val_qparams(cfg), "quant_dict": {}}).to(dev).eval()
+        qm.set_quant_state(weight_quant=True, act_quant=True)
+        mask = torch.full((S, S), fmin, device=dev).triu(1)[None, None].expand(B, 1, S, S).contiguous()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            qm(torch.randn(B, S, E, device=dev), attention_mask=mask)  # calibration batches (percentile 99.999 + running average, on the device)
+        torch.cuda.synchronize()
+        print(f"calibration: 2 batches in {(time.perf_counter() - t0) * 1e3:.1f} ms (incl. first-call overheads)")
+        t0 = time.perf_counter()
+        qm(torch.randn(B, S, E, device=dev), attention_mask=mask)
+        torch.cuda.synchronize()
+        print(f"calibration: one more batch {(time.perf_counter() - t0) * 1e3:.1f} ms")
+        qm.fix_ranges()
+        x = torch.randn(B, S, E, device=dev)
+        for i8 in (False, True):
+            Q.INT8_STORAGE = i8
+            t_mod = timeit(lambda: qm(x, attention_mask=mask), n=50)
+            print(f"QuantizedOPT module fp32, INT8 storage core={i8}: {t_mod:8.1f} us  {B * S / t_mod:8.1f} M tokens/s")
+        Q.INT8_STORAGE = True
+        t_lin = timeit(lambda: qm.q_proj(x), n=50)
+        print(f"   parts: one QuantLinear (fp32 GEMM + output fake-quant) {t_lin:.1f} us")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "int8":
+        quantised()
+    else:
+        main()
