@@ -214,6 +214,13 @@ int oeh_fake_quant_range(const void* x, void* y, int64_t n, int32_t dtype, const
 int oeh_quantize_heads_i8(const void* x, int8_t* out, void* y, int64_t B, int32_t S, int32_t H, const int64_t x_stride[2],
                           const int64_t y_stride[2], int32_t dtype, float scale, float zero_point, int32_t transpose, void* stream);
 
+/* fp32 activations as fp16 operand pairs for a library GEMM either side of the attention core (the q/k/v and output
+ * projections of an fp32 model, opt_attention.py:167-201,318-324 / quantized_opt.py:67-75): out[r][0:K] = hi = RN16(x[r]),
+ * out[r][K:2K] = lo = RN16((x[r] - hi) * 2^11); with the weight matrix stacked as [W ; W * 2^-11] one fp16 GEMM with fp32
+ * accumulation gives x.W to ~2^-22 relative (the weight side exactly when W holds 8-bit integers, as QuantLinear's weights
+ * do up to their scale) at fp16 matrix-core speed.  x: (rows, K) fp32, K % 8 == 0, 16-byte aligned rows; out: (rows, 2K) fp16. */
+int oeh_split_pairs(const float* x, void* out_f16, int64_t rows, int32_t K, int64_t x_stride_row, void* stream);
+
 /* library information (host side, no device work) */
 int oeh_abi_version(void);
 const char* oeh_build_info(void);       /* "gfx950 hipcc <version> ..." */

@@ -272,6 +272,19 @@ def centre_indices(idx: torch.Tensor) -> torch.Tensor:
     return (idx ^ 128).view(torch.int8)
 
 
+def split_pairs(x: torch.Tensor) -> torch.Tensor:
+    """fp32 (rows, K) -> fp16 (rows, 2K) = [hi | lo] operand pairs (`oeh_split_pairs`): x = hi + lo * 2^-11 to 2^-22 relative."""
+    dev = _need_gpu(x)
+    if x.dim() != 2 or x.dtype != torch.float32 or x.shape[1] % 8 != 0:
+        raise ValueError("x must be a 2-D fp32 tensor with a multiple of 8 columns")
+    xc = x if x.stride(1) == 1 else x.contiguous()
+    out = torch.empty((xc.shape[0], 2 * xc.shape[1]), dtype=torch.float16, device=x.device)
+    with _on_device(dev):
+        rc = _lib.load().oeh_split_pairs(_ptr(xc), _ptr(out), xc.shape[0], xc.shape[1], xc.stride(0), _stream())
+    _lib.check(rc, "oeh_split_pairs")
+    return out
+
+
 def quantize_heads_i8(x: torch.Tensor, spec: "FakeQuantSpec", H: int, transpose: bool = False, want_values: bool = False):
     """A projection's output quantiser for the INT8-storage core (`oeh_quantize_heads_i8`): x (B,S,H*64) -> centred int8 indices,
     as a logical (B,H,S,64) view of a (B,S,H*64) tensor, or with `transpose` as the contiguous (B,H,64,S) tensor `attn_fwd_i8`

@@ -444,3 +444,41 @@ def test_quantised_opt_uses_the_int8_storage_core(oa, monkeypatch):
     with torch.no_grad():
         qm(x, attention_mask=_decoder_mask(B, T, [T, T - 5, T], torch.float32, dev))
     assert len(calls) == 2
+
+
+def test_quantlinear_operand_pair_gemm(oa, monkeypatch):
+    """QuantLinear on an fp32 model (the reference's validate precision): the quantised weight is scale * (8-bit integer),
+    exact in fp16, and the fp32 input is carried as fp16 operand pairs (oeh_split_pairs), so ONE fp16 GEMM with fp32
+    accumulation gives the fp32 linear - at least as close to the exact (float64) result as torch's fp32 GEMM - and the
+    module's quantised outputs agree with the fp32-GEMM path except for rare single steps of the output grid."""
+    from outeffhop_amd import ops, quantization as Q
+
+    torch.manual_seed(31)
+    dev = torch.device("cuda:0")
+    lin = torch.nn.Linear(768, 768).to(dev)
+    ql = Q.quantize_model(lin, **_qparams(oa)).to(dev).eval()
+    ql.quantized_weights()
+    x = torch.randn(4, 512, 768, device=dev) * 1.7
+    with torch.no_grad():
+        ql(x)  # initialises the weight range
+        assert ql.pair_gemm_ok(x)
+        pairs = ops.split_pairs(x.reshape(-1, 768))
+        rec = pairs[:, :768].float() + pairs[:, 768:].float() / 2048.0
+        assert float(((rec - x.reshape(-1, 768)).abs() / x.reshape(-1, 768).abs().clamp(min=1e-30)).max()) <= 2.0 ** -21
+        got = ql.linear_pairs(x)
+        wq, b = ql.get_params()
+        exact = torch.nn.functional.linear(x.double(), wq.double(), b.double())
+        e_pair = float((got.double() - exact).abs().max())
+        e_lib = float((torch.nn.functional.linear(x, wq, b).double() - exact).abs().max())
+        assert e_pair <= max(2.0 * e_lib, 1e-5), (e_pair, e_lib)
+        # with the output quantiser on (fixed range): same indices as the fp32-GEMM path up to rare boundary cases
+        ql.quantized_acts()
+        ql.activation_quantizer.set_quant_range(-6.0, 6.0)
+        ql.activation_quantizer.fix_ranges()
+        a = ql(x)
+        monkeypatch.setattr(Q, "PAIR_GEMM", False)
+        assert not ql.pair_gemm_ok(x)
+        b_ = ql(x)
+    step = 12.0 / 255.0
+    d = (a - b_).abs()
+    assert float(d.max()) <= 1.01 * step and float((d > 0).float().mean()) <= 1e-3
