@@ -209,10 +209,14 @@ int oeh_fake_quant_range(const void* x, void* y, int64_t n, int32_t dtype, const
  *   transpose == 0: out is (B, S, H*64) int8 in x's element order (q, k; needs x_stride[0] == S * x_stride[1]);
  *   transpose == 1: out is (B, H, 64, S) int8, keys contiguous (v: the layout the second product wants; S % 16 == 0);
  *   y (optional, may be NULL): the dequantised values scale * (idx - zero_point) in `dtype`, y_stride like x_stride - what a
- *   decoder keeps as its (k, v) cache - in the same pass.
+ *   decoder keeps as its (k, v) cache - in the same pass;
+ *   bias (optional, fp32 device array of H*64, may be NULL): x is a raw GEMM accumulator and the value that is quantised is
+ *   alpha * x + bias[column] - the projection's weight scale and bias folded into this pass (oeh_split_pairs' GEMM);
+ *   bias == NULL: x is quantised as it is (alpha ignored).
  * One launch per projection instead of fake-quant + index conversion + transpose copy. */
 int oeh_quantize_heads_i8(const void* x, int8_t* out, void* y, int64_t B, int32_t S, int32_t H, const int64_t x_stride[2],
-                          const int64_t y_stride[2], int32_t dtype, float scale, float zero_point, int32_t transpose, void* stream);
+                          const int64_t y_stride[2], int32_t dtype, float scale, float zero_point, int32_t transpose, float alpha,
+                          const float* bias, void* stream);
 
 /* fp32 activations as fp16 operand pairs for a library GEMM either side of the attention core (the q/k/v and output
  * projections of an fp32 model, opt_attention.py:167-201,318-324 / quantized_opt.py:67-75): out[r][0:K] = hi = RN16(x[r]),

@@ -99,7 +99,7 @@ def load() -> C.CDLL:
     lib.oeh_percentile_ema.restype = C.c_int
     lib.oeh_fake_quant_range.argtypes = [vp, vp, i64, i32, vp, i32, f64, vp]
     lib.oeh_fake_quant_range.restype = C.c_int
-    lib.oeh_quantize_heads_i8.argtypes = [vp, vp, vp, i64, i32, i32, C.POINTER(i64), C.POINTER(i64), i32, f32, f32, i32, vp]
+    lib.oeh_quantize_heads_i8.argtypes = [vp, vp, vp, i64, i32, i32, C.POINTER(i64), C.POINTER(i64), i32, f32, f32, i32, f32, vp, vp]
     lib.oeh_quantize_heads_i8.restype = C.c_int
     lib.oeh_split_pairs.argtypes = [vp, vp, i64, i32, i64, vp]
     lib.oeh_split_pairs.restype = C.c_int

@@ -32,7 +32,7 @@ int launch_percentile_ema(const void* x, long n, int in, double q_lo, double q_h
 int launch_fake_quant_range(const void* x, void* y, long n, int in, const double* range, float qmax, double eps, hipStream_t st);
 int launch_split_pairs(const float* x, void* out, long rows, int K, long x_sr, hipStream_t st);
 int launch_quantize_heads_i8(const void* x, signed char* out, void* y, long B, int S, int H, long x_sb, long x_ss, long y_sb, long y_ss, int in,
-                             FqP f, int transpose, hipStream_t st);
+                             FqP f, int transpose, float alpha, const float* bias, hipStream_t st);
 }  // namespace oeh
 
 using oeh::AttnParams;
@@ -408,7 +408,7 @@ int oeh_fake_quant_range(const void* x, void* y, int64_t n, int32_t dtype, const
 }
 
 int oeh_quantize_heads_i8(const void* x, int8_t* out, void* y, int64_t B, int32_t S, int32_t H, const int64_t x_stride[2], const int64_t y_stride[2],
-                          int32_t dtype, float scale, float zero_point, int32_t transpose, void* stream) {
+                          int32_t dtype, float scale, float zero_point, int32_t transpose, float alpha, const float* bias, void* stream) {
   if (x == nullptr || out == nullptr || x_stride == nullptr || B <= 0 || S <= 0 || H <= 0 || !dtype_ok(dtype)) return OEH_EINVAL;
   if (!(scale > 0.0f) || zero_point < 0.0f || zero_point > 255.0f || zero_point != std::nearbyint(zero_point)) return OEH_EINVAL;
   if (y != nullptr && y_stride == nullptr) return OEH_EINVAL;
@@ -420,7 +420,7 @@ int oeh_quantize_heads_i8(const void* x, int8_t* out, void* y, int64_t B, int32_
   std::memset(&f, 0, sizeof(f));
   f.en = 1; f.scale = scale; f.rscale = 1.0f / scale; f.zp = zero_point; f.qmax = 255.0f; f.lo = -zero_point; f.hi = 255.0f - zero_point;
   return oeh::launch_quantize_heads_i8(x, reinterpret_cast<signed char*>(out), y, B, S, H, x_stride[0], x_stride[1], y != nullptr ? y_stride[0] : 0,
-                                       y != nullptr ? y_stride[1] : 0, dtype, f, transpose ? 1 : 0, reinterpret_cast<hipStream_t>(stream));
+                                       y != nullptr ? y_stride[1] : 0, dtype, f, transpose ? 1 : 0, alpha, bias, reinterpret_cast<hipStream_t>(stream));
 }
 
 int oeh_split_pairs(const float* x, void* out_f16, int64_t rows, int32_t K, int64_t x_stride_row, void* stream) {

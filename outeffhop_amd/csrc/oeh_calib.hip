@@ -226,10 +226,44 @@ int launch_fake_quant_range(const void* x, void* y, long n, int in, const double
 // (a decoder's (k, v) cache) in the same pass.  Replaces fake-quant + index XOR + transpose copy per projection.
 namespace oeh {
 
+// 16 consecutive storage elements -> fp32 (explicit 16-byte loads), optionally alpha * x + bias[0..15]
+template <int IN>
+__device__ __forceinline__ void load16_affine(const void* xp_, float (&v)[16], float alpha, const float* bias16) {
+  if constexpr (IN == IN_F32) {
+    const f4* p = reinterpret_cast<const f4*>(xp_);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f4 t = p[q];
+      v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+    }
+  } else {
+    const u4* p = reinterpret_cast<const u4*>(xp_);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const u4 t = p[q];
+      const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[8 * q + 2 * e] = In<IN>::to_f32((unsigned short)(w[e] & 0xffffu));
+        v[8 * q + 2 * e + 1] = In<IN>::to_f32((unsigned short)(w[e] >> 16));
+      }
+    }
+  }
+  if (bias16 != nullptr) {  // (wave-uniform: one branch per 16 elements)
+    const f4* bp = reinterpret_cast<const f4*>(bias16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f4 t = bp[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * q + e] = __builtin_fmaf(v[4 * q + e], alpha, t[e]);
+    }
+  }
+}
+
 // layout 0: out (B, S, H*64) int8, same element order as x
 template <int IN, bool WANT_Y>
 __global__ __launch_bounds__(256) void quantize_rows_kernel(const void* __restrict__ xin, signed char* __restrict__ out, void* __restrict__ yout,
-                                                            long rows, int E_, long x_sr, long y_sr, FqP f) {
+                                                            long rows, int E_, long x_sr, long y_sr, FqP f, float alpha, const float* __restrict__ bias) {
   typedef typename In<IN>::elem E;
   const long chunks_per_row = E_ / 16;
   const long total = rows * chunks_per_row;
@@ -238,10 +272,11 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const void* __restri
     const int c0 = (int)(i - r * chunks_per_row) * 16;
     const E* xp = reinterpret_cast<const E*>(xin) + r * x_sr + c0;
     unsigned int w[4];
-    float yv[16];
+    float yv[16], xv16[16];
+    load16_affine<IN>(xp, xv16, alpha, bias != nullptr ? bias + c0 : nullptr);  // (the projection's scale and bias when a raw accumulator comes in)
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const float rel = fq_rel(In<IN>::to_f32(xp[k]), f);
+      const float rel = fq_rel(xv16[k], f);
       const unsigned int idx = (unsigned int)(rel + f.zp);
       if ((k & 3) == 0) w[k >> 2] = 0u;
       w[k >> 2] |= (idx ^ 0x80u) << (8 * (k & 3));
@@ -259,7 +294,8 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const void* __restri
 // layout 1: out (B, H, 64, S) int8 (keys contiguous): a 64 x 64 byte tile per workgroup goes through LDS
 template <int IN, bool WANT_Y>
 __global__ __launch_bounds__(256) void quantize_heads_t_kernel(const void* __restrict__ xin, signed char* __restrict__ out, void* __restrict__ yout,
-                                                               int S, int H, long x_sb, long x_ss, long y_sb, long y_ss, FqP f) {
+                                                               int S, int H, long x_sb, long x_ss, long y_sb, long y_ss, FqP f, float alpha,
+                                                               const float* __restrict__ bias) {
   typedef typename In<IN>::elem E;
   __shared__ unsigned char tile[64][64 + 16];  // [d][key], rows padded to keep the 16-B row reads aligned and spread over banks
   const int tiles = (S + 63) >> 6;
@@ -270,9 +306,11 @@ __global__ __launch_bounds__(256) void quantize_heads_t_kernel(const void* __res
   if (s < S) {
     const E* xp = reinterpret_cast<const E*>(xin) + (long)b * x_sb + (long)s * x_ss + h * 64 + d0;
     E* yp = WANT_Y ? reinterpret_cast<E*>(yout) + (long)b * y_sb + (long)s * y_ss + h * 64 + d0 : nullptr;
+    float xv16[16];
+    load16_affine<IN>(xp, xv16, alpha, bias != nullptr ? bias + h * 64 + d0 : nullptr);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const float rel = fq_rel(In<IN>::to_f32(xp[k]), f);
+      const float rel = fq_rel(xv16[k], f);
       tile[d0 + k][row] = (unsigned char)(((unsigned int)(rel + f.zp)) ^ 0x80u);
       if constexpr (WANT_Y) yp[k] = In<IN>::from_f32(f.scale * rel);
     }
@@ -287,15 +325,15 @@ __global__ __launch_bounds__(256) void quantize_heads_t_kernel(const void* __res
 }
 
 int launch_quantize_heads_i8(const void* x, signed char* out, void* y, long B, int S, int H, long x_sb, long x_ss, long y_sb, long y_ss, int in,
-                             FqP f, int transpose, hipStream_t st) {
+                             FqP f, int transpose, float alpha, const float* bias, hipStream_t st) {
   const bool wy = y != nullptr;
   if (!transpose) {
     const long rows = B * S;  // requires x_sb == S * x_ss (checked by the caller)
     const long total = rows * (H * 64 / 16);
     const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
 #define OEH_QR(IN_) \
-    if (wy) hipLaunchKernelGGL((quantize_rows_kernel<IN_, true>), dim3(blocks), dim3(256), 0, st, x, out, y, rows, H * 64, x_ss, y_ss, f); \
-    else hipLaunchKernelGGL((quantize_rows_kernel<IN_, false>), dim3(blocks), dim3(256), 0, st, x, out, y, rows, H * 64, x_ss, y_ss, f)
+    if (wy) hipLaunchKernelGGL((quantize_rows_kernel<IN_, true>), dim3(blocks), dim3(256), 0, st, x, out, y, rows, H * 64, x_ss, y_ss, f, alpha, bias); \
+    else hipLaunchKernelGGL((quantize_rows_kernel<IN_, false>), dim3(blocks), dim3(256), 0, st, x, out, y, rows, H * 64, x_ss, y_ss, f, alpha, bias)
     switch (in) {
       case IN_F16: OEH_QR(IN_F16); break;
       case IN_BF16: OEH_QR(IN_BF16); break;
@@ -305,8 +343,8 @@ int launch_quantize_heads_i8(const void* x, signed char* out, void* y, long B, i
   } else {
     const unsigned blocks = (unsigned)(B * H * ((S + 63) / 64));
 #define OEH_QT(IN_) \
-    if (wy) hipLaunchKernelGGL((quantize_heads_t_kernel<IN_, true>), dim3(blocks), dim3(256), 0, st, x, out, y, S, H, x_sb, x_ss, y_sb, y_ss, f); \
-    else hipLaunchKernelGGL((quantize_heads_t_kernel<IN_, false>), dim3(blocks), dim3(256), 0, st, x, out, y, S, H, x_sb, x_ss, y_sb, y_ss, f)
+    if (wy) hipLaunchKernelGGL((quantize_heads_t_kernel<IN_, true>), dim3(blocks), dim3(256), 0, st, x, out, y, S, H, x_sb, x_ss, y_sb, y_ss, f, alpha, bias); \
+    else hipLaunchKernelGGL((quantize_heads_t_kernel<IN_, false>), dim3(blocks), dim3(256), 0, st, x, out, y, S, H, x_sb, x_ss, y_sb, y_ss, f, alpha, bias)
     switch (in) {
       case IN_F16: OEH_QT(IN_F16); break;
       case IN_BF16: OEH_QT(IN_BF16); break;

@@ -285,11 +285,15 @@ def split_pairs(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def quantize_heads_i8(x: torch.Tensor, spec: "FakeQuantSpec", H: int, transpose: bool = False, want_values: bool = False):
+def quantize_heads_i8(x: torch.Tensor, spec: "FakeQuantSpec", H: int, transpose: bool = False, want_values: bool = False,
+                      alpha: float = 1.0, bias: Optional[torch.Tensor] = None):
     """A projection's output quantiser for the INT8-storage core (`oeh_quantize_heads_i8`): x (B,S,H*64) -> centred int8 indices,
     as a logical (B,H,S,64) view of a (B,S,H*64) tensor, or with `transpose` as the contiguous (B,H,64,S) tensor `attn_fwd_i8`
-    wants for v; `want_values`: also the dequantised values (B,S,H*64) in x's dtype (a decoder's cache), same pass."""
-    dev = _need_gpu(x)
+    wants for v; `want_values`: also the dequantised values (B,S,H*64) in x's dtype (a decoder's cache), same pass; `bias`
+    (fp32, H*64): x is a raw GEMM accumulator and alpha * x + bias is what gets quantised."""
+    dev = _need_gpu(x, bias)
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != H * 64 or not bias.is_contiguous()):
+        raise ValueError("bias must be a contiguous fp32 vector of H*64")
     if x.dim() != 3 or x.shape[2] != H * 64 or x.dtype not in _DT or spec.qmax != 255.0:
         raise ValueError("x must be (B,S,H*64) fp16/bf16/fp32 and the grid 8-bit")
     xc = x if x.stride(2) == 1 else x.contiguous()
@@ -300,7 +304,7 @@ def quantize_heads_i8(x: torch.Tensor, spec: "FakeQuantSpec", H: int, transpose:
     ys = (C.c_int64 * 2)(S * E, E)
     with _on_device(dev):
         rc = _lib.load().oeh_quantize_heads_i8(_ptr(xc), _ptr(out), _ptr(y), B, S, H, xs, ys, _DT[x.dtype], float(spec.scale), float(spec.zero_point),
-                                               int(bool(transpose)), _stream())
+                                               int(bool(transpose)), float(alpha), _ptr(bias), _stream())
     _lib.check(rc, "oeh_quantize_heads_i8")
     idx = out if transpose else out.view(B, S, H, 64).permute(0, 2, 1, 3)
     return (idx, y) if want_values else idx

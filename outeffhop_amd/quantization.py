@@ -553,15 +553,17 @@ class QuantLinear(QuantizedModule, nn.Linear):
         return (PAIR_GEMM and not self.training and self._qw and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
                 and type(qz) is SymmetricUniformQuantizer and qz.is_initialized and qz.n_bits <= 8 and self.in_features % 8 == 0)
 
-    def linear_pairs(self, x, pairs=None):
+    def linear_pairs(self, x, pairs=None, raw: bool = False):
         """x @ W_q^T + b through one fp16 GEMM on operand pairs (`pairs` = ops.split_pairs(x 2-D), shared by projections of the
-        same input): fp32-accurate (the weight side exactly), ~3x faster than the fp32 library GEMM at these sizes."""
+        same input): fp32-accurate (the weight side exactly), ~3x faster than the fp32 library GEMM at these sizes.
+        raw: return (accumulator, weight scale, bias) instead - the caller folds scale and bias into its next pass."""
         ww, s32 = self._pair_weights()
         if pairs is None:
             pairs = ops.split_pairs(x.reshape(-1, x.shape[-1]))
-        acc = torch.mm(pairs, ww, out_dtype=torch.float32)
-        res = torch.add(self.bias.detach(), acc, alpha=s32) if self.bias is not None else acc * s32
-        return res.view(*x.shape[:-1], self.out_features)
+        acc = torch.mm(pairs, ww, out_dtype=torch.float32).view(*x.shape[:-1], self.out_features)
+        if raw:
+            return acc, s32, self.bias
+        return torch.add(self.bias.detach(), acc, alpha=s32) if self.bias is not None else acc * s32
 
     def forward(self, x, offsets=None):
         weight, bias = self.get_params()
@@ -762,14 +764,16 @@ class QuantizedOPTAttentionWithExtras(_QuantAttnBase):
         pairs = None
         for n_, m in enumerate(lins):  # GEMM, then ONE kernel: centred int8 indices in the core's layout (v transposed) [+ the cache's floats]
             w, b = m.get_params()
-            if m.pair_gemm_ok(hidden_states):  # fp32 model: the input as fp16 operand pairs, split once for the three projections
-                if pairs is None:
+            alpha, qbias = 1.0, None
+            if m.pair_gemm_ok(hidden_states) and m.bias is not None:  # fp32 model: the input as fp16 operand pairs, split once for the
+                if pairs is None:                                       # three projections; weight scale and bias folded into the quantiser pass
                     pairs = ops.split_pairs(hidden_states.reshape(-1, hidden_states.shape[-1]))
-                res = m.linear_pairs(hidden_states, pairs)
+                res, alpha, qbias = m.linear_pairs(hidden_states, pairs, raw=True)
+                qbias = qbias.detach()
             else:
                 res = nn.functional.linear(hidden_states.contiguous(), w.contiguous(), bias=b)
             sp = m.activation_quantizer.quantizer.spec()
-            outs.append(ops.quantize_heads_i8(res, sp, H, transpose=(n_ == 2), want_values=(n_ > 0 and self.is_decoder)))
+            outs.append(ops.quantize_heads_i8(res, sp, H, transpose=(n_ == 2), want_values=(n_ > 0 and self.is_decoder), alpha=alpha, bias=qbias))
             grids.append(ops.QuantGrid.of(sp))
         qc = outs[0]
         kc, yk = outs[1] if self.is_decoder else (outs[1], None)
