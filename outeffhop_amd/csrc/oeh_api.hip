@@ -182,7 +182,7 @@ bool small_eligible(const oeh_attn_desc* d, const void* q, const void* k, const 
 unsigned long long* g_stamps = nullptr;  // tools/timeline.py only
 int g_variant_off = 0;                   // tools/microbench.py only: bit (1 << Variant) disables a variant
 int g_flash_mq = 0;                      // tools/microbench.py only: force query blocks per wave
-int g_prio = 0;                          // tools/microbench.py only: 1 = heavier causal workgroups at higher wave priority
+int g_place = 0;                         // tools/microbench.py only: 1 = plain block order in the one-pass kernel (no snake placement)
 
 // query blocks (16 rows) per wave of the one-pass kernel: 2 (128-row workgroups) once that still gives every CU two
 // workgroups, else 1
@@ -256,8 +256,7 @@ void fill_params(AttnParams& P, const oeh_attn_desc* d, const void* q, const voi
     P.ctx_before_gate = fq->ctx_quant_before_gate ? 1 : 0;
   }
   P.stamps = g_stamps;
-  P.prio = (g_prio == 3 || (g_prio && d->causal)) ? g_prio : 0;
-  if (P.prio == 2 && (((d->Sq + 63) / 64) & 1)) P.prio = 0;  // slab pairing needs an even slab count
+  P.snake = (g_place & 1) ? 0 : 1;
   P.nQT = (d->Sq + 63) / 64;
   P.nBH = d->B * d->H;
   P.nBHpad = (P.nBH + 7) & ~7;
@@ -437,7 +436,7 @@ static bool debug_hooks_on() {
 }
 int oeh_debug_set_variant(int off_mask, int flash_mq_force) {
   if (!debug_hooks_on()) return OEH_ENOTSUP;
-  g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force; g_prio = (off_mask >> 9) & 3;
+  g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force; g_place = (off_mask >> 9) & 1;
   return OEH_OK;
 }
 int oeh_debug_set_stamps(void* device_buffer) {

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   __shared__ __attribute__((aligned(16))) float lds_padrow[PAD ? PADROW : 4];
   __shared__ int lds_last[4];
 
-  const int bid = blockIdx.x;
+  const int bid = P.snake ? snake_block_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int qt_rev = bid / P.nBHpad;
   const int bh = bid - qt_rev * P.nBHpad;
   if (bh >= P.nBH) return;
@@ -97,7 +97,6 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
 #pragma unroll
   for (int j = 0; j < MQ; ++j) {
     slab[j] = qt * MQ + j;
-    if (MQ == 2 && P.prio == 2) slab[j] = (j == 0) ? qt : 2 * P.nQT - 1 - qt;  // experiment: a light slab with a heavy one
     rb[j] = 64 * slab[j] + 16 * wave;
   }
   const int last_row_wg = 64 * slab[MQ - 1] + 63;  // last query row of the workgroup (bounds the tiles it streams)
@@ -109,7 +108,6 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     tm0[j] = ((causal ? min(rb[j] + off, Sk - 1) : Sk - 1) + 1) >> 6;
   }
 
-  if (P.prio == 1) set_wave_priority((qt * 4) / P.nQT);  // q tiles further down the causal triangle stream more keys
   unsigned long long* stamp = nullptr;  // diagnostic runs of tools/timeline.py only
   if (P.stamps != nullptr) stamp = P.stamps + ((long)bid * 4 + wave) * 32;
 #define OEH_STAMP(slot)                                                                \

@@ -45,7 +45,7 @@ struct AttnParams {
   int nQT;                    // q tiles (64 rows) per (b,h)
   int nBH, nBHpad;            // B*H and B*H rounded up to a multiple of 8 (XCD affinity of a head's q tiles)
   int skip_ok;                // causal tiles above the diagonal may be skipped (see oeh_api.hip)
-  int prio;                   // causal: waves of the workgroups with more key tiles get a higher issue priority (s_setprio)
+  int snake;                  // one-pass kernel: every second row of 256 block ids walked backwards (snake_block_id, oeh_common.h)
   unsigned long long* stamps; // diagnostic builds only: per-wave s_memtime stamps (null in production)
 };
 

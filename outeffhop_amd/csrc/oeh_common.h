@@ -238,11 +238,17 @@ __device__ __forceinline__ void barrier_mem() {
   asm volatile("" ::: "memory");
 }
 
-// s_setprio takes an immediate: level 0..3 from a wave-uniform value
-__device__ __forceinline__ void set_wave_priority(int level) {
-  if (level >= 3) __builtin_amdgcn_s_setprio(3);
-  else if (level == 2) __builtin_amdgcn_s_setprio(2);
-  else if (level == 1) __builtin_amdgcn_s_setprio(1);
+// Workgroup placement.  With every workgroup of a launch resident at once, CU c is given the block ids c, c + 256,
+// c + 512 (tools/timeline.py reads HW_ID), so with the causal q tiles in heaviest-first order a quarter of the CUs get
+// 8 + 6 + 4 key tiles and a quarter 6 + 4 + 2.  Walking every second row of 256 ids backwards (in units of 8, so that a
+// head keeps its XCD and its K/V stay L2 hits for all its q tiles) gives 16 / 14 / 16 / 14 instead.
+__device__ __forceinline__ int snake_block_id(int bid, const int nblocks) {
+  const int row = bid >> 8;
+  if ((row & 1) && ((row + 1) << 8) <= nblocks) {
+    const int col = bid & 255;
+    bid = (row << 8) | ((31 - (col >> 3)) << 3) | (col & 7);
+  }
+  return bid;
 }
 
 // byte offset of an LDS object inside the workgroup's allocation (what M0 / ds_* addresses are made of)

@@ -4,7 +4,7 @@ rotating over enough buffer sets to exceed the 256 MiB Infinity Cache.  Usage:
     python tools/microbench.py "B=16,H=12,S=512,D=64,causal=1" "B=32,H=12,S=128,D=64,pad=1" ...
 keys: B H S D causal pad clip int8 dtype(f16|bf16|f32) full iters reps gate base graph(=launches per captured graph)
       gmlp (>= 0: per-token gate predictor with that many hidden units evaluated in the kernel; 0 = Linear)
-      off (bit mask of kernel variants to disable: 2 = one-pass, 4 = full-row; 64 / 128 = their fp32-storage forms; 256 = one-pass also for Sk <= 128)  mq (force one-pass query blocks per wave)
+      off (bit mask of kernel variants to disable: 2 = one-pass, 4 = full-row; 64 / 128 = their fp32-storage forms; 256 = one-pass also for Sk <= 128; 512 = no snake placement)  mq (force one-pass query blocks per wave)
 """
 import ctypes as C
 import sys
