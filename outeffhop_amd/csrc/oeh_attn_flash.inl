@@ -138,21 +138,24 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   int nx_tile = 0, nx_slot = 0;
   auto issue_next = [&]() {
     const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(nx_slot * STAGEB + wave * G * 1024));
-    const bool tail = nx_tile * 64 + 64 > Sk;  // rows past Sk are redirected to row Sk-1 (finite data, masked later)
-    unsigned ko[G], vo[G];
+    if (nx_tile * 64 + 64 > Sk) {  // ragged last tile: rows past Sk are redirected to row Sk-1 (finite data, masked later)
+      unsigned ko[G], vo[G];
 #pragma unroll
-    for (int j = 0; j < G; ++j) {
-      ko[j] = koff[j];
-      vo[j] = voff[j];
-      if (tail) {
+      for (int j = 0; j < G; ++j) {
         const int over = nx_tile * 64 + piece_row(j) - (Sk - 1);
-        if (over > 0) { ko[j] -= 2u * (unsigned)(over * P.ks_s); vo[j] -= 2u * (unsigned)(over * P.vs_s); }
+        ko[j] = koff[j] - (over > 0 ? 2u * (unsigned)(over * P.ks_s) : 0u);
+        vo[j] = voff[j] - (over > 0 ? 2u * (unsigned)(over * P.vs_s) : 0u);
       }
+#pragma unroll
+      for (int j = 0; j < G; ++j) glds16_s(kcur, ko[j], slot + j * 1024);
+#pragma unroll
+      for (int j = 0; j < G; ++j) glds16_s(vcur, vo[j], slot + TILEB + j * 1024);
+    } else {  // (its own branch: the common path then issues from the loop-invariant offset registers, no copies)
+#pragma unroll
+      for (int j = 0; j < G; ++j) glds16_s(kcur, koff[j], slot + j * 1024);        // the K tile first: tile 0 starts on Q + K
+#pragma unroll
+      for (int j = 0; j < G; ++j) glds16_s(vcur, voff[j], slot + TILEB + j * 1024);
     }
-#pragma unroll
-    for (int j = 0; j < G; ++j) glds16_s(kcur, ko[j], slot + j * 1024);          // the K tile first: tile 0 starts on Q + K
-#pragma unroll
-    for (int j = 0; j < G; ++j) glds16_s(vcur, vo[j], slot + TILEB + j * 1024);
     kcur += kstep;
     vcur += vstep;
     ++nx_tile;
@@ -474,14 +477,15 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
 #pragma unroll
     for (int j = J0; j < MQ; ++j) {
       // row maximum of the exponent arguments (fma / select results: no canonicalising v_max is needed in front)
-      float mt = __builtin_fmaxf(__builtin_fmaxf(s[j][0][0], s[j][0][1]), s[j][0][2]);
-      mt = __builtin_fmaxf(__builtin_fmaxf(mt, s[j][0][3]), s[j][1][0]);
-      mt = __builtin_fmaxf(__builtin_fmaxf(mt, s[j][1][1]), s[j][1][2]);
-      mt = __builtin_fmaxf(__builtin_fmaxf(mt, s[j][1][3]), s[j][2][0]);
-      mt = __builtin_fmaxf(__builtin_fmaxf(mt, s[j][2][1]), s[j][2][2]);
-      mt = __builtin_fmaxf(__builtin_fmaxf(mt, s[j][2][3]), s[j][3][0]);
-      mt = __builtin_fmaxf(__builtin_fmaxf(mt, s[j][3][1]), s[j][3][2]);
-      mt = __builtin_fmaxf(mt, s[j][3][3]);
+      // (v_max3 written out: from fmaxf the compiler puts two canonicalising v_max x,x,x in front of every chain)
+      float mt = max3_raw(s[j][0][0], s[j][0][1], s[j][0][2]);
+      mt = max3_raw(mt, s[j][0][3], s[j][1][0]);
+      mt = max3_raw(mt, s[j][1][1], s[j][1][2]);
+      mt = max3_raw(mt, s[j][1][3], s[j][2][0]);
+      mt = max3_raw(mt, s[j][2][1], s[j][2][2]);
+      mt = max3_raw(mt, s[j][2][3], s[j][3][0]);
+      mt = max3_raw(mt, s[j][3][1], s[j][3][2]);
+      mt = max3_raw(mt, s[j][3][3], s[j][3][3]);
       // Move the reference: always on the first tile (to that tile's row maximum, unless every key of it is masked),
       // later only for rows whose maximum exceeds it by 2^8.  The common case is decided on the LANE maxima (no cross-lane
       // step); the row maximum is formed only when some row moves.  Decided per ROW, so that a row's result depends on

@@ -238,6 +238,13 @@ __device__ __forceinline__ void barrier_mem() {
   asm volatile("" ::: "memory");
 }
 
+// max(a, b, c) as the one instruction it is (inputs are arithmetic results, never signalling NaNs)
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // Workgroup placement.  With every workgroup of a launch resident at once, CU c is given the block ids c, c + 256,
 // c + 512 (tools/timeline.py reads HW_ID), so with the causal q tiles in heaviest-first order a quarter of the CUs get
 // 8 + 6 + 4 key tiles and a quarter 6 + 4 + 2.  Walking every second row of 256 ids backwards (in units of 8, so that a

@@ -4,6 +4,7 @@ rotating over enough buffer sets to exceed the 256 MiB Infinity Cache.  Usage:
     python tools/microbench.py "B=16,H=12,S=512,D=64,causal=1" "B=32,H=12,S=128,D=64,pad=1" ...
 keys: B H S D causal pad clip int8 dtype(f16|bf16|f32) full iters reps gate base graph(=launches per captured graph)
       gmlp (>= 0: per-token gate predictor with that many hidden units evaluated in the kernel; 0 = Linear)
+      ab=<other liboeh_hip.so>: same-process A/B - blocks of launches alternate between the built library and the other one
       off (bit mask of kernel variants to disable: 2 = one-pass, 4 = full-row; 64 / 128 = their fp32-storage forms; 256 = one-pass also for Sk <= 128; 512 = no snake placement)  mq (force one-pass query blocks per wave)
 """
 import ctypes as C
@@ -20,10 +21,10 @@ from outeffhop_amd import _lib, ops
 
 
 def run(spec):
-    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, reps=1, graph=0, gmlp=-1)
+    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, reps=1, graph=0, gmlp=-1, ab="")
     for item in spec.split(","):
         k, v = item.split("=")
-        kv[k] = v if k == "dtype" else int(v)
+        kv[k] = v if k in ("dtype", "ab") else int(v)
     B, H, S, D = kv["B"], kv["H"], kv["S"], kv["D"]
     _lib.load().oeh_debug_set_variant(kv["off"], kv["mq"])
     dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[kv["dtype"]]
@@ -70,6 +71,28 @@ def run(spec):
         calls[i % nsets](stream)
     torch.cuda.synchronize()
     n = kv["iters"]
+    if kv["ab"]:  # boxes differ by +-8 % and clocks wander within a run: compare two builds inside one process, interleaved
+        other = C.CDLL(kv["ab"], mode=os.RTLD_LOCAL | os.RTLD_DEEPBIND)  # DEEPBIND: its own kernels, not the already loaded library's
+        other.oeh_attn_fwd.argtypes = calls[0]._fn.argtypes
+        other.oeh_attn_fwd.restype = C.c_int
+        fns = {"built": calls[0]._fn, "other": other.oeh_attn_fwd}
+        res = {k_: [] for k_ in fns}
+        for rnd in range(12):
+            for name, fn in fns.items():
+                for c_ in calls[:4]:
+                    fn(*c_._args, stream)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(n):
+                    if fn(*calls[i % nsets]._args, stream) != 0:
+                        raise RuntimeError("launch failed")
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd >= 2:
+                    res[name].append(e0.elapsed_time(e1) * 1e3 / n)
+        mb, mo = float(np.median(res["built"])), float(np.median(res["other"]))
+        print(f"{spec[:60]:60s} built {mb:7.2f} us (min {min(res['built']):.2f})   other {mo:7.2f} us (min {min(res['other']):.2f})   built/other {mb / mo:.4f}", flush=True)
+        return
     graph = None
     if kv["graph"]:  # replay a captured graph of `graph` launches instead of launching one by one
         graph = torch.cuda.CUDAGraph()
