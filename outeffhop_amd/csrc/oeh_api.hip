@@ -187,7 +187,8 @@ int g_place = 0;                         // tools/microbench.py only: 1 = plain 
 // query blocks (16 rows) per wave of the one-pass kernel: 2 (128-row workgroups) once that still gives every CU two
 // workgroups, else 1
 int flash_mq(const oeh_attn_desc* d) {
-  if (g_flash_mq != 0) return g_flash_mq;
+  if (g_flash_mq != 0 && !(d->D == 128 && d->dtype == OEH_F32)) return g_flash_mq;
+  if (d->D == 128 && d->dtype == OEH_F32) return 1;  // two blocks of fp32 operand pairs at d = 128 do not fit the register file (130 spills)
   const long wg2 = (long)((d->Sq + 127) / 128) * d->B * d->H;
   return (d->Sq > 64 && wg2 >= 512) ? 2 : 1;
 }

@@ -673,7 +673,7 @@ template <int D, int MQ, int IN>
 static void launch_flash_d_mq_in(const AttnParams& P, unsigned grid, hipStream_t st) {
   const bool pad = P.pad != nullptr, gate = P.gh != nullptr;
   if (P.src32) {  // fp32 storage read directly, fp32 output; no in-kernel gate predictor on this path
-    if constexpr (IN == IN_F16) {
+    if constexpr (IN == IN_F16 && !(D == 128 && MQ == 2)) {  // (d = 128 with two blocks per wave: never selected, oeh_api.hip: flash_mq)
       if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, true>), dim3(grid), dim3(256), 0, st, P);
       else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true>), dim3(grid), dim3(256), 0, st, P);
     }
