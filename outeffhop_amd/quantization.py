@@ -738,6 +738,16 @@ class QuantizedOPTAttentionWithExtras(_QuantAttnBase):
     def _shape(self, tensor, seq_len, bsz):
         return tensor.view(bsz, seq_len, self.num_heads, self.head_dim).transpose(1, 2).contiguous()
 
+    def _qkv_pair_weights(self):
+        """The three projections' operand-pair weights (`QuantLinear._pair_weights`) side by side, (2K, 3E) fp16, and their fp32
+        weight scales; rebuilt when any of the three was (a changed weight or weight range rebuilds that projection's own cache)."""
+        parts = [m._pair_weights() for m in (self.q_proj, self.k_proj, self.v_proj)]
+        hit = self.__dict__.get("_qkv_pair_cache")
+        if hit is None or any(a is not b for a, (b, _) in zip(hit[0], parts)):
+            hit = (tuple(p[0] for p in parts), torch.cat([p[0] for p in parts], dim=1).contiguous())
+            self.__dict__["_qkv_pair_cache"] = hit
+        return hit[1], [p[1] for p in parts]
+
     def _int8_storage_core(self, hidden_states, attention_mask, gate, fq):
         """the q/k/v projections are QuantLinear - their outputs ARE 8-bit indices on calibrated grids
         (hijacker.py:78-127) - so the attention core can take the indices themselves and run both products on the integer
@@ -761,16 +771,24 @@ class QuantizedOPTAttentionWithExtras(_QuantAttnBase):
                 return None
         H = self.num_heads
         outs, grids = [], []
-        pairs = None
+        pairs, acc3 = None, None
+        if all(m.pair_gemm_ok(hidden_states) and m.bias is not None for m in lins):
+            # fp32 model: the input as fp16 operand pairs, split once, and ONE fp16 GEMM against the three integer weight
+            # matrices side by side; each projection's weight scale and bias are folded into its quantiser pass
+            pairs = ops.split_pairs(hidden_states.reshape(-1, hidden_states.shape[-1]))
+            ww3, scales3 = self._qkv_pair_weights()
+            acc3 = torch.mm(pairs, ww3, out_dtype=torch.float32).view(bsz, tgt_len, 3 * self.embed_dim)
         for n_, m in enumerate(lins):  # GEMM, then ONE kernel: centred int8 indices in the core's layout (v transposed) [+ the cache's floats]
-            w, b = m.get_params()
             alpha, qbias = 1.0, None
-            if m.pair_gemm_ok(hidden_states) and m.bias is not None:  # fp32 model: the input as fp16 operand pairs, split once for the
-                if pairs is None:                                       # three projections; weight scale and bias folded into the quantiser pass
+            if acc3 is not None:
+                res, alpha, qbias = acc3[..., n_ * self.embed_dim:(n_ + 1) * self.embed_dim], scales3[n_], m.bias.detach()
+            elif m.pair_gemm_ok(hidden_states) and m.bias is not None:
+                if pairs is None:
                     pairs = ops.split_pairs(hidden_states.reshape(-1, hidden_states.shape[-1]))
                 res, alpha, qbias = m.linear_pairs(hidden_states, pairs, raw=True)
                 qbias = qbias.detach()
             else:
+                w, b = m.get_params()
                 res = nn.functional.linear(hidden_states.contiguous(), w.contiguous(), bias=b)
             sp = m.activation_quantizer.quantizer.spec()
             outs.append(ops.quantize_heads_i8(res, sp, H, transpose=(n_ == 2), want_values=(n_ > 0 and self.is_decoder), alpha=alpha, bias=qbias))

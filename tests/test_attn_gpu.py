@@ -347,6 +347,27 @@ def test_one_pass_kernel_geometries(ops, mq):
         lib.oeh_debug_set_variant(0, 0)
 
 
+def test_snake_block_order_changes_nothing_but_the_placement(ops):
+    """The one-pass kernel walks every second row of 256 block ids backwards (CU load balance on causal
+    shapes).  Same results bit for bit with the plain order, for grids of whole rows, a ragged last row and a head
+    count that is not a multiple of 8."""
+    from outeffhop_amd import _lib
+
+    lib = _lib.load()
+    for n, (B, H, S) in enumerate([(16, 12, 512), (5, 12, 512), (3, 7, 1024), (9, 12, 320)]):
+        q, k, v = (_rand((B, H, S, 64), 3100 + 3 * n + i).cuda() for i in range(3))
+        assert ops.attn_variant(B, H, S, S, 64, torch.float16, causal=True).startswith("flash16/")
+        a = ops.attn_fwd(q, k, v, causal=True, clamp_min=True)
+        lib.oeh_debug_set_variant(512, 0)  # plain block order
+        try:
+            b = ops.attn_fwd(q, k, v, causal=True, clamp_min=True)
+        finally:
+            lib.oeh_debug_set_variant(0, 0)
+        assert torch.equal(a, b), f"case {n}"
+        want = O.attn_core(_np32(q[:1, :1]), _np32(k[:1, :1]), _np32(v[:1, :1]), causal=True, clamp_min=True)
+        _check(a[:1, :1], want, msg=f"case {n}")
+
+
 def test_randomised_kernel_sweep(ops):
     """Seeded random configurations through each 16-bit MFMA kernel that is eligible for them (the library's diagnostic
     hook disables variants: one-pass, full-row, general), against the oracle.  Shapes are ragged on purpose (Sq, Sk not

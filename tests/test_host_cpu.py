@@ -236,6 +236,10 @@ def test_attn_variant_describes_the_real_problem():
     assert ops.attn_variant(16, 12, 512, 512, 64, f16, causal=True).startswith("flash16/")
     assert ops.attn_variant(16, 12, 512, 512, 64, f16, clip=True, causal=True).startswith("fast16/")
     assert ops.attn_variant(32, 12, 128, 128, 64, f16, key_pad=True, scale_div=8.0).startswith("fast16/")
+    # two 16-row blocks per wave once every CU still gets two workgroups; never for fp32 operand pairs at d = 128 (registers)
+    assert ops.attn_variant(16, 12, 512, 512, 64, f16, causal=True) == "flash16/MQ2/D64/f16"
+    assert ops.attn_variant(2, 12, 512, 512, 64, f16, causal=True) == "flash16/MQ1/D64/f16"
+    assert ops.attn_variant(8, 16, 512, 512, 128, torch.float32, causal=True) == "flash16/MQ1/D128/f32"
     # vanilla softmax + key padding + long rows: neither 16-bit fast kernel takes it
     assert not ops.fused_gate_ok(2, 4, 640, 640, 64, f16, base=0, key_pad=True)
     assert ops.fused_gate_ok(2, 4, 640, 640, 64, f16, base=1, key_pad=True)
