@@ -209,7 +209,8 @@ int oeh_fake_quant_range(const void* x, void* y, int64_t n, int32_t dtype, const
  *   transpose == 0: out is (B, S, H*64) int8 in x's element order (q, k; needs x_stride[0] == S * x_stride[1]);
  *   transpose == 1: out is (B, H, 64, S) int8, keys contiguous (v: the layout the second product wants; S % 16 == 0);
  *   y (optional, may be NULL): the dequantised values scale * (idx - zero_point) in `dtype`, y_stride like x_stride - what a
- *   decoder keeps as its (k, v) cache - in the same pass;
+ *   decoder keeps as its (k, v) cache - in the same pass; with transpose == 0, out may be NULL when y is given: the values
+ *   only, i.e. a QuantLinear's scale + bias + output fake-quant in one pass over the GEMM accumulator (out_proj);
  *   bias (optional, fp32 device array of H*64, may be NULL): x is a raw GEMM accumulator and the value that is quantised is
  *   alpha * x + bias[column] - the projection's weight scale and bias folded into this pass (oeh_split_pairs' GEMM);
  *   bias == NULL: x is quantised as it is (alpha ignored).

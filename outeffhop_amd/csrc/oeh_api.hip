@@ -409,13 +409,14 @@ int oeh_fake_quant_range(const void* x, void* y, int64_t n, int32_t dtype, const
 
 int oeh_quantize_heads_i8(const void* x, int8_t* out, void* y, int64_t B, int32_t S, int32_t H, const int64_t x_stride[2], const int64_t y_stride[2],
                           int32_t dtype, float scale, float zero_point, int32_t transpose, float alpha, const float* bias, void* stream) {
-  if (x == nullptr || out == nullptr || x_stride == nullptr || B <= 0 || S <= 0 || H <= 0 || !dtype_ok(dtype)) return OEH_EINVAL;
+  if (x == nullptr || (out == nullptr && (y == nullptr || transpose)) || x_stride == nullptr || B <= 0 || S <= 0 || H <= 0 || !dtype_ok(dtype)) return OEH_EINVAL;
   if (!(scale > 0.0f) || zero_point < 0.0f || zero_point > 255.0f || zero_point != std::nearbyint(zero_point)) return OEH_EINVAL;
   if (y != nullptr && y_stride == nullptr) return OEH_EINVAL;
   if (!transpose && x_stride[0] != (int64_t)S * x_stride[1]) return OEH_ENOTSUP;
   if (!transpose && y != nullptr && y_stride[0] != (int64_t)S * y_stride[1]) return OEH_ENOTSUP;
   if (transpose && (S & 15) != 0) return OEH_ENOTSUP;
   if ((reinterpret_cast<uintptr_t>(out) & 15) != 0) return OEH_EALIGN;
+  if (y != nullptr && ((reinterpret_cast<uintptr_t>(y) | (uintptr_t)(y_stride[0] * elem_bytes(dtype)) | (uintptr_t)(y_stride[1] * elem_bytes(dtype))) & 15) != 0) return OEH_EALIGN;  // 16-byte value stores
   FqP f;
   std::memset(&f, 0, sizeof(f));
   f.en = 1; f.scale = scale; f.rscale = 1.0f / scale; f.zp = zero_point; f.qmax = 255.0f; f.lo = -zero_point; f.hi = 255.0f - zero_point;

@@ -260,6 +260,27 @@ __device__ __forceinline__ void load16_affine(const void* xp_, float (&v)[16], f
   }
 }
 
+// 16 fp32 values -> 16 consecutive storage elements (explicit 16-byte stores: element-wise stores of the unrolled loop are
+// 4 B per lane at a 64-B lane stride, measured 15 us against 9 us for the 8192 x 768 fp32 case)
+template <int IN>
+__device__ __forceinline__ void store16(void* yp_, const float (&v)[16]) {
+  if constexpr (IN == IN_F32) {
+    f4* p = reinterpret_cast<f4*>(yp_);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q] = f4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+  } else {
+    u4* p = reinterpret_cast<u4*>(yp_);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      unsigned w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        w[e] = (unsigned)In<IN>::from_f32(v[8 * q + 2 * e]) | ((unsigned)In<IN>::from_f32(v[8 * q + 2 * e + 1]) << 16);
+      p[q] = u4{w[0], w[1], w[2], w[3]};
+    }
+  }
+}
+
 // layout 0: out (B, S, H*64) int8, same element order as x
 template <int IN, bool WANT_Y>
 __global__ __launch_bounds__(256) void quantize_rows_kernel(const void* __restrict__ xin, signed char* __restrict__ out, void* __restrict__ yout,
@@ -282,11 +303,9 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const void* __restri
       w[k >> 2] |= (idx ^ 0x80u) << (8 * (k & 3));
       yv[k] = f.scale * rel;
     }
-    *reinterpret_cast<u4*>(out + r * E_ + c0) = u4{w[0], w[1], w[2], w[3]};
+    if (out != nullptr) *reinterpret_cast<u4*>(out + r * E_ + c0) = u4{w[0], w[1], w[2], w[3]};  // (NULL: the values only)
     if constexpr (WANT_Y) {
-      E* yp = reinterpret_cast<E*>(yout) + r * y_sr + c0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) yp[k] = In<IN>::from_f32(yv[k]);
+      store16<IN>(reinterpret_cast<E*>(yout) + r * y_sr + c0, yv);
     }
   }
 }
@@ -306,14 +325,15 @@ __global__ __launch_bounds__(256) void quantize_heads_t_kernel(const void* __res
   if (s < S) {
     const E* xp = reinterpret_cast<const E*>(xin) + (long)b * x_sb + (long)s * x_ss + h * 64 + d0;
     E* yp = WANT_Y ? reinterpret_cast<E*>(yout) + (long)b * y_sb + (long)s * y_ss + h * 64 + d0 : nullptr;
-    float xv16[16];
+    float xv16[16], yv[16];
     load16_affine<IN>(xp, xv16, alpha, bias != nullptr ? bias + h * 64 + d0 : nullptr);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const float rel = fq_rel(xv16[k], f);
       tile[d0 + k][row] = (unsigned char)(((unsigned int)(rel + f.zp)) ^ 0x80u);
-      if constexpr (WANT_Y) yp[k] = In<IN>::from_f32(f.scale * rel);
+      yv[k] = f.scale * rel;
     }
+    if constexpr (WANT_Y) store16<IN>(yp, yv);
   }
   __syncthreads();
   const int d = t >> 2, k0 = (t & 3) * 16;          // 16 consecutive keys of d row `d`

@@ -286,11 +286,12 @@ def split_pairs(x: torch.Tensor) -> torch.Tensor:
 
 
 def quantize_heads_i8(x: torch.Tensor, spec: "FakeQuantSpec", H: int, transpose: bool = False, want_values: bool = False,
-                      alpha: float = 1.0, bias: Optional[torch.Tensor] = None):
+                      alpha: float = 1.0, bias: Optional[torch.Tensor] = None, want_indices: bool = True):
     """A projection's output quantiser for the INT8-storage core (`oeh_quantize_heads_i8`): x (B,S,H*64) -> centred int8 indices,
     as a logical (B,H,S,64) view of a (B,S,H*64) tensor, or with `transpose` as the contiguous (B,H,64,S) tensor `attn_fwd_i8`
     wants for v; `want_values`: also the dequantised values (B,S,H*64) in x's dtype (a decoder's cache), same pass; `bias`
-    (fp32, H*64): x is a raw GEMM accumulator and alpha * x + bias is what gets quantised."""
+    (fp32, H*64): x is a raw GEMM accumulator and alpha * x + bias is what gets quantised.  `want_indices=False` (with
+    `want_values`, not transposed): only the values come back - scale + bias + output fake-quant of a QuantLinear in one pass."""
     dev = _need_gpu(x, bias)
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != H * 64 or not bias.is_contiguous()):
         raise ValueError("bias must be a contiguous fp32 vector of H*64")
@@ -298,7 +299,9 @@ def quantize_heads_i8(x: torch.Tensor, spec: "FakeQuantSpec", H: int, transpose:
         raise ValueError("x must be (B,S,H*64) fp16/bf16/fp32 and the grid 8-bit")
     xc = x if x.stride(2) == 1 else x.contiguous()
     B, S, E = xc.shape
-    out = torch.empty((B, H, 64, S) if transpose else (B, S, E), dtype=torch.int8, device=x.device)
+    if not want_indices and (transpose or not want_values):
+        raise ValueError("want_indices=False needs want_values and the untransposed layout")
+    out = torch.empty((B, H, 64, S) if transpose else (B, S, E), dtype=torch.int8, device=x.device) if want_indices else None
     y = torch.empty((B, S, E), dtype=x.dtype, device=x.device) if want_values else None
     xs = (C.c_int64 * 2)(xc.stride(0), xc.stride(1))
     ys = (C.c_int64 * 2)(S * E, E)
@@ -306,6 +309,8 @@ def quantize_heads_i8(x: torch.Tensor, spec: "FakeQuantSpec", H: int, transpose:
         rc = _lib.load().oeh_quantize_heads_i8(_ptr(xc), _ptr(out), _ptr(y), B, S, H, xs, ys, _DT[x.dtype], float(spec.scale), float(spec.zero_point),
                                                int(bool(transpose)), float(alpha), _ptr(bias), _stream())
     _lib.check(rc, "oeh_quantize_heads_i8")
+    if not want_indices:
+        return y
     idx = out if transpose else out.view(B, S, H, 64).permute(0, 2, 1, 3)
     return (idx, y) if want_values else idx
 

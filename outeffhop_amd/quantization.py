@@ -565,9 +565,25 @@ class QuantLinear(QuantizedModule, nn.Linear):
             return acc, s32, self.bias
         return torch.add(self.bias.detach(), acc, alpha=s32) if self.bias is not None else acc * s32
 
+    def _pair_gemm_quantised(self, x):
+        """The pair GEMM with its epilogue in ONE pass over the accumulator (`oeh_quantize_heads_i8`, values only): weight scale,
+        bias and the frozen 8-bit output quantiser.  None when that does not apply (the caller then runs the separate ops)."""
+        if (not self._qa or self.activation_function is not None or self.bias is None or self.out_features % 64 != 0 or x.dim() < 2
+                or not self.activation_quantizer.is_fixed or type(self.activation_quantizer.quantizer) is not AsymmetricUniformQuantizer
+                or self.activation_quantizer.quantizer.n_bits != 8):
+            return None
+        acc, s32, bias = self.linear_pairs(x, raw=True)
+        sp = self.activation_quantizer.quantizer.spec()
+        y = ops.quantize_heads_i8(acc.reshape(1, -1, self.out_features), sp, self.out_features // 64, want_values=True, alpha=s32,
+                                  bias=bias.detach(), want_indices=False)
+        return y.view(*x.shape[:-1], self.out_features)
+
     def forward(self, x, offsets=None):
         weight, bias = self.get_params()
         if self.pair_gemm_ok(x):
+            fused = self._pair_gemm_quantised(x)
+            if fused is not None:
+                return fused
             res = self.linear_pairs(x)
         else:
             res = nn.functional.linear(x.contiguous(), weight.contiguous(), bias=bias)
