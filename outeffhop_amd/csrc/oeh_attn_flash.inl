@@ -51,9 +51,15 @@ constexpr int flash_occupancy() { return D >= 128 ? 1 : (SRC32 ? 2 : 3); }  // f
 // from three MFMAs per k-step (q.k = qh.kh + 2^-11 (qh.kl + ql.kh)), the context from two (P is an fp16 operand, V the pair):
 // fp32 accuracy on the scores, fp32 accumulation and fp32 output straight from the accumulators (OUT32); Q goes global ->
 // registers directly.  No conversion pre-pass (which costs more HBM time than the attention itself).
-template <int D, int IN, int MQ, bool PAD, bool GATE, bool SRC32 = false>
+// CLIP: clipped softmax (softmax.py:10-19: clip(p (eta - gamma) + gamma, 0, 1)) needs the finished denominator before any
+// probability can enter the second product, so the key stream runs TWICE: a statistics pass (scores, lazy reference, row
+// sums of the exponentials - no V product) and a final pass that recomputes the scores against the now final reference,
+// forms p = e / den, clips and multiplies by V.  Rows of any length (the full-row kernel holds at most 512 scores per row in
+// registers and is the faster form up to there: it computes the scores once); masked keys have e = 0 and stay 0 (gamma <= 0).
+template <int D, int IN, int MQ, bool PAD, bool GATE, bool SRC32 = false, bool CLIP = false>
 __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_attn_flash_kernel(const AttnParams P) {
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit matrix-core operands");
+  static_assert(!CLIP || (!PAD && !GATE && !SRC32), "two-pass clipped form: 16-bit storage, no key padding, no in-kernel gate predictor");
   static_assert(!SRC32 || (!GATE && IN == IN_F16), "fp32 storage: fp16 operands, fp32 output, no in-kernel gate predictor");
   constexpr bool OUT32 = SRC32;
   static_assert(MQ == 1 || MQ == 2, "one or two query blocks per wave");
@@ -122,8 +128,10 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
 
   // ---- LDS-DMA stream of (K tile, V tile) stages, strictly in order: the scalar base pointers advance by 64 rows per
   // stage, the per-lane byte offsets (row of the piece, swizzled 16-B chunk) never change
-  const unsigned char* kcur = reinterpret_cast<const unsigned char*>(P.k) + 2 * ((long)b * P.ks_b + (long)h * P.ks_h);
-  const unsigned char* vcur = reinterpret_cast<const unsigned char*>(P.v) + 2 * ((long)b * P.vs_b + (long)h * P.vs_h);
+  const unsigned char* const kbase0 = reinterpret_cast<const unsigned char*>(P.k) + 2 * ((long)b * P.ks_b + (long)h * P.ks_h);
+  const unsigned char* const vbase0 = reinterpret_cast<const unsigned char*>(P.v) + 2 * ((long)b * P.vs_b + (long)h * P.vs_h);
+  const unsigned char* kcur = kbase0;
+  const unsigned char* vcur = vbase0;
   const int prow = lane / CPR, pch = lane % CPR;
   const unsigned lds_base = lds_offset(lds);
   auto piece_row = [&](int j) { return (wave * G + j) * RPP + prow; };
@@ -382,6 +390,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   // exponent argument; O and l are sums of exp2(t).  The reference is the first tile's row maximum and afterwards
   // moves only when a tile maximum exceeds it by 2^8.  softmax_1's "+1" is exp2(mcneg) (= exp(-reference)).
   float mcneg[MQ];
+  float lsum[MQ], pinv[MQ];             // CLIP: this lane's share of the row sum of exp (statistics pass); 1 / denominator (final pass)
+#pragma unroll
+  for (int j = 0; j < MQ; ++j) { lsum[j] = 0.0f; pinv[j] = 1.0f; }
   f4 lacc[MQ];                          // row sums of the ROUNDED P, accumulated by a ones-row MFMA (every register = l)
   f4 o[MQ][DT], ox[SRC32 ? MQ : 1][SRC32 ? DT : 1];  // ox: the V-lo part of the context (SRC32), scaled by 2^-11 at the end
 #pragma unroll
@@ -397,9 +408,11 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   }
 
   // ---- one 64-key tile for blocks J0..MQ-1 of this wave (J0 = 1: block 0's rows end before this tile)
-  auto tile = [&](auto j0c, auto firstc, const int i, const int soff) {
+  // MODE 0: the one-pass tile; CLIP: 1 = statistics pass (no second product), 2 = final pass (final reference, clip)
+  auto tile = [&](auto j0c, auto firstc, auto modec, const int i, const int soff) {
     constexpr int J0 = decltype(j0c)::value;
     constexpr bool FIRST = decltype(firstc)::value;  // tile 0: V tile 0 is awaited between the two products
+    constexpr int MODE = decltype(modec)::value;
     // S^T = K Q^T; every K fragment is read once and used by all active blocks
     __builtin_amdgcn_s_setprio(1);  // matrix-core phases at a higher issue priority than the other waves' softmax arithmetic (dense S=512: -2.7 %)
     f4 s[MQ][4];
@@ -476,6 +489,24 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     u4 pb[MQ][2];
 #pragma unroll
     for (int j = J0; j < MQ; ++j) {
+      if constexpr (MODE == 2) {  // final reference: exponentials, p = e / den, clip, pack
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pv = __builtin_amdgcn_exp2f(s[j][sub][r]) * pinv[j];
+            pv = pv * P.clip_w;
+            pv = pv + P.clip_g;
+            s[j][sub][r] = __builtin_amdgcn_fmed3f(pv, 0.0f, 1.0f);
+          }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f4 a = s[j][2 * u], bb = s[j][2 * u + 1];
+          if constexpr (IN == IN_BF16) pb[j][u] = u4{pack2_bf16(a[0], a[1]), pack2_bf16(a[2], a[3]), pack2_bf16(bb[0], bb[1]), pack2_bf16(bb[2], bb[3])};
+          else pb[j][u] = u4{pack2_f16(a[0], a[1]), pack2_f16(a[2], a[3]), pack2_f16(bb[0], bb[1]), pack2_f16(bb[2], bb[3])};
+        }
+        continue;
+      }
       // row maximum of the exponent arguments (fma / select results: no canonicalising v_max is needed in front)
       // (v_max3 written out: from fmaxf the compiler puts two canonicalising v_max x,x,x in front of every chain)
       float mt = max3_raw(s[j][0][0], s[j][0][1], s[j][0][2]);
@@ -500,6 +531,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
           for (int r = 0; r < 4; ++r) s[j][sub][r] -= delta;
         if (i != 0) {
           const float alpha = __builtin_amdgcn_exp2f(-delta);
+          if constexpr (MODE == 1) lsum[j] *= alpha;
 #pragma unroll
           for (int r = 0; r < 4; ++r) lacc[j][r] *= alpha;
 #pragma unroll
@@ -518,6 +550,11 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[j][sub][r] = __builtin_amdgcn_exp2f(s[j][sub][r]);
+      if constexpr (MODE == 1) {  // statistics pass: the sum of the exponentials themselves (fp32), nothing else
+        f4 t4 = (s[j][0] + s[j][1]) + (s[j][2] + s[j][3]);
+        lsum[j] += (t4[0] + t4[1]) + (t4[2] + t4[3]);
+        continue;
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const f4 a = s[j][2 * u], bb = s[j][2 * u + 1];
@@ -535,11 +572,14 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       if (2 < n_kt) issue_next();
     }
     // O^T += V^T P^T and l += 1^T P^T; every V^T fragment is read once and used by all active blocks
+    if constexpr (MODE == 1) return;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
+      if constexpr (MODE == 0) {
 #pragma unroll
-      for (int j = J0; j < MQ; ++j) lacc[j] = mfma16<IN>(ones, pb[j][u], lacc[j]);
+        for (int j = J0; j < MQ; ++j) lacc[j] = mfma16<IN>(ones, pb[j][u], lacc[j]);
+      }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const unsigned char* a0 = vaddr[dt] + soff + u * 32 * ROWB;
@@ -574,13 +614,14 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       slot_r ^= 1;
       if (i >= nkb[MQ - 1]) continue;
       if (MQ == 2 && i >= nkb[0]) {
-        if constexpr (MQ == 2) tile(J0_1{}, std::false_type{}, i, soff);
+        if constexpr (MQ == 2) tile(J0_1{}, std::false_type{}, std::integral_constant<int, 0>{}, i, soff);
       } else {
-        tile(J0_0{}, std::false_type{}, i, soff);
+        tile(J0_0{}, std::false_type{}, std::integral_constant<int, 0>{}, i, soff);
       }
     }
   } else {
-  tile(J0_0{}, std::true_type{}, 0, 0);  // every block sees key 0: tile 0 is computed by every wave, for all its blocks
+  using MODE_A = std::integral_constant<int, CLIP ? 1 : 0>;  // the (first) pass over the keys
+  tile(J0_0{}, std::true_type{}, MODE_A{}, 0, 0);  // every block sees key 0: tile 0 is computed by every wave, for all its blocks
   OEH_STAMP(6);
   int slot_i = 1;
   for (int i = 1; i < n_kt; ++i) {
@@ -598,11 +639,46 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     slot_i = (slot_i == R - 1) ? 0 : slot_i + 1;
     if (i >= nkb[MQ - 1]) continue;  // this wave's rows end before this tile (causal): nothing to compute
     if (MQ == 2 && i >= nkb[0]) {
-      if constexpr (MQ == 2) tile(J0_1{}, std::false_type{}, i, soff);
+      if constexpr (MQ == 2) tile(J0_1{}, std::false_type{}, MODE_A{}, i, soff);
     } else {
-      tile(J0_0{}, std::false_type{}, i, soff);
+      tile(J0_0{}, std::false_type{}, MODE_A{}, i, soff);
     }
     if (i < 8) OEH_STAMP(6 + 3 * i);
+  }
+  if constexpr (CLIP) {
+    // ---- denominators (sum over the 4 lanes of a row), then the same stream once more: both slots of the ring are primed
+    // again and every tile goes through the loop form (no Q stage this time: the operands are in registers)
+    using MODE_B = std::integral_constant<int, 2>;
+#pragma unroll
+    for (int j = 0; j < MQ; ++j) {
+      float l = lsum[j];
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      if (P.base != 0) l = l + __builtin_amdgcn_exp2f(mcneg[j]);  // softmax_1: + 1*exp(-reference)
+      pinv[j] = 1.0f / l;
+    }
+    barrier_mem();  // every wave has left the last stages of the first pass; nothing is in flight
+    kcur = kbase0;
+    vcur = vbase0;
+    nx_tile = 0;
+    nx_slot = 0;
+    issue_next();
+    if (1 < n_kt) issue_next();
+    int slot_b = 0;
+    for (int i = 0; i < n_kt; ++i) {
+      if (i + 1 < n_kt) wait_vm(std::integral_constant<int, 2>{});
+      else wait_vm(std::integral_constant<int, 0>{});
+      barrier_mem();
+      if (i + 2 < n_kt) issue_next();
+      const int soff = slot_b * STAGEB;
+      slot_b = (slot_b == R - 1) ? 0 : slot_b + 1;
+      if (i >= nkb[MQ - 1]) continue;
+      if (MQ == 2 && i >= nkb[0]) {
+        if constexpr (MQ == 2) tile(J0_1{}, std::false_type{}, MODE_B{}, i, soff);
+      } else {
+        tile(J0_0{}, std::false_type{}, MODE_B{}, i, soff);
+      }
+    }
   }
   }
   OEH_STAMP(2);
@@ -623,6 +699,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     float den = lacc[j][0];
     if (P.base != 0) den = den + __builtin_amdgcn_exp2f(mcneg[j]);  // softmax_1: + 1*exp(-reference)  (vutils/softmax_1.py:18-20)
     float rowscale = 1.0f / den;
+    if constexpr (CLIP) rowscale = 1.0f;  // the clipped probabilities went into the product as they are
     if (P.gate != nullptr && qrow < Sq) rowscale = rowscale * P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
     if constexpr (GATE) rowscale = rowscale * gate_row[j];
     if constexpr (OUT32) {  // fp32 output straight from the accumulators (fp32 storage): 16 B per lane, 64 B per row and instruction
@@ -677,6 +754,10 @@ static void launch_flash_d_mq_in(const AttnParams& P, unsigned grid, hipStream_t
       if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, true>), dim3(grid), dim3(256), 0, st, P);
       else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true>), dim3(grid), dim3(256), 0, st, P);
     }
+    return;
+  }
+  if (P.clip) {  // (oeh_api.hip: flash_clip_eligible - no key padding, no in-kernel predictor)
+    hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, false, true>), dim3(grid), dim3(256), 0, st, P);
     return;
   }
   if (pad) {

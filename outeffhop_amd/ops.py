@@ -217,8 +217,8 @@ def attn_fwd(
         _fill_fq(fqd.probs, fq.probs)
         _fill_fq(fqd.ctx, fq.ctx)
         fqd.ctx_quant_before_gate = int(bool(fq.ctx_before_gate))
-    _warn_if_any_shape_kernel(B, H, Sq, Sk, D, q.dtype, softmax, fqd is not None)
     lib = _lib.load()
+    _warn_if_any_shape_kernel(lib, d, fqd, softmax)
     if _prepared is not None:  # hand back the prebuilt C call instead of launching (bench / hipGraph loops)
         args = (C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), None if fqd is None else C.byref(fqd))
         _prepared.extend([lib.oeh_attn_fwd, args, (d, fqd, keep, q, k, v, out)])
@@ -232,18 +232,23 @@ def attn_fwd(
 _warned_generic = set()
 
 
-def _warn_if_any_shape_kernel(B, H, Sq, Sk, D, dtype, softmax, has_fq) -> None:
+def _warn_if_any_shape_kernel(lib, d, fqd, softmax) -> None:
     """The any-shape kernel (one workgroup per query ROW, fp32 FMAs) is correct for everything and ~100x slower than the
     matrix-core kernels: say so once per kind of shape instead of letting a configuration fall off that cliff silently
-    (VERDICT r1 weak #13).  Host-side checks only (no library call on the hot path)."""
-    reason = None
-    if D not in (16, 32, 64, 128):
-        reason = f"head dim {D} (matrix-core kernels: 32, 64, 128; 16 for <= 64 keys)"
-    elif D == 16 and (Sk > 64 or Sq > 64):
-        reason = f"head dim 16 with more than 64 rows (Sq={Sq}, Sk={Sk})"
-    elif Sk > 512 and (softmax.clip or has_fq):
-        reason = f"{'clipped softmax' if softmax.clip else 'fused fake-quant'} with {Sk} > 512 keys (the full-row kernels hold a row of <= 512 scores)"
-    if reason is not None and reason not in _warned_generic:
+    (VERDICT r1 weak #13).  Asks the library which kernel the descriptor selects (a host-side call, no launch)."""
+    name = lib.oeh_attn_variant(C.byref(d), None if fqd is None else C.byref(fqd))
+    if name is None or not name.startswith(b"generic"):
+        return
+    if d.D not in (16, 32, 64, 128):
+        reason = f"head dim {d.D} (matrix-core kernels: 32, 64, 128; 16 for <= 64 keys)"
+    elif d.D == 16:
+        reason = f"head dim 16 with more than 64 rows (Sq={d.Sq}, Sk={d.Sk})"
+    elif d.Sk > 512:
+        what = "fused fake-quant" if fqd is not None else ("clipped softmax outside the two-pass kernel's cases" if softmax.clip else "this mask / scale combination")
+        reason = f"{what} with {d.Sk} > 512 keys (the full-row kernels hold a row of <= 512 scores)"
+    else:
+        reason = "unaligned q / k / v / out (16-byte rows) or a mask / scale combination outside the matrix-core kernels"
+    if reason not in _warned_generic:
         import warnings
 
         _warned_generic.add(reason)

@@ -347,6 +347,46 @@ def test_one_pass_kernel_geometries(ops, mq):
         lib.oeh_debug_set_variant(0, 0)
 
 
+@pytest.mark.parametrize("mq", [1, 2])
+def test_clipped_softmax_on_long_rows_two_pass(ops, mq):
+    """Clipped softmax (softmax.py:10-19) on rows of more than 512 keys: the one-pass kernel's two-pass form (statistics pass,
+    then the product against the final denominator) instead of the any-shape kernel.  Causal, cross attention with a ragged
+    last tile, a key/value cache offset, bf16, D in {32, 128}; and, forced onto rows the full-row kernel takes, the two
+    kernels agree to the fp16 contract."""
+    from outeffhop_amd import _lib
+
+    lib = _lib.load()
+    lib.oeh_debug_set_variant(0, mq)
+    try:
+        cases = [  # (B, H, Sq, Sk, D, causal, softmax, dtype)
+            (1, 2, 640, 640, 64, True, "clippedsoftmax1(-.025:1)", torch.float16),
+            (1, 1, 200, 1000, 64, False, "clipped(-.003:1.003)", torch.float16),
+            (1, 2, 192, 704, 64, True, "clippedsoftmax1(-.025:1)", torch.float16),
+            (1, 2, 576, 576, 128, True, "clippedsoftmax1(-.025:1)", torch.float16),
+            (2, 1, 130, 700, 32, False, "clipped(-.003:1.003)", torch.bfloat16),
+        ]
+        for n, (B, H, Sq, Sk, D, causal, sm, dt) in enumerate(cases):
+            sp = SPECS[sm]
+            name = ops.attn_variant(B, H, Sq, Sk, D, dt, clip=True, base=sp["base"], gamma=sp["gamma"], causal=causal, scale=D ** -0.5)
+            assert name.startswith(f"flash16/MQ{mq}/") and name.endswith("/clip2p"), name
+            q = _rand((B, H, Sq, D), 4100 + n, dtype=dt)
+            k, v = _rand((B, H, Sk, D), 4120 + n, dtype=dt), _rand((B, H, Sk, D), 4140 + n, dtype=dt)
+            want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=D ** -0.5, causal=causal, clamp_min=causal, **sp)
+            got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=_spec(ops, sm), scale=D ** -0.5, causal=causal, clamp_min=causal)
+            tol = F16_TOL if dt == torch.float16 else dict(atol=2e-2, rtol=2e-2)
+            _check(got, want, tol=tol, msg=f"case {n} mq={mq}")
+        # rows the full-row kernel takes: force the two-pass form over the same problem
+        q, k, v = (_rand((2, 3, 512, 64), 4200 + i).cuda() for i in range(3))
+        kw = dict(softmax=_spec(ops, "clippedsoftmax1(-.025:1)"), scale=0.125, causal=True, clamp_min=True)
+        lib.oeh_debug_set_variant(0, 0)
+        a = ops.attn_fwd(q, k, v, **kw)
+        lib.oeh_debug_set_variant(256, mq)
+        b = ops.attn_fwd(q, k, v, **kw)
+        assert float((a.float() - b.float()).abs().max()) <= 1.5e-3
+    finally:
+        lib.oeh_debug_set_variant(0, 0)
+
+
 def test_snake_block_order_changes_nothing_but_the_placement(ops):
     """The one-pass kernel walks every second row of 256 block ids backwards (CU load balance on causal
     shapes).  Same results bit for bit with the plain order, for grids of whole rows, a ragged last row and a head
