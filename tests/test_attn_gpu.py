@@ -175,13 +175,15 @@ def test_other_storage_dtypes(ops, dtype, tol):
 
 
 def test_generic_kernel_shapes(ops):
-    """Shapes outside the MFMA kernel (D=16/48, Sk>512) run the generic HIP kernel."""
-    for (B, H, Sq, Sk, D) in [(3, 4, 7, 5, 16), (1, 2, 33, 33, 48), (1, 1, 20, 700, 64)]:
-        assert ops.attn_variant(B, H, Sq, Sk, D, clip=True) == ("generic" if D != 16 else "small/ST2/D16/f16")
-        q, k, v = _rand((B, H, Sq, D), 71), _rand((B, H, Sk, D), 72), _rand((B, H, Sk, D), 73)
+    """Shapes outside the MFMA kernels (D = 48; clipped softmax on more than 512 keys of fp32 storage) run the any-shape HIP
+    kernel; D = 16 with few rows has the small-shape kernel, 16-bit clipped rows of more than 512 keys the two-pass one."""
+    for (B, H, Sq, Sk, D, dt, name) in [(3, 4, 7, 5, 16, torch.float16, "small/ST2/D16/f16"), (1, 2, 33, 33, 48, torch.float16, "generic"),
+                                        (1, 1, 20, 700, 64, torch.float16, "flash16/MQ1/D64/f16/clip2p"), (1, 1, 20, 700, 64, torch.float32, "generic")]:
+        assert ops.attn_variant(B, H, Sq, Sk, D, dt, clip=True) == name
+        q, k, v = _rand((B, H, Sq, D), 71, dtype=dt), _rand((B, H, Sk, D), 72, dtype=dt), _rand((B, H, Sk, D), 73, dtype=dt)
         want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=1 / math.sqrt(D), **SPECS["clippedsoftmax1(-.025:1)"])
         got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=_spec(ops, "clippedsoftmax1(-.025:1)"), scale=1 / math.sqrt(D))
-        _check(got, want, msg=f"{(B, H, Sq, Sk, D)}")
+        _check(got, want, msg=f"{(B, H, Sq, Sk, D, dt)}")
     assert ops.attn_variant(16, 12, 512, 512, 64, clip=True) == "fast16/NT32/D64/f16/clip"
     assert ops.attn_variant(16, 12, 512, 512, 64) == "flash16/MQ2/D64/f16"
 
