@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   if (bh >= P.nBH) return;
   const int b = bh / P.H, h = bh - b * P.H;
 
+  if constexpr (SRC32) fp16_overflow_clamp();  // out-of-range fp32 operands saturate (oeh_common.h)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

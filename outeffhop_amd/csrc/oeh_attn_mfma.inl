@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256, (occupancy_hint<NT, D, IN>())) void oeh_attn_m
   const int qt = P.nQT - 1 - qt_rev;
   const int b = bh / P.H, h = bh - b * P.H;
 
+  if constexpr (SPLIT) fp16_overflow_clamp();  // out-of-range fp32 operands saturate (oeh_common.h)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

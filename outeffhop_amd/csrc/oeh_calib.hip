@@ -387,6 +387,7 @@ namespace oeh {
 __global__ __launch_bounds__(256) void split_pairs_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, long rows, int K, long x_sr) {
   const long chunks = (long)K / 8;
   const long total = rows * chunks;
+  fp16_overflow_clamp();  // activations beyond the fp16 range saturate instead of becoming inf (oeh_common.h)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / chunks;
     const int c0 = (int)(i - r * chunks) * 8;

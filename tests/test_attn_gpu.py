@@ -700,6 +700,25 @@ def test_bert_order_with_a_divisor_that_is_not_a_power_of_two(ops, D):
     assert _lib.load().oeh_attn_variant(d, fqd).decode().startswith("mfma16/")
 
 
+def test_fp32_storage_out_of_range_values_saturate(ops):
+    """fp32 q / k / v are carried as fp16 operand pairs; a value beyond the fp16 range must not turn into inf
+    (and the row into NaN).  The pair saturates: exact up to 65504 + 32, finite beyond; every other row is untouched."""
+    B, H, S, D = 1, 2, 192, 64
+    q, k, v = (_rand((B, H, S, D), 5100 + i, dtype=torch.float32).cuda() for i in range(3))
+    base = ops.attn_fwd(q, k, v, causal=True, clamp_min=True, scale=0.125)
+    q2, v2 = q.clone(), v.clone()
+    q2[0, 0, 17, 3] = 65520.0      # inside hi + lo 2^-11: still exact to 2^-22
+    q2[0, 1, 40, 9] = 3.0e5        # beyond: saturates
+    v2[0, 1, 5, 0] = -1.0e6
+    out = ops.attn_fwd(q2, k, v2, causal=True, clamp_min=True, scale=0.125)
+    assert bool(torch.isfinite(out).all())
+    want = O.attn_core(_np32(q2[:, :1]), _np32(k[:, :1]), _np32(v[:, :1]), causal=True, clamp_min=True, scale=0.125)
+    _check(out[:, :1], want, tol=dict(atol=5e-4, rtol=5e-4), msg="head 0 (65520 in q)")
+    untouched = torch.ones(S, dtype=torch.bool, device="cuda")
+    untouched[40] = False
+    assert torch.equal(out[0, 1, untouched, 1:], base[0, 1, untouched, 1:])  # v's column 0 and q's row 40 are the only places the big values reach
+
+
 def test_randomised_sweep_fp32_storage(ops):
     """The same kind of sweep on fp32 tensors: the register-staged fp32 forms of the one-pass and the full-row kernel and
     the general kernel, ragged shapes, strided head views, masks, gates, clipped and plain softmax, against the oracle."""

@@ -466,6 +466,9 @@ def test_quantlinear_operand_pair_gemm(oa, monkeypatch):
         rec = pairs[:, :768].float() + pairs[:, 768:].float() / 2048.0
         x2 = x.reshape(-1, 768)  # hi + lo 2^-11 reproduces x to 2^-22 relative (values below the fp16 normal range: to 2^-34 absolute)
         assert bool(((rec - x2).abs() <= 2.0 ** -21 * x2.abs() + 2.0 ** -34).all())
+        big = torch.tensor([[65520.0, -3.0e5, 1.0, 0.0, 2.0, 3.0, 4.0, 5.0]], device=dev)  # beyond the fp16 range: saturates, never inf
+        pb = ops.split_pairs(big).float()
+        assert bool(torch.isfinite(pb).all()) and float(pb[0, 0] + pb[0, 8] / 2048.0) == 65520.0 and float(pb[0, 1]) == -65504.0
         got = ql.linear_pairs(x)
         wq, b = ql.get_params()
         exact = torch.nn.functional.linear(x.double(), wq.double(), b.double())
