@@ -146,7 +146,9 @@ bool flash_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq, bool short_ro
 // Clipped softmax on rows of MORE than 512 keys: the one-pass kernel's two-pass form (CLIP: statistics, then the product;
 // oeh_attn_flash.inl).  Up to 512 keys the full-row kernel computes the scores once and is the faster one.
 bool flash_clip_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
-  if (!d->clip || any_fq(fq) || !fast_eligible(d, fq)) return false;  // (fast_eligible: 16-bit storage, gamma <= 0, masks, scale)
+  oeh_attn_desc t = *d;
+  if (t.dtype == OEH_F32) t.dtype = OEH_F16;  // fp32 storage: the SRC32 form (operand pairs), same conditions on the problem
+  if (!d->clip || any_fq(fq) || !fast_eligible(&t, fq)) return false;  // (fast_eligible: gamma <= 0, masks, scale)
   if (d->key_pad_mask != nullptr || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
   return d->Sk > 512 || g_force_flash;
 }
@@ -229,7 +231,7 @@ Variant pick_variant(const oeh_attn_desc* d, const void* q, const void* k, const
   if (small_eligible(d, q, k, v, o, fq) && !(g_variant_off & (1 << V_SMALL))) return V_SMALL;
   if (d_ok && al && flash_eligible(d, fq) && !(g_variant_off & (1 << V_FLASH))) return V_FLASH;
   if (d_ok && al && flash32_eligible(d, fq) && !(g_variant_off & ((1 << V_FLASH) | (1 << 6)))) return V_FLASH;
-  if (d_ok && al && flash_clip_eligible(d, fq) && !(g_variant_off & (1 << V_FLASH))) return V_FLASH;
+  if (d_ok && al && flash_clip_eligible(d, fq) && !(g_variant_off & ((1 << V_FLASH) | (d->dtype == OEH_F32 ? (1 << 6) : 0)))) return V_FLASH;
   if (shape_ok && p_exact && al && fast_eligible(d, fq) && !(g_variant_off & (1 << V_FAST))) return V_FAST;
   if (shape_ok && p_exact && al && fast32_eligible(d, fq) && !(g_variant_off & ((1 << V_FAST) | (1 << 7)))) return V_FAST;
   if (shape_ok && p_exact && al) return V_MFMA;

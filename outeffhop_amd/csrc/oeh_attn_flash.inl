@@ -59,7 +59,7 @@ constexpr int flash_occupancy() { return D >= 128 ? 1 : (SRC32 ? 2 : 3); }  // f
 template <int D, int IN, int MQ, bool PAD, bool GATE, bool SRC32 = false, bool CLIP = false>
 __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_attn_flash_kernel(const AttnParams P) {
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit matrix-core operands");
-  static_assert(!CLIP || (!PAD && !GATE && !SRC32), "two-pass clipped form: 16-bit storage, no key padding, no in-kernel gate predictor");
+  static_assert(!CLIP || (!PAD && !GATE), "two-pass clipped form: no key padding, no in-kernel gate predictor");
   static_assert(!SRC32 || (!GATE && IN == IN_F16), "fp32 storage: fp16 operands, fp32 output, no in-kernel gate predictor");
   constexpr bool OUT32 = SRC32;
   static_assert(MQ == 1 || MQ == 2, "one or two query blocks per wave");
@@ -606,19 +606,37 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   using J0_0 = std::integral_constant<int, 0>;
   using J0_1 = std::integral_constant<int, 1>;
   if constexpr (SRC32) {
-    int slot_r = 0;
-    for (int i = 0; i < n_kt; ++i) {
-      commit_regs(slot_r);                  // stage i (its loads were issued a tile ago) -> LDS; the slot's last readers (tile i-2) are behind the previous barrier
-      barrier_mem();
-      if (i + 1 < n_kt) load_regs(i + 1);   // lands while tile i is computed
-      const int soff = slot_r * SLOT32;
-      slot_r ^= 1;
-      if (i >= nkb[MQ - 1]) continue;
-      if (MQ == 2 && i >= nkb[0]) {
-        if constexpr (MQ == 2) tile(J0_1{}, std::false_type{}, std::integral_constant<int, 0>{}, i, soff);
-      } else {
-        tile(J0_0{}, std::false_type{}, std::integral_constant<int, 0>{}, i, soff);
+    auto stream32 = [&](auto modec) {  // one pass over the register-staged stream (stage 0 is in the registers on entry)
+      int slot_r = 0;
+      for (int i = 0; i < n_kt; ++i) {
+        commit_regs(slot_r);                  // stage i (its loads were issued a tile ago) -> LDS; the slot's last readers (tile i-2) are behind the previous barrier
+        barrier_mem();
+        if (i + 1 < n_kt) load_regs(i + 1);   // lands while tile i is computed
+        const int soff = slot_r * SLOT32;
+        slot_r ^= 1;
+        if (i >= nkb[MQ - 1]) continue;
+        if (MQ == 2 && i >= nkb[0]) {
+          if constexpr (MQ == 2) tile(J0_1{}, std::false_type{}, modec, i, soff);
+        } else {
+          tile(J0_0{}, std::false_type{}, modec, i, soff);
+        }
       }
+    };
+    if constexpr (CLIP) {
+      stream32(std::integral_constant<int, 1>{});
+#pragma unroll
+      for (int j = 0; j < MQ; ++j) {
+        float l = lsum[j];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        if (P.base != 0) l = l + __builtin_amdgcn_exp2f(mcneg[j]);  // softmax_1: + 1*exp(-reference)
+        pinv[j] = 1.0f / l;
+      }
+      barrier_mem();  // the last stages of the first pass have been read by every wave
+      load_regs(0);
+      stream32(std::integral_constant<int, 2>{});
+    } else {
+      stream32(std::integral_constant<int, 0>{});
     }
   } else {
   using MODE_A = std::integral_constant<int, CLIP ? 1 : 0>;  // the (first) pass over the keys
@@ -752,7 +770,8 @@ static void launch_flash_d_mq_in(const AttnParams& P, unsigned grid, hipStream_t
   const bool pad = P.pad != nullptr, gate = P.gh != nullptr;
   if (P.src32) {  // fp32 storage read directly, fp32 output; no in-kernel gate predictor on this path
     if constexpr (IN == IN_F16 && !(D == 128 && MQ == 2)) {  // (d = 128 with two blocks per wave: never selected, oeh_api.hip: flash_mq)
-      if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, true>), dim3(grid), dim3(256), 0, st, P);
+      if (P.clip) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true, true>), dim3(grid), dim3(256), 0, st, P);
+      else if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, true>), dim3(grid), dim3(256), 0, st, P);
       else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true>), dim3(grid), dim3(256), 0, st, P);
     }
     return;
