@@ -40,8 +40,16 @@ template <int ET, int ST, int IN>
 __global__ __launch_bounds__(256, 2) void oeh_attn_small_kernel(const AttnParams P) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int bh = blockIdx.x * 4 + wave;
+  // P.nQT query blocks of 16 rows per wave: all of them (one wave per problem), or ONE (P.nQT == 1: a wave per problem and
+  // 16-row block, the waves of a problem next to each other in a workgroup so that their K / V loads meet in the CU's cache) -
+  // chosen by the launcher when whole problems would leave most SIMDs without a wave
+  const int nqb = (P.Sq + 15) >> 4;
+  const int per = (P.nQT == 1) ? nqb : 1;       // waves per problem
+  const int wg = blockIdx.x * 4 + wave;
+  const int bh = wg / per;
   if (bh >= P.nBH) return;
+  const int qb0 = (wg - bh * per) * 16;
+  const int q_end = (P.nQT == 1) ? min(P.Sq, qb0 + 16) : P.Sq;
   const int b = bh / P.H, h = bh - b * P.H;
   const int c = lane & 15, g = lane >> 4;
   const int Sk = P.Sk, Sq = P.Sq;
@@ -64,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void oeh_attn_small_kernel(const AttnParams
   }
   const bool use_div = P.scale_div != 0.0f;
 
-  for (int q0 = 0; q0 < Sq; q0 += 16) {
+  for (int q0 = qb0; q0 < q_end; q0 += 16) {
     const int qrow = q0 + c;
     const long qoff = (long)b * P.qs_b + (long)h * P.qs_h + (long)min(qrow, Sq - 1) * P.qs_s + 4 * g;
     f4 qf[ET];
@@ -145,11 +153,17 @@ __global__ __launch_bounds__(256, 2) void oeh_attn_small_kernel(const AttnParams
 
 template <int ET, int ST>
 static int launch_small_et_st(const AttnParams& P, int in, hipStream_t st) {
-  const unsigned grid = (unsigned)((P.nBH + 3) / 4);
+  // fewer than two waves per SIMD of the device with one wave per problem: a wave per 16-row block instead (STanHop: 896
+  // problems of 28 rows on 1024 SIMDs -> 1792 waves; 12.1 -> see DESIGN 4.8)
+  AttnParams Q = P;
+  const long nqb = (P.Sq + 15) / 16;
+  Q.nQT = (nqb > 1 && (long)P.nBH < 2048) ? 1 : 0;
+  const long waves = Q.nQT == 1 ? (long)P.nBH * nqb : (long)P.nBH;
+  const unsigned grid = (unsigned)((waves + 3) / 4);
   switch (in) {
-    case IN_F16: hipLaunchKernelGGL((oeh_attn_small_kernel<ET, ST, IN_F16>), dim3(grid), dim3(256), 0, st, P); break;
-    case IN_BF16: hipLaunchKernelGGL((oeh_attn_small_kernel<ET, ST, IN_BF16>), dim3(grid), dim3(256), 0, st, P); break;
-    default: hipLaunchKernelGGL((oeh_attn_small_kernel<ET, ST, IN_F32>), dim3(grid), dim3(256), 0, st, P); break;
+    case IN_F16: hipLaunchKernelGGL((oeh_attn_small_kernel<ET, ST, IN_F16>), dim3(grid), dim3(256), 0, st, Q); break;
+    case IN_BF16: hipLaunchKernelGGL((oeh_attn_small_kernel<ET, ST, IN_BF16>), dim3(grid), dim3(256), 0, st, Q); break;
+    default: hipLaunchKernelGGL((oeh_attn_small_kernel<ET, ST, IN_F32>), dim3(grid), dim3(256), 0, st, Q); break;
   }
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
