@@ -153,6 +153,17 @@ bool flash_clip_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
   return d->Sk > 512 || g_force_flash;
 }
 
+// The fused INT8 chain on rows of MORE than 512 keys: the one-pass kernel's two-pass form of the grid chain (TP = 2).  What
+// the full-row kernel's FQ == 1 takes: scores and probabilities both quantised, no clip, no key padding, no test dumps.
+bool flash_fq_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
+  oeh_attn_desc t = *d;
+  if (t.dtype == OEH_F32) t.dtype = OEH_F16;  // fp32 storage: the SRC32 form
+  if (!any_fq(fq) || d->clip || !fast_eligible(&t, fq)) return false;  // (fast_eligible: both quantisers, no dumps, scale, masks)
+  if (d->key_pad_mask != nullptr || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
+  if (fq->probs.qmax > (d->dtype == OEH_BF16 ? 255.0f : 2047.0f)) return false;  // the integer-valued P operand must be exact
+  return d->Sk > 512 || g_force_flash;
+}
+
 // fp32 storage on the one-pass kernel (SRC32 variants: tiles staged through registers, fp16 operands, fp32 output): the same
 // conditions on the problem; the in-kernel gate predictor reads a 16-bit layer input and is not available
 bool flash32_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
@@ -231,6 +242,7 @@ Variant pick_variant(const oeh_attn_desc* d, const void* q, const void* k, const
   if (small_eligible(d, q, k, v, o, fq) && !(g_variant_off & (1 << V_SMALL))) return V_SMALL;
   if (d_ok && al && flash_eligible(d, fq) && !(g_variant_off & (1 << V_FLASH))) return V_FLASH;
   if (d_ok && al && flash32_eligible(d, fq) && !(g_variant_off & ((1 << V_FLASH) | (1 << 6)))) return V_FLASH;
+  if (d_ok && al && flash_fq_eligible(d, fq) && !(g_variant_off & ((1 << V_FLASH) | (d->dtype == OEH_F32 ? (1 << 6) : 0)))) return V_FLASH;
   if (d_ok && al && flash_clip_eligible(d, fq) && !(g_variant_off & ((1 << V_FLASH) | (d->dtype == OEH_F32 ? (1 << 6) : 0)))) return V_FLASH;
   if (shape_ok && p_exact && al && fast_eligible(d, fq) && !(g_variant_off & (1 << V_FAST))) return V_FAST;
   if (shape_ok && p_exact && al && fast32_eligible(d, fq) && !(g_variant_off & ((1 << V_FAST) | (1 << 7)))) return V_FAST;
@@ -297,7 +309,7 @@ const char* variant_name(Variant v, const oeh_attn_desc* d, bool fq) {
   if (v == V_NONE) return nullptr;
   const int nt = d->Sk <= 128 ? 8 : (d->Sk <= 256 ? 16 : 32);
   const char* dt = d->dtype == OEH_F16 ? "f16" : (d->dtype == OEH_BF16 ? "bf16" : "f32");
-  if (v == V_FLASH) std::snprintf(buf, sizeof(buf), "flash16/MQ%d/D%d/%s%s", flash_mq(d), d->D, dt, d->clip ? "/clip2p" : "");
+  if (v == V_FLASH) std::snprintf(buf, sizeof(buf), "flash16/MQ%d/D%d/%s%s", flash_mq(d), d->D, dt, fq ? "/fq2p" : (d->clip ? "/clip2p" : ""));
   else if (v == V_FAST) std::snprintf(buf, sizeof(buf), "fast16/NT%d/D%d/%s%s%s", nt, d->D, dt, d->clip ? "/clip" : "", fq ? "/fq" : "");
   else std::snprintf(buf, sizeof(buf), "mfma16/NT%d/D%d/%s%s", nt, d->D, dt, fq ? "/fq" : "");
   return buf;

@@ -56,10 +56,15 @@ constexpr int flash_occupancy() { return D >= 128 ? 1 : (SRC32 ? 2 : 3); }  // f
 // sums of the exponentials - no V product) and a final pass that recomputes the scores against the now final reference,
 // forms p = e / den, clips and multiplies by V.  Rows of any length (the full-row kernel holds at most 512 scores per row in
 // registers and is the faster form up to there: it computes the scores once); masked keys have e = 0 and stay 0 (gamma <= 0).
-template <int D, int IN, int MQ, bool PAD, bool GATE, bool SRC32 = false, bool CLIP = false>
+// TP = 2: the fused INT8 chain on the quantiser grid (oeh_attn_fast.inl, FQ == 1: rel = clamp(rint(s k1)), exp2((rel - rel_max) c2),
+// index of the probability from e * RN(1 / (den scale_p))) in the same two passes: the statistics pass keeps a running maximum
+// and sum per LANE (no cross-lane step inside the loop), the final pass recomputes rel against the row's maximum and feeds the
+// integer-valued probability to the second product; context quantiser and gate in the epilogue.  Rows of any length.
+template <int D, int IN, int MQ, bool PAD, bool GATE, bool SRC32 = false, int TP = 0>
 __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_attn_flash_kernel(const AttnParams P) {
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit matrix-core operands");
-  static_assert(!CLIP || (!PAD && !GATE), "two-pass clipped form: no key padding, no in-kernel gate predictor");
+  constexpr bool CLIP = (TP == 1), FQ2 = (TP == 2);
+  static_assert(TP == 0 || (!PAD && !GATE), "two-pass forms: no key padding, no in-kernel gate predictor");
   static_assert(!SRC32 || (!GATE && IN == IN_F16), "fp32 storage: fp16 operands, fp32 output, no in-kernel gate predictor");
   constexpr bool OUT32 = SRC32;
   static_assert(MQ == 1 || MQ == 2, "one or two query blocks per wave");
@@ -391,9 +396,11 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   // exponent argument; O and l are sums of exp2(t).  The reference is the first tile's row maximum and afterwards
   // moves only when a tile maximum exceeds it by 2^8.  softmax_1's "+1" is exp2(mcneg) (= exp(-reference)).
   float mcneg[MQ];
-  float lsum[MQ], pinv[MQ];             // CLIP: this lane's share of the row sum of exp (statistics pass); 1 / denominator (final pass)
+  float lsum[MQ], pinv[MQ];             // two-pass forms: this lane's share of the row sum of exp (statistics pass); 1 / denominator (final pass)
+  float mrl[MQ];                        // TP = 2: the lane's running maximum of rel, then the row's
+  const float fq_k1 = sc * P.fq_s.rscale, fq_c2 = P.fq_s.c2;
 #pragma unroll
-  for (int j = 0; j < MQ; ++j) { lsum[j] = 0.0f; pinv[j] = 1.0f; }
+  for (int j = 0; j < MQ; ++j) { lsum[j] = 0.0f; pinv[j] = 1.0f; mrl[j] = P.fq_s.lo - 1.0f; }  // (one below every index: never a sentinel in exp2 arguments)
   f4 lacc[MQ];                          // row sums of the ROUNDED P, accumulated by a ones-row MFMA (every register = l)
   f4 o[MQ][DT], ox[SRC32 ? MQ : 1][SRC32 ? DT : 1];  // ox: the V-lo part of the context (SRC32), scaled by 2^-11 at the end
 #pragma unroll
@@ -460,12 +467,21 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
           for (int r = 0; r < 4; ++r) s[j][sub][r] = __builtin_fmaxf(__builtin_fmaf(s[j][sub][r], sc, padv[r]), NEG);
       }
     }
+    if constexpr (MODE >= 3) {  // the score quantiser's integer rel = idx - zp (masked keys get the -1e30 sentinel below)
+#pragma unroll
+      for (int j = J0; j < MQ; ++j)
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[j][sub][r] = __builtin_amdgcn_fmed3f(__builtin_rintf(s[j][sub][r] * fq_k1), P.fq_s.lo, P.fq_s.hi);
+    } else {
 #pragma unroll
     for (int j = J0; j < MQ; ++j)
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[j][sub][r] = __builtin_fmaf(s[j][sub][r], c1, mcneg[j]);
+    }
     // causal / tail mask, classified per 16x16 sub-tile with wave-uniform tests: untouched, all masked, or mixed
 #pragma unroll
     for (int j = J0; j < MQ; ++j) {
@@ -490,6 +506,42 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     u4 pb[MQ][2];
 #pragma unroll
     for (int j = J0; j < MQ; ++j) {
+      if constexpr (MODE == 3) {  // statistics of the grid chain, per lane
+        float mt = max3_raw(s[j][0][0], s[j][0][1], s[j][0][2]);
+        mt = max3_raw(mt, s[j][0][3], s[j][1][0]);
+        mt = max3_raw(mt, s[j][1][1], s[j][1][2]);
+        mt = max3_raw(mt, s[j][1][3], s[j][2][0]);
+        mt = max3_raw(mt, s[j][2][1], s[j][2][2]);
+        mt = max3_raw(mt, s[j][2][3], s[j][3][0]);
+        mt = max3_raw(mt, s[j][3][1], s[j][3][2]);
+        mt = max3_raw(mt, s[j][3][3], mrl[j]);
+        lsum[j] *= __builtin_amdgcn_exp2f((mrl[j] - mt) * fq_c2);
+        mrl[j] = mt;
+        f4 t4 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t4[r] += __builtin_amdgcn_exp2f((s[j][sub][r] - mt) * fq_c2);
+        lsum[j] += (t4[0] + t4[1]) + (t4[2] + t4[3]);
+        continue;
+      }
+      if constexpr (MODE == 4) {  // final pass of the grid chain: exponential against the row maximum, index of the probability
+        const float plo = P.fq_p.lo, phi = P.fq_p.hi;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f((s[j][sub][r] - mrl[j]) * fq_c2);
+            s[j][sub][r] = __builtin_amdgcn_fmed3f(__builtin_rintf(e * pinv[j]), plo, phi);
+          }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f4 a = s[j][2 * u], bb = s[j][2 * u + 1];
+          if constexpr (IN == IN_BF16) pb[j][u] = u4{pack2_bf16(a[0], a[1]), pack2_bf16(a[2], a[3]), pack2_bf16(bb[0], bb[1]), pack2_bf16(bb[2], bb[3])};
+          else pb[j][u] = u4{pack2_f16(a[0], a[1]), pack2_f16(a[2], a[3]), pack2_f16(bb[0], bb[1]), pack2_f16(bb[2], bb[3])};
+        }
+        continue;
+      }
       if constexpr (MODE == 2) {  // final reference: exponentials, p = e / den, clip, pack
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub)
@@ -573,7 +625,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       if (2 < n_kt) issue_next();
     }
     // O^T += V^T P^T and l += 1^T P^T; every V^T fragment is read once and used by all active blocks
-    if constexpr (MODE == 1) return;
+    if constexpr (MODE == 1 || MODE == 3) return;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -603,6 +655,29 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     __builtin_amdgcn_s_setprio(0);
   };
 
+  auto finish_stats = [&]() {  // two-pass forms: the row's denominator from the lanes' shares
+#pragma unroll
+    for (int j = 0; j < MQ; ++j) {
+      if constexpr (FQ2) {
+        float mr = mrl[j];
+        mr = __builtin_fmaxf(mr, __shfl_xor(mr, 16));
+        mr = __builtin_fmaxf(mr, __shfl_xor(mr, 32));
+        float l = lsum[j] * __builtin_amdgcn_exp2f((mrl[j] - mr) * fq_c2);
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float m = mr * P.fq_s.scale;                           // the reference's row maximum, fl(scale * rel_max)
+        if (P.base != 0) l = l + exp_acc(m * -1.0f);                  // softmax_1: + 1*exp(-max)  (softmax_1.py:18-20)
+        mrl[j] = mr;
+        pinv[j] = (1.0f / l) * P.fq_p.rscale;                        // e * this -> the probability's index (before rint)
+      } else {
+        float l = lsum[j];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        if (P.base != 0) l = l + __builtin_amdgcn_exp2f(mcneg[j]);    // softmax_1: + 1*exp(-reference)
+        pinv[j] = 1.0f / l;
+      }
+    }
+  };
   using J0_0 = std::integral_constant<int, 0>;
   using J0_1 = std::integral_constant<int, 1>;
   if constexpr (SRC32) {
@@ -622,24 +697,17 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
         }
       }
     };
-    if constexpr (CLIP) {
-      stream32(std::integral_constant<int, 1>{});
-#pragma unroll
-      for (int j = 0; j < MQ; ++j) {
-        float l = lsum[j];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
-        if (P.base != 0) l = l + __builtin_amdgcn_exp2f(mcneg[j]);  // softmax_1: + 1*exp(-reference)
-        pinv[j] = 1.0f / l;
-      }
+    if constexpr (TP != 0) {
+      stream32(std::integral_constant<int, CLIP ? 1 : 3>{});
+      finish_stats();
       barrier_mem();  // the last stages of the first pass have been read by every wave
       load_regs(0);
-      stream32(std::integral_constant<int, 2>{});
+      stream32(std::integral_constant<int, CLIP ? 2 : 4>{});
     } else {
       stream32(std::integral_constant<int, 0>{});
     }
   } else {
-  using MODE_A = std::integral_constant<int, CLIP ? 1 : 0>;  // the (first) pass over the keys
+  using MODE_A = std::integral_constant<int, CLIP ? 1 : (FQ2 ? 3 : 0)>;  // the (first) pass over the keys
   tile(J0_0{}, std::true_type{}, MODE_A{}, 0, 0);  // every block sees key 0: tile 0 is computed by every wave, for all its blocks
   OEH_STAMP(6);
   int slot_i = 1;
@@ -664,18 +732,11 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     }
     if (i < 8) OEH_STAMP(6 + 3 * i);
   }
-  if constexpr (CLIP) {
+  if constexpr (TP != 0) {
     // ---- denominators (sum over the 4 lanes of a row), then the same stream once more: both slots of the ring are primed
     // again and every tile goes through the loop form (no Q stage this time: the operands are in registers)
-    using MODE_B = std::integral_constant<int, 2>;
-#pragma unroll
-    for (int j = 0; j < MQ; ++j) {
-      float l = lsum[j];
-      l += __shfl_xor(l, 16);
-      l += __shfl_xor(l, 32);
-      if (P.base != 0) l = l + __builtin_amdgcn_exp2f(mcneg[j]);  // softmax_1: + 1*exp(-reference)
-      pinv[j] = 1.0f / l;
-    }
+    using MODE_B = std::integral_constant<int, CLIP ? 2 : 4>;
+    finish_stats();
     barrier_mem();  // every wave has left the last stages of the first pass; nothing is in flight
     kcur = kbase0;
     vcur = vbase0;
@@ -718,9 +779,21 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     float den = lacc[j][0];
     if (P.base != 0) den = den + __builtin_amdgcn_exp2f(mcneg[j]);  // softmax_1: + 1*exp(-reference)  (vutils/softmax_1.py:18-20)
     float rowscale = 1.0f / den;
-    if constexpr (CLIP) rowscale = 1.0f;  // the clipped probabilities went into the product as they are
+    if constexpr (TP != 0) rowscale = 1.0f;  // the clipped probabilities / the probability indices went into the product as they are
     if (P.gate != nullptr && qrow < Sq) rowscale = rowscale * P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
     if constexpr (GATE) rowscale = rowscale * gate_row[j];
+    // TP = 2: [scale of the quantised P] [context quantiser] gate [context quantiser] - the full-row kernel's epilogue chain
+    auto finish = [&](float x) {
+      if constexpr (FQ2) {
+        x = P.fq_p.scale * x;
+        if (P.fq_c.en && P.ctx_before_gate) x = fq_dequant(fq_index(x, P.fq_c), P.fq_c);
+        if (P.gate != nullptr) x = x * rowscale;
+        if (P.fq_c.en && !P.ctx_before_gate) x = fq_dequant(fq_index(x, P.fq_c), P.fq_c);
+        return x;
+      } else {
+        return x * rowscale;
+      }
+    };
     if constexpr (OUT32) {  // fp32 output straight from the accumulators (fp32 storage): 16 B per lane, 64 B per row and instruction
       if (qrow < Sq) {
         float* orow = reinterpret_cast<float*>(P.o) + (long)b * P.os_b + (long)h * P.os_h + (long)qrow * P.os_s + 4 * ge;
@@ -728,7 +801,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
         for (int dt = 0; dt < DT; ++dt) {
           f4 ov;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ov[r] = __builtin_fmaf(ox[j][dt][r], kSplitDown, o[j][dt][r]) * rowscale;
+          for (int r = 0; r < 4; ++r) ov[r] = finish(__builtin_fmaf(ox[j][dt][r], kSplitDown, o[j][dt][r]));
           store_wt16(orow + 16 * dt, u4{f32_bits(ov[0]), f32_bits(ov[1]), f32_bits(ov[2]), f32_bits(ov[3])});
         }
       }
@@ -737,11 +810,11 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     for (int dt = 0; dt < DT; ++dt) {
       u2 w;
       if constexpr (IN == IN_BF16) {
-        w.x = pack2_bf16(o[j][dt][0] * rowscale, o[j][dt][1] * rowscale);
-        w.y = pack2_bf16(o[j][dt][2] * rowscale, o[j][dt][3] * rowscale);
+        w.x = pack2_bf16(finish(o[j][dt][0]), finish(o[j][dt][1]));
+        w.y = pack2_bf16(finish(o[j][dt][2]), finish(o[j][dt][3]));
       } else {
-        w.x = pack2_f16(o[j][dt][0] * rowscale, o[j][dt][1] * rowscale);
-        w.y = pack2_f16(o[j][dt][2] * rowscale, o[j][dt][3] * rowscale);
+        w.x = pack2_f16(finish(o[j][dt][0]), finish(o[j][dt][1]));
+        w.y = pack2_f16(finish(o[j][dt][2]), finish(o[j][dt][3]));
       }
       *reinterpret_cast<u2*>(ebase + (16 * j + ce) * ROWB + ((((2 * dt + (ge >> 1)) ^ (ce & XM)) << 4) | ((ge & 1) << 3))) = w;
     }
@@ -770,14 +843,19 @@ static void launch_flash_d_mq_in(const AttnParams& P, unsigned grid, hipStream_t
   const bool pad = P.pad != nullptr, gate = P.gh != nullptr;
   if (P.src32) {  // fp32 storage read directly, fp32 output; no in-kernel gate predictor on this path
     if constexpr (IN == IN_F16 && !(D == 128 && MQ == 2)) {  // (d = 128 with two blocks per wave: never selected, oeh_api.hip: flash_mq)
-      if (P.clip) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true, true>), dim3(grid), dim3(256), 0, st, P);
+      if (P.fq_s.en) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true, 2>), dim3(grid), dim3(256), 0, st, P);
+      else if (P.clip) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true, 1>), dim3(grid), dim3(256), 0, st, P);
       else if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, true>), dim3(grid), dim3(256), 0, st, P);
       else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true>), dim3(grid), dim3(256), 0, st, P);
     }
     return;
   }
+  if (P.fq_s.en) {  // (oeh_api.hip: flash_fq_eligible - the grid chain: no key padding, no clip, no in-kernel predictor)
+    hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, false, 2>), dim3(grid), dim3(256), 0, st, P);
+    return;
+  }
   if (P.clip) {  // (oeh_api.hip: flash_clip_eligible - no key padding, no in-kernel predictor)
-    hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, false, true>), dim3(grid), dim3(256), 0, st, P);
+    hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, false, 1>), dim3(grid), dim3(256), 0, st, P);
     return;
   }
   if (pad) {

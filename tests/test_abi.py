@@ -79,7 +79,9 @@ def test_variant_selection_host_only():
     assert ops.attn_variant(224, 4, 28, 28, 64, torch.float32) == "small/ST2/D64/f32"
     assert ops.attn_variant(3, 4, 7, 5, 48) == "generic"
     assert ops.attn_variant(1, 1, 8, 100000, 64, torch.float32) == "flash16/MQ1/D64/f32"  # fp32 rows of any length: one-pass kernel
-    assert ops.attn_variant(1, 1, 8, 100000, 64, torch.float32, clip=True) is None
+    assert ops.attn_variant(1, 1, 8, 100000, 64, torch.float32, clip=True) == "flash16/MQ1/D64/f32/clip2p"  # two-pass forms: any length
+    assert ops.attn_variant(1, 1, 8, 100000, 64, torch.float16, fq=True) == "flash16/MQ1/D64/f16/fq2p"
+    assert ops.attn_variant(1, 1, 8, 100000, 64, torch.float32, clip=True, gamma=0.01) is None          # nothing holds a 100000-key row with gamma > 0
 
 
 def test_no_cpu_fallback():

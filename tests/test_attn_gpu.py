@@ -391,6 +391,50 @@ def test_clipped_softmax_on_long_rows_two_pass(ops, mq):
         lib.oeh_debug_set_variant(0, 0)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.float32])
+def test_int8_chain_on_long_rows_two_pass(ops, dt):
+    """The fused INT8 chain (quantized_opt.py:151-210: scores, probabilities and context on 8-bit grids) on rows of more than
+    512 keys: the one-pass kernel's two-pass form of the grid chain instead of the any-shape kernel.  Against the oracle on
+    640 causal keys (rare single steps of the context grid allowed, as for the full-row kernel), and, forced onto 512 keys,
+    against the full-row kernel."""
+    from outeffhop_amd import _lib
+
+    lib = _lib.load()
+    fmin = float(np.finfo(np.float32).min)
+    B, H, S, D = 1, 2, 640, 64
+    q = _rand((B, H, S, D), 4301, dtype=dt)
+    q = (q.float() * D ** -0.5).to(dt)
+    k, v = _rand((B, H, S, D), 4302, dtype=dt), _rand((B, H, S, D), 4303, dtype=dt)
+    gate = torch.rand((B, H, S, 1), generator=torch.Generator().manual_seed(44))
+    common = dict(causal=True, clamp_min=True, gate=gate.numpy(), **SPECS["softmax1"])
+    _, fp = O.attn_core(_np32(q), _np32(k), _np32(v), want=("scores", "probs"), **common)
+    d_s = O.quant_range_to_params(*np.percentile(fp["scores"], (0.001, 99.999)))
+    d_p = O.quant_range_to_params(*np.percentile(fp["probs"], (0.001, 99.999)))
+    ctx_fp = O.attn_core(_np32(q), _np32(k), _np32(v), **{**common, "gate": None})
+    d_c = O.quant_range_to_params(*np.percentile(ctx_fp, (0.001, 99.999)))
+    want = O.attn_core(_np32(q), _np32(k), _np32(v), fq_scores=d_s, fq_probs=d_p, fq_ctx=d_c, ctx_quant_before_gate=True, **common)
+    FQ = ops.FakeQuantSpec.from_delta
+    fq = ops.AttnFakeQuant(FQ(*d_s), FQ(*d_p), FQ(*d_c), ctx_before_gate=True)
+    name = ops.attn_variant(B, H, S, S, D, dt, fq=True, causal=True)
+    assert name.startswith("flash16/") and name.endswith("/fq2p"), name
+    args = dict(softmax=_spec(ops, "softmax1"), causal=True, clamp_min=True, gate=gate.cuda(), mask_min=fmin)
+    got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=fq, **args)
+    step = float(np.float32(d_c[0])) * float(gate.max())
+    err = np.abs(_np32(got) - want)
+    flipped = err > 1e-3 + 1e-3 * np.abs(want)
+    assert flipped.mean() < 4e-3 and err.max() <= 1.05 * step + 2e-3, f"out: {flipped.mean():.2e} elements off, max err {err.max():.3e} (step {step:.3e})"
+    # 512 keys: the full-row kernel's result against the two-pass form forced over the same problem
+    q5, k5, v5, g5 = q[:, :, :512].cuda(), k[:, :, :512].cuda(), v[:, :, :512].cuda(), gate[:, :, :512].cuda()
+    a = ops.attn_fwd(q5, k5, v5, fq=fq, **{**args, "gate": g5})
+    lib.oeh_debug_set_variant(256, 0)
+    try:
+        b = ops.attn_fwd(q5, k5, v5, fq=fq, **{**args, "gate": g5})
+    finally:
+        lib.oeh_debug_set_variant(0, 0)
+    d = (a.float() - b.float()).abs()
+    assert float(d.max()) <= 1.05 * step + 2e-3 and float((d > 1e-3).float().mean()) < 2e-3, (float(d.max()), float((d > 1e-3).float().mean()))
+
+
 def test_snake_block_order_changes_nothing_but_the_placement(ops):
     """The one-pass kernel walks every second row of 256 block ids backwards (CU load balance on causal
     shapes).  Same results bit for bit with the plain order, for grids of whole rows, a ragged last row and a head
