@@ -72,6 +72,34 @@ def build_gate(num_heads: int, head_dim: int, model_dim: int, gate_type, gate_in
     return nn.ModuleList(heads)
 
 
+class GateBookkeeping:
+    """`last_gate_avg_prob` (bert_attention.py:329-331: the per-head mean of the gate probabilities, read by the training scripts'
+    logging) as a LAZY attribute: the forward pass records the gate tensor, the two reductions run when somebody reads the
+    value - not as two extra launches in every layer of every forward.  Assignment (None, a tensor) works as before."""
+
+    @property
+    def last_gate_avg_prob(self):
+        src = self.__dict__.get("_oeh_gate_avg_src")
+        if src is not None:
+            gate, num_heads = src
+            self.__dict__["_oeh_gate_avg"] = gate.mean(dim=0).view(num_heads, -1).mean(dim=1)
+            self.__dict__["_oeh_gate_avg_src"] = None
+        return self.__dict__.get("_oeh_gate_avg")
+
+    @last_gate_avg_prob.setter
+    def last_gate_avg_prob(self, value):
+        self.__dict__["_oeh_gate_avg"] = value
+        self.__dict__["_oeh_gate_avg_src"] = None
+
+
+def _note_gate(mod: nn.Module, gate: torch.Tensor, num_heads: int) -> None:
+    mod.last_gate_all_probs = gate
+    if isinstance(mod, GateBookkeeping):
+        mod.__dict__["_oeh_gate_avg_src"] = (gate, num_heads)
+    else:
+        mod.last_gate_avg_prob = gate.mean(dim=0).view(num_heads, -1).mean(dim=1)
+
+
 class GateState:
     """Evaluates the gate with HIP kernels and keeps the reference's bookkeeping attributes."""
 
@@ -111,9 +139,7 @@ class GateState:
 
     @staticmethod
     def finish_predictor(mod: nn.Module, gp, num_heads: int) -> None:
-        gate = gp.out.unsqueeze(3)
-        mod.last_gate_all_probs = gate
-        mod.last_gate_avg_prob = gate.mean(dim=0).view(num_heads, -1).mean(dim=1)
+        _note_gate(mod, gp.out.unsqueeze(3), num_heads)
 
     @staticmethod
     def evaluate(mod: nn.Module, hidden_states: torch.Tensor, num_heads: int) -> Optional[torch.Tensor]:
@@ -132,8 +158,7 @@ class GateState:
             w1, b1, w2, b2 = GateState.packed_weights(mod)
             gate = ops.gate_fwd(hidden_states, num_heads, w1, b1, w2, b2,
                                 per_head_pool=(gt == AttentionGateType.conditional_per_head), scaling=1.0)
-        mod.last_gate_all_probs = gate
-        mod.last_gate_avg_prob = gate.mean(dim=0).view(num_heads, -1).mean(dim=1)
+        _note_gate(mod, gate, num_heads)
         return gate
 
 

@@ -14,11 +14,11 @@ from typing import Optional, Tuple
 import torch
 from torch import nn
 
-from .attention import AttentionGateType, GateState, attention_core, build_gate, fused_qkv, has_hooks, unfused_core
+from .attention import AttentionGateType, GateBookkeeping, GateState, attention_core, build_gate, fused_qkv, has_hooks, unfused_core
 from .softmax import clipped_softmax, spec_of
 
 
-class BertSelfAttentionWithExtras(nn.Module):
+class BertSelfAttentionWithExtras(GateBookkeeping, nn.Module):
     def __init__(self, config, position_embedding_type=None, softmax_fn=torch.nn.functional.softmax, alpha=None, ssm_eps=None,
                  tau=None, max_seq_length=None, skip_attn=False, attn_gate_type=AttentionGateType.none, attn_gate_init=None,
                  attn_gate_mlp=False, attn_gate_mlp2=False, attn_gate_linear_all_features=False, fine_tuning=False):

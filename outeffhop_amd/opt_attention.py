@@ -16,11 +16,11 @@ from typing import Optional, Tuple
 import torch
 from torch import nn
 
-from .attention import AttentionGateType, GateState, attention_core, build_gate, fused_qkv, has_hooks, unfused_core
+from .attention import AttentionGateType, GateBookkeeping, GateState, attention_core, build_gate, fused_qkv, has_hooks, unfused_core
 from .softmax import clipped_softmax, clipped_softmax1, spec_of
 
 
-class OPTAttentionWithExtras(nn.Module):
+class OPTAttentionWithExtras(GateBookkeeping, nn.Module):
     """Multi-headed attention with the OutEffHop extras (modified softmax, gating)."""
 
     def __init__(self, embed_dim: int, num_heads: int, dropout: float = 0.0, is_decoder: bool = False, bias: bool = True,

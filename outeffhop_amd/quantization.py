@@ -27,7 +27,7 @@ from torch import nn
 
 from . import ops
 from ._lib import OehError as _OehError
-from .attention import AttentionGateType, BaseEnumOptions, GateState, attention_core, classify_causal, unfused_core
+from .attention import AttentionGateType, BaseEnumOptions, GateBookkeeping, GateState, attention_core, classify_causal, unfused_core
 from .ops import AttnFakeQuant, FakeQuantSpec
 from .softmax import spec_of
 
@@ -649,7 +649,7 @@ class QuantizedModel(nn.Module):
 # ------------------------------------------------------------------------------------------------------------
 # the two quantised attention classes
 # ------------------------------------------------------------------------------------------------------------
-class _QuantAttnBase(QuantizedModel):
+class _QuantAttnBase(GateBookkeeping, QuantizedModel):
     def _init_common(self, org_model, quant_params):
         self.attn_scores_act_quantizer = QuantizedActivation(**quant_params)
         self.attn_probs_act_quantizer = QuantizedActivation(**quant_params)

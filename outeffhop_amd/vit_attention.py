@@ -12,11 +12,11 @@ from functools import partial
 import torch
 from torch import nn
 
-from .attention import AttentionGateType, GateState, attention_core, build_gate, has_hooks, unfused_core
+from .attention import AttentionGateType, GateBookkeeping, GateState, attention_core, build_gate, has_hooks, unfused_core
 from .softmax import spec_of
 
 
-class ViTSelfAttentionWithExtras(nn.Module):
+class ViTSelfAttentionWithExtras(GateBookkeeping, nn.Module):
     def __init__(self, dim: int, num_heads: int = 8, qkv_bias: bool = False, qk_norm: bool = False, attn_drop: float = 0.0,
                  proj_drop: float = 0.0, norm_layer: nn.Module = nn.LayerNorm, softmax_fn=torch.nn.functional.softmax, gamma=None,
                  ssm_eps=None, tau=None, skip_attn=False, attn_gate_type=AttentionGateType.none, attn_gate_init=None,
