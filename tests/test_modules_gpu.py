@@ -263,6 +263,38 @@ def test_gated_modules_in_16bit_use_the_in_kernel_predictor(oa):
     _close(o16.last_gate_all_probs, o32.last_gate_all_probs.cpu().numpy(), "opt gate probs", dict(atol=2e-3, rtol=2e-3))
 
 
+def test_module_forwards_can_be_captured_into_a_hip_graph(oa):
+    """The drop-in modules launch on the current stream and never read device memory on the host (the OPT path classifies a
+    mask TENSOR once - here before the capture), so a whole forward - gated BERT with key padding, OPT with a causal mask -
+    can be captured with torch.cuda.graph and replayed on new data in the static input: same bits as the eager forward."""
+    from outeffhop_amd.attention import AttentionGateType as GT
+
+    torch.manual_seed(11)
+    f16min = torch.finfo(torch.float16).min
+    bm = oa.BertSelfAttentionWithExtras(Cfg(), softmax_fn=oa.SOFTMAX_MAPPING["softmax1"], attn_gate_type=GT.conditional_per_token,
+                                        attn_gate_init=0.25, attn_gate_mlp=True).cuda().half().eval()
+    E = Cfg().hidden_size
+    xb = torch.randn(4, 96, E, device="cuda").half()
+    pad = torch.zeros(4, 1, 1, 96, device="cuda", dtype=torch.float16)
+    pad[2, :, :, 60:] = f16min
+    om = oa.OPTAttentionWithExtras(128, 2, is_decoder=True, softmax_fn=oa.SOFTMAX_MAPPING["clippedsoftmax1(-.025:1)"]).cuda().half().eval()
+    xo = torch.randn(2, 160, 128, device="cuda").half()
+    cm = torch.full((160, 160), f16min, device="cuda", dtype=torch.float16).triu(1)[None, None].expand(2, 1, 160, 160).contiguous()
+    with torch.no_grad():
+        for fn, x in ((lambda: bm(xb, attention_mask=pad)[0], xb), (lambda: om(xo, attention_mask=cm)[0], xo)):
+            fn()  # warm-up: weight caches, and the one host-side look at the OPT mask
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = fn()
+            x.copy_(torch.randn_like(x))  # new data in the captured input
+            g.replay()
+            torch.cuda.synchronize()
+            got = out.clone()
+            want = fn()
+            assert torch.equal(got, want)
+
+
 def test_fused_qkv_projection_matches_three_linears(oa):
     """one GEMM with the concatenated q/k/v weights (OPT: the q scaling folded in) feeding strided views to
     the kernel - same module output as three Linears, and the cache follows in-place weight updates."""
