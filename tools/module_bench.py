@@ -112,6 +112,17 @@ def quantised():
             t_mod = timeit(lambda: qm(x, attention_mask=mask), n=50)
             print(f"QuantizedOPT module fp32, INT8 storage core={i8}: {t_mod:8.1f} us  {B * S / t_mod:8.1f} M tokens/s")
         Q.INT8_STORAGE = True
+        try:  # the frozen-range INT8 forward as a captured HIP graph
+            qm(x, attention_mask=mask)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                out_g = qm(x, attention_mask=mask)
+            t_g = timeit(gr.replay, n=50)
+            print(f"QuantizedOPT module fp32, INT8 storage core, captured HIP graph: {t_g:8.1f} us  {B * S / t_g:8.1f} M tokens/s  "
+                  f"(replay equals eager: {torch.equal(out_g[0], qm(x, attention_mask=mask)[0])})")
+        except Exception as e:  # noqa: BLE001
+            print("capture of the quantised module failed:", type(e).__name__, str(e)[:200])
         t_lin = timeit(lambda: qm.q_proj(x), n=50)
         print(f"   parts: one QuantLinear (fp32 GEMM + output fake-quant) {t_lin:.1f} us")
 
