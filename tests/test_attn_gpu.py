@@ -391,8 +391,9 @@ def test_clipped_softmax_on_long_rows_two_pass(ops, mq):
         lib.oeh_debug_set_variant(0, 0)
 
 
+@pytest.mark.parametrize("order", ["opt", "bert"])
 @pytest.mark.parametrize("dt", [torch.float16, torch.float32])
-def test_int8_chain_on_long_rows_two_pass(ops, dt):
+def test_int8_chain_on_long_rows_two_pass(ops, dt, order):
     """The fused INT8 chain (quantized_opt.py:151-210: scores, probabilities and context on 8-bit grids) on rows of more than
     512 keys: the one-pass kernel's two-pass form of the grid chain instead of the any-shape kernel.  Against the oracle on
     640 causal keys (rare single steps of the context grid allowed, as for the full-row kernel), and, forced onto 512 keys,
@@ -403,23 +404,29 @@ def test_int8_chain_on_long_rows_two_pass(ops, dt):
     fmin = float(np.finfo(np.float32).min)
     B, H, S, D = 1, 2, 640, 64
     q = _rand((B, H, S, D), 4301, dtype=dt)
-    q = (q.float() * D ** -0.5).to(dt)
+    opt = order == "opt"   # OPT: q pre-scaled, causal, context quantised before the gate; BERT: scores / 8, no mask, after the gate
+    if opt:
+        q = (q.float() * D ** -0.5).to(dt)
     k, v = _rand((B, H, S, D), 4302, dtype=dt), _rand((B, H, S, D), 4303, dtype=dt)
     gate = torch.rand((B, H, S, 1), generator=torch.Generator().manual_seed(44))
-    common = dict(causal=True, clamp_min=True, gate=gate.numpy(), **SPECS["softmax1"])
+    common = dict(causal=opt, clamp_min=opt, gate=gate.numpy(), **SPECS["softmax1"])
+    if not opt:
+        common.update(scale=8.0, scale_is_divisor=True)
     _, fp = O.attn_core(_np32(q), _np32(k), _np32(v), want=("scores", "probs"), **common)
     d_s = O.quant_range_to_params(*np.percentile(fp["scores"], (0.001, 99.999)))
     d_p = O.quant_range_to_params(*np.percentile(fp["probs"], (0.001, 99.999)))
-    ctx_fp = O.attn_core(_np32(q), _np32(k), _np32(v), **{**common, "gate": None})
+    ctx_fp = O.attn_core(_np32(q), _np32(k), _np32(v), **{**common, "gate": None if opt else gate.numpy()})
     d_c = O.quant_range_to_params(*np.percentile(ctx_fp, (0.001, 99.999)))
-    want = O.attn_core(_np32(q), _np32(k), _np32(v), fq_scores=d_s, fq_probs=d_p, fq_ctx=d_c, ctx_quant_before_gate=True, **common)
+    want = O.attn_core(_np32(q), _np32(k), _np32(v), fq_scores=d_s, fq_probs=d_p, fq_ctx=d_c, ctx_quant_before_gate=opt, **common)
     FQ = ops.FakeQuantSpec.from_delta
-    fq = ops.AttnFakeQuant(FQ(*d_s), FQ(*d_p), FQ(*d_c), ctx_before_gate=True)
-    name = ops.attn_variant(B, H, S, S, D, dt, fq=True, causal=True)
+    fq = ops.AttnFakeQuant(FQ(*d_s), FQ(*d_p), FQ(*d_c), ctx_before_gate=opt)
+    name = ops.attn_variant(B, H, S, S, D, dt, fq=True, causal=opt, **({} if opt else {"scale_div": 8.0}))
     assert name.startswith("flash16/") and name.endswith("/fq2p"), name
-    args = dict(softmax=_spec(ops, "softmax1"), causal=True, clamp_min=True, gate=gate.cuda(), mask_min=fmin)
+    args = dict(softmax=_spec(ops, "softmax1"), causal=opt, clamp_min=opt, gate=gate.cuda(), mask_min=fmin)
+    if not opt:
+        args["scale_div"] = 8.0
     got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=fq, **args)
-    step = float(np.float32(d_c[0])) * float(gate.max())
+    step = float(np.float32(d_c[0])) * (float(gate.max()) if opt else 1.0)
     err = np.abs(_np32(got) - want)
     flipped = err > 1e-3 + 1e-3 * np.abs(want)
     assert flipped.mean() < 4e-3 and err.max() <= 1.05 * step + 2e-3, f"out: {flipped.mean():.2e} elements off, max err {err.max():.3e} (step {step:.3e})"
