@@ -41,4 +41,11 @@ case("fp32 one-pass pad S=512", 16,12,512,64, lambda pad: dict(scale_div=8.0, ke
 case("fp32 one-pass pad S=128", 32,12,128,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad), torch.float32)
 case("INT8 full-row causal S=512", 16,12,512,64, lambda pad: dict(causal=True, clamp_min=True, fq=int8))
 case("INT8 fp32 causal S=512", 16,12,512,64, lambda pad: dict(causal=True, clamp_min=True, fq=int8), torch.float32)
+# the two-pass forms of the one-pass kernel (the key stream restarts behind a barrier) and the small-shape kernel
+clipsm = ops.SoftmaxSpec(1, True, -0.025, 1.1)
+case("two-pass clip causal S=1024", 8,12,1024,64, lambda pad: dict(causal=True, clamp_min=True, softmax=clipsm))
+case("two-pass clip S=640 fp32", 8,12,640,64, lambda pad: dict(causal=True, clamp_min=True, softmax=clipsm), torch.float32)
+case("two-pass INT8 causal S=1024", 8,12,1024,64, lambda pad: dict(causal=True, clamp_min=True, fq=int8))
+case("two-pass INT8 S=640 fp32", 8,12,640,64, lambda pad: dict(causal=True, clamp_min=True, fq=int8), torch.float32)
+case("small-shape 28x28", 224,4,28,64, lambda pad: dict(scale=0.125), torch.float32)
 sys.exit(1 if tot else 0)
