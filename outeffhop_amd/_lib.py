@@ -60,7 +60,7 @@ class oeh_attn_desc(C.Structure):
 
 # every symbol include/oeh.h declares (tests/test_abi.py checks the .so exports exactly these)
 EXPORTS = (
-    "oeh_attn_fwd", "oeh_softmax_rows", "oeh_fake_quant", "oeh_gate_fwd", "oeh_minmax", "oeh_percentile_ema", "oeh_fake_quant_range", "oeh_quantize_heads_i8", "oeh_split_pairs",
+    "oeh_attn_fwd", "oeh_softmax_rows", "oeh_fake_quant", "oeh_gate_fwd", "oeh_minmax", "oeh_percentile_ema", "oeh_fake_quant_range", "oeh_quantize_heads_i8", "oeh_split_pairs", "oeh_split_triples",
     "oeh_abi_version", "oeh_build_info", "oeh_strerror", "oeh_attn_variant",
 )
 
@@ -103,6 +103,8 @@ def load() -> C.CDLL:
     lib.oeh_quantize_heads_i8.restype = C.c_int
     lib.oeh_split_pairs.argtypes = [vp, vp, i64, i32, i64, vp]
     lib.oeh_split_pairs.restype = C.c_int
+    lib.oeh_split_triples.argtypes = [vp, vp, i64, i32, i64, vp]
+    lib.oeh_split_triples.restype = C.c_int
     lib.oeh_abi_version.restype = C.c_int
     lib.oeh_build_info.restype = C.c_char_p
     lib.oeh_strerror.argtypes = [C.c_int]

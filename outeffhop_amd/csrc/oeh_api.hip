@@ -31,6 +31,7 @@ int launch_percentile_ema(const void* x, long n, int in, double q_lo, double q_h
                           hipStream_t st);
 int launch_fake_quant_range(const void* x, void* y, long n, int in, const double* range, float qmax, double eps, hipStream_t st);
 int launch_split_pairs(const float* x, void* out, long rows, int K, long x_sr, hipStream_t st);
+int launch_split_triples(const float* x, void* out, long rows, int K, long x_sr, hipStream_t st);
 int launch_quantize_heads_i8(const void* x, signed char* out, void* y, long B, int S, int H, long x_sb, long x_ss, long y_sb, long y_ss, int in,
                              FqP f, int transpose, float alpha, const float* bias, hipStream_t st);
 }  // namespace oeh
@@ -445,6 +446,13 @@ int oeh_quantize_heads_i8(const void* x, int8_t* out, void* y, int64_t B, int32_
   f.en = 1; f.scale = scale; f.rscale = 1.0f / scale; f.zp = zero_point; f.qmax = 255.0f; f.lo = -zero_point; f.hi = 255.0f - zero_point;
   return oeh::launch_quantize_heads_i8(x, reinterpret_cast<signed char*>(out), y, B, S, H, x_stride[0], x_stride[1], y != nullptr ? y_stride[0] : 0,
                                        y != nullptr ? y_stride[1] : 0, dtype, f, transpose ? 1 : 0, alpha, bias, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oeh_split_triples(const float* x, void* out_f16, int64_t rows, int32_t K, int64_t x_stride_row, void* stream) {
+  if (x == nullptr || out_f16 == nullptr || rows <= 0 || K <= 0) return OEH_EINVAL;
+  if ((K & 7) != 0) return OEH_ENOTSUP;
+  if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out_f16) | (uintptr_t)(x_stride_row * 4)) & 15) != 0) return OEH_EALIGN;
+  return oeh::launch_split_triples(x, out_f16, rows, K, x_stride_row, reinterpret_cast<hipStream_t>(stream));
 }
 
 int oeh_split_pairs(const float* x, void* out_f16, int64_t rows, int32_t K, int64_t x_stride_row, void* stream) {

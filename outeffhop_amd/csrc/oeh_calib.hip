@@ -399,6 +399,53 @@ __global__ __launch_bounds__(256) void split_pairs_kernel(const float* __restric
   }
 }
 
+// The same for GENERAL fp32 weights W = Wh + Wl 2^-11 (not exact in fp16): x W^T + b to ~2^-22 relative as ONE fp16 GEMM over
+// K' = 3K + 8 with   A = [ xh | xh 2^-5 | xl 2^-5 | 1, 2^-5, 0 x6 ]   and   B = [ Wh ; Wl 2^-6 ; Wh 2^-6 ; bh ; bl 2^-6 ; 0 x6 ]
+// (the dropped xl.Wl term is 2^-22 relative; the power-of-two factors are split between the two sides so that neither the
+// scaled activations nor the scaled weights of ordinary magnitude fall into the fp16 subnormals).  This kernel writes A;
+// the weight side is prepared once per Linear on the host side (outeffhop_amd/attention.py: triple_weights).
+__global__ __launch_bounds__(256) void split_triples_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, long rows, int K, long x_sr) {
+  const long chunks = (long)K / 8 + 1;   // the last chunk of a row is the constant tail
+  const long total = rows * chunks;
+  const long ld = 3L * K + 8;
+  fp16_overflow_clamp();
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / chunks;
+    const int ch = (int)(i - r * chunks);
+    unsigned short* orow = out + r * ld;
+    if (ch == K / 8) {  // [1, 2^-5, 0 ...]: the bias pair rides the same GEMM
+      *reinterpret_cast<u4*>(orow + 3L * K) = u4{0x28003C00u, 0u, 0u, 0u};  // fp16 1.0 = 0x3C00, 2^-5 = 0x2800
+      continue;
+    }
+    const int c0 = ch * 8;
+    const f4* p = reinterpret_cast<const f4*>(x + r * x_sr + c0);
+    const f4 a = p[0], b = p[1];
+    u4 hi, lo;
+    split8(a, b, hi, lo);
+    // hi 2^-5 and lo 2^-5 (lo = (x - hi) 2^11): exact scalings of fp16 values unless they leave the normal range
+    const h2* hh = reinterpret_cast<const h2*>(&hi);
+    const h2* ll = reinterpret_cast<const h2*>(&lo);
+    u4 hs, ls;
+    unsigned* hsw = reinterpret_cast<unsigned*>(&hs);
+    unsigned* lsw = reinterpret_cast<unsigned*>(&ls);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      hsw[q] = pack2_f16((float)hh[q][0] * 0.03125f, (float)hh[q][1] * 0.03125f);
+      lsw[q] = pack2_f16((float)ll[q][0] * 0.03125f, (float)ll[q][1] * 0.03125f);
+    }
+    *reinterpret_cast<u4*>(orow + c0) = hi;
+    *reinterpret_cast<u4*>(orow + K + c0) = hs;
+    *reinterpret_cast<u4*>(orow + 2L * K + c0) = ls;
+  }
+}
+
+int launch_split_triples(const float* x, void* out, long rows, int K, long x_sr, hipStream_t st) {
+  const long total = rows * ((long)K / 8 + 1);
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(split_triples_kernel, dim3(blocks), dim3(256), 0, st, x, static_cast<unsigned short*>(out), rows, K, x_sr);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
 int launch_split_pairs(const float* x, void* out, long rows, int K, long x_sr, hipStream_t st) {
   const long total = rows * (K / 8);
   const unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);

@@ -290,6 +290,21 @@ def split_pairs(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def split_triples(x2d: torch.Tensor) -> torch.Tensor:
+    """fp32 activations (rows, K) -> the fp16 matrix [xh | xh 2^-5 | xl 2^-5 | 1, 2^-5, 0 x6] (rows, 3K + 8) of `oeh_split_triples`:
+    against `attention.triple_weights(weight, bias)` ONE fp16 GEMM with fp32 accumulation (torch.mm(..., out_dtype=float32)) is
+    the fp32 Linear - general weights, bias included."""
+    dev = _need_gpu(x2d)
+    if x2d.dim() != 2 or x2d.dtype != torch.float32 or x2d.shape[1] % 8 != 0:
+        raise ValueError("x must be a 2-D fp32 tensor with K % 8 == 0")
+    xc = x2d if x2d.stride(1) == 1 else x2d.contiguous()
+    out = torch.empty((xc.shape[0], 3 * xc.shape[1] + 8), dtype=torch.float16, device=xc.device)
+    with _on_device(dev):
+        rc = _lib.load().oeh_split_triples(_ptr(xc), _ptr(out), xc.shape[0], xc.shape[1], xc.stride(0), _stream())
+    _lib.check(rc, "oeh_split_triples")
+    return out
+
+
 def quantize_heads_i8(x: torch.Tensor, spec: "FakeQuantSpec", H: int, transpose: bool = False, want_values: bool = False,
                       alpha: float = 1.0, bias: Optional[torch.Tensor] = None, want_indices: bool = True):
     """A projection's output quantiser for the INT8-storage core (`oeh_quantize_heads_i8`): x (B,S,H*64) -> centred int8 indices,

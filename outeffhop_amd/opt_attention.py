@@ -16,7 +16,7 @@ from typing import Optional, Tuple
 import torch
 from torch import nn
 
-from .attention import AttentionGateType, GateBookkeeping, GateState, attention_core, build_gate, fused_qkv, has_hooks, unfused_core
+from .attention import AttentionGateType, GateBookkeeping, GateState, attention_core, build_gate, fused_qkv, has_hooks, linear_fp32, unfused_core
 from .softmax import clipped_softmax, clipped_softmax1, spec_of
 
 
@@ -135,4 +135,4 @@ class OPTAttentionWithExtras(GateBookkeeping, nn.Module):
             if gate is not None:
                 ctx = ctx * gate.to(ctx.dtype)
             merged = ctx.transpose(1, 2).reshape(bsz, tgt_len, self.embed_dim)
-        return self.out_proj(merged), weights, new_past
+        return linear_fp32(self.out_proj, merged), weights, new_past  # (fp32 inference: one fp16 GEMM on operand triples)

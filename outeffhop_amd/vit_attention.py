@@ -12,7 +12,7 @@ from functools import partial
 import torch
 from torch import nn
 
-from .attention import AttentionGateType, GateBookkeeping, GateState, attention_core, build_gate, has_hooks, unfused_core
+from .attention import AttentionGateType, GateBookkeeping, GateState, attention_core, build_gate, has_hooks, linear_fp32, unfused_core
 from .softmax import spec_of
 
 
@@ -61,7 +61,7 @@ class ViTSelfAttentionWithExtras(GateBookkeeping, nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, N, C = x.shape
         H, d = self.num_attention_heads, self.attention_head_size
-        q, k, v = self.qkv(x).reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4).unbind(0)  # (B,H,N,d) views, unit d stride
+        q, k, v = linear_fp32(self.qkv, x).reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4).unbind(0)  # (B,H,N,d) views, unit d stride
         q, k = self.q_norm(q), self.k_norm(k)
         fusable = (spec_of(self.softmax_fn) is not None and not (self.training and self.attn_drop.p > 0.0)
                    and not has_hooks(self.attn_scores, self.attn_probs_before_dropout, self.attn_probs_after_dropout))
@@ -82,4 +82,4 @@ class ViTSelfAttentionWithExtras(GateBookkeeping, nn.Module):
             if gate is not None:
                 ctx = ctx * gate.to(ctx.dtype)
             merged = ctx.transpose(1, 2).reshape(B, N, C)
-        return self.proj_drop(self.proj(merged))
+        return self.proj_drop(linear_fp32(self.proj, merged))

@@ -263,6 +263,42 @@ def test_gated_modules_in_16bit_use_the_in_kernel_predictor(oa):
     _close(o16.last_gate_all_probs, o32.last_gate_all_probs.cpu().numpy(), "opt gate probs", dict(atol=2e-3, rtol=2e-3))
 
 
+def test_fp32_linears_as_one_fp16_gemm_on_operand_triples(oa, monkeypatch):
+    """Unquantised fp32 models (the reference's validate precision): q/k/v and the output projection run as ONE fp16 GEMM with
+    fp32 accumulation on operand triples (oeh_split_triples; x = xh + xl 2^-11, W = Wh + Wl 2^-11, bias inside the GEMM) - at
+    least as close to the exact (float64) result as torch's fp32 GEMM, with outliers and tiny values in the input - and the
+    module output is the three-Linears output to fp32 accuracy."""
+    from outeffhop_amd import attention as A, ops
+
+    torch.manual_seed(41)
+    dev = torch.device("cuda:0")
+    lin = torch.nn.Linear(768, 2304).to(dev)
+    x = torch.randn(4, 512, 768, device=dev) * 1.5
+    x[:, ::37, 11] *= 60.0       # hidden-state outliers
+    x[:, 1::53, :40] *= 1e-4     # and values far below one
+    with torch.no_grad():
+        assert A.triple_gemm_ok(x, lin)
+        got = A.linear_fp32(lin, x)
+        exact = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double())
+        e_new = float((got.double() - exact).abs().max())
+        e_lib = float((lin(x).double() - exact).abs().max())
+        assert e_new <= max(1.5 * e_lib, 2e-5), (e_new, e_lib)
+        # the activation matrix: [xh | xh 2^-5 | xl 2^-5 | 1, 2^-5, 0 ...]
+        a = ops.split_triples(x.reshape(-1, 768)).float()
+        assert a.shape[1] == 3 * 768 + 8 and bool((a[:, 2304] == 1.0).all()) and bool((a[:, 2305] == 2.0 ** -5).all()) and bool((a[:, 2306:] == 0).all())
+        rec = a[:, :768] + a[:, 1536:2304] * (32.0 / 2048.0)
+        x2 = x.reshape(-1, 768)
+        assert bool(((rec - x2).abs() <= 2.0 ** -20 * x2.abs() + 2.0 ** -30).all())
+        # whole module: OPT layer, causal mask, against the three separate fp32 Linears
+        m = oa.OPTAttentionWithExtras(256, 4, is_decoder=True, softmax_fn=oa.SOFTMAX_MAPPING["softmax1"]).to(dev).eval()
+        h = torch.randn(3, 96, 256, device=dev)
+        mask = _decoder_mask(3, 96, [96, 90, 96], torch.float32, dev)
+        out = m(h, attention_mask=mask)[0]
+        monkeypatch.setattr(A, "TRIPLE_GEMM", False)
+        ref = m(h, attention_mask=mask)[0]
+    assert float((out - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_module_forwards_can_be_captured_into_a_hip_graph(oa):
     """The drop-in modules launch on the current stream and never read device memory on the host (the OPT path classifies a
     mask TENSOR once - here before the capture), so a whole forward - gated BERT with key padding, OPT with a causal mask -
