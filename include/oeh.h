@@ -140,8 +140,10 @@ typedef struct oeh_attn_desc {
    *   v_stride = (batch, head, d row) - the second product sums over keys;
    *   o has dtype o_dtype (OEH_F16 | OEH_BF16 | OEH_F32).
    * Requires D == 64, Sk <= 512 and a multiple of 16, 16-byte aligned rows, masks none | causal, no clipping, and `fq`
-   * with scores and probabilities enabled (probabilities on a full 8-bit grid, qmax == 255): OEH_ENOTSUP otherwise (run
-   * the fake-quant variants on dequantised values). */
+   * with scores and probabilities enabled (probabilities on a full 8-bit grid, qmax == 255; whole-number zero points, as
+   * uniform_quantizers.py:79 makes them): OEH_ENOTSUP otherwise (run the fake-quant variants on dequantised values).
+   * The test-only index dumps (oeh_fq.dump_idx) are honoured with o_dtype == OEH_F32: scores for every key (the reference
+   * quantises before the mask is added), probabilities, context - same layouts as everywhere. */
   struct { float scale; float zero_point; } q_grid, k_grid, v_grid;
   int32_t o_dtype;
 } oeh_attn_desc;

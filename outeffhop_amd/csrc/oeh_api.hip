@@ -219,7 +219,11 @@ int flash_mq(const oeh_attn_desc* d) {
 bool i8_eligible(const oeh_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const oeh_fq_desc* fq) {
   if (d->dtype != OEH_I8 || d->D != 64 || d->Sk > 512 || (d->Sk & 15) != 0) return false;
   if (fq == nullptr || !fq->scores.enable || !fq->probs.enable || fq->probs.qmax != 255.0f) return false;
-  if (fq->scores.dump_idx != nullptr || fq->probs.dump_idx != nullptr || fq->ctx.dump_idx != nullptr) return false;
+  // the kernel forms the probabilities' indices with the float zero point and centres them with the integer one; the score
+  // index is rounded in the integer domain: both zero points must be whole numbers (they are: uniform_quantizers.py:79 rounds)
+  if (fq->probs.zero_point != std::nearbyint(fq->probs.zero_point) || fq->scores.zero_point != std::nearbyint(fq->scores.zero_point)) return false;
+  const bool dumps = fq->scores.dump_idx != nullptr || fq->probs.dump_idx != nullptr || fq->ctx.dump_idx != nullptr;
+  if (dumps && d->o_dtype != OEH_F32) return false;  // the index dumps (tests) exist in the fp32-output form
   if (d->clip || d->key_pad_mask != nullptr || d->full_mask != nullptr || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
   if (d->scale_div != 0.0f ? !(d->scale_div > 0.0f && std::isfinite(d->scale_div)) : !(d->scale > 0.0f && std::isfinite(d->scale))) return false;
   if (d->causal && (d->Sq > d->Sk || !(d->mask_min < -1.0e4f))) return false;

@@ -388,34 +388,46 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
       // and the probability's index comes from e * RN(1 / (den scale_p)): ~2 ulp in front of rint() instead of 1.5, twelve
       // vector operations per score element instead of twenty-five.  A key the row must not see carries RELMASK: its
       // exponential is exactly 0, as in the reference (a causal row always sees key 0, so the row maximum is a real score).
-      constexpr float RELMASK = -1.0e30f;
-      const float k1 = sc * P.fq_s.rscale, slo = P.fq_s.lo, shi = P.fq_s.hi;
+      // Instruction count is the cost of this phase (the launch is VALU-issue bound): the index comes from ONE fused multiply-add
+      // against M = 1.5 * 2^23 - RN(s k1 + M) = M + rint(s k1), ties to even on the exact product - clamped in that domain
+      // (a product too large for the trick lies beyond the clamp on the same side); rel is carried as M + rel, whose
+      // differences are the exact integer differences the exponent needs; row maximum by v_max3 chains; the causal / tail
+      // test of a diagonal tile is one compare + select per element against a per-lane limit, and only there.
+      constexpr float RELMASK = -1.0e30f, MAGIC = kGridMagic;  // (oeh_common.h: grid_rel_m)
+      const float k1 = sc * P.fq_s.rscale, slo = MAGIC + P.fq_s.lo, shi = MAGIC + P.fq_s.hi;
       const int klime = causal ? min(klimc, Sk - 1) : Sk - 1;                 // last key of this lane's row
+      const int klim_g = klime - 4 * g;                                       // ... relative to the lane's first key of a tile
       float mr = RELMASK;
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         if (kt < n_kt) {
           const bool open_tile = kt < kt_causal && kt < kt_tail;               // no mask touches this 64-key tile (wave-uniform)
+          const int lim = klim_g - 64 * kt;                                    // element (sub, r) is masked when 16 sub + r > lim
 #pragma unroll
           for (int sub = 0; sub < 4; ++sub) {
             const int t = kt * 4 + sub;
-            const int key0 = 16 * t + 4 * g;
             f4 rel;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rel[r] = __builtin_amdgcn_fmed3f(__builtin_rintf(s[t][r] * k1), slo, shi);
+            for (int r = 0; r < 4; ++r) rel[r] = grid_rel_m(s[t][r], k1, slo, shi);
             if (!open_tile) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r)
-                if (key0 + r > klime) rel[r] = RELMASK;
+              for (int r = 0; r < 4; ++r) rel[r] = (16 * sub + r > lim) ? RELMASK : rel[r];
             }
             s[t] = rel;
-            mr = __builtin_fmaxf(__builtin_fmaxf(mr, __builtin_fmaxf(rel[0], rel[1])), __builtin_fmaxf(rel[2], rel[3]));
           }
+          mr = max3_raw(mr, s[kt * 4][0], s[kt * 4][1]);
+          mr = max3_raw(mr, s[kt * 4][2], s[kt * 4][3]);
+          mr = max3_raw(mr, s[kt * 4 + 1][0], s[kt * 4 + 1][1]);
+          mr = max3_raw(mr, s[kt * 4 + 1][2], s[kt * 4 + 1][3]);
+          mr = max3_raw(mr, s[kt * 4 + 2][0], s[kt * 4 + 2][1]);
+          mr = max3_raw(mr, s[kt * 4 + 2][2], s[kt * 4 + 2][3]);
+          mr = max3_raw(mr, s[kt * 4 + 3][0], s[kt * 4 + 3][1]);
+          mr = max3_raw(mr, s[kt * 4 + 3][2], s[kt * 4 + 3][3]);
         }
       }
       mr = __builtin_fmaxf(mr, __shfl_xor(mr, 16));
       mr = __builtin_fmaxf(mr, __shfl_xor(mr, 32));
-      m = mr * P.fq_s.scale;                                                  // the reference's row maximum, fl(scale * rel_max)
+      m = (mr - MAGIC) * P.fq_s.scale;                                        // the reference's row maximum, fl(scale * rel_max)
       const float c2 = P.fq_s.c2;
       f4 sum4 = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -400,7 +400,8 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   float mrl[MQ];                        // TP = 2: the lane's running maximum of rel, then the row's
   const float fq_k1 = sc * P.fq_s.rscale, fq_c2 = P.fq_s.c2;
 #pragma unroll
-  for (int j = 0; j < MQ; ++j) { lsum[j] = 0.0f; pinv[j] = 1.0f; mrl[j] = P.fq_s.lo - 1.0f; }  // (one below every index: never a sentinel in exp2 arguments)
+  for (int j = 0; j < MQ; ++j) { lsum[j] = 0.0f; pinv[j] = 1.0f; mrl[j] = kGridMagic + (P.fq_s.lo - 1.0f); }  // (one below every index: never a sentinel in exp2 arguments; rel is carried as M + rel, oeh_common.h: grid_rel_m)
+  const float fq_slo = kGridMagic + P.fq_s.lo, fq_shi = kGridMagic + P.fq_s.hi;
   f4 lacc[MQ];                          // row sums of the ROUNDED P, accumulated by a ones-row MFMA (every register = l)
   f4 o[MQ][DT], ox[SRC32 ? MQ : 1][SRC32 ? DT : 1];  // ox: the V-lo part of the context (SRC32), scaled by 2^-11 at the end
 #pragma unroll
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[j][sub][r] = __builtin_amdgcn_fmed3f(__builtin_rintf(s[j][sub][r] * fq_k1), P.fq_s.lo, P.fq_s.hi);
+          for (int r = 0; r < 4; ++r) s[j][sub][r] = grid_rel_m(s[j][sub][r], fq_k1, fq_slo, fq_shi);
     } else {
 #pragma unroll
     for (int j = J0; j < MQ; ++j)
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
         float l = lsum[j] * __builtin_amdgcn_exp2f((mrl[j] - mr) * fq_c2);
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
-        const float m = mr * P.fq_s.scale;                           // the reference's row maximum, fl(scale * rel_max)
+        const float m = (mr - kGridMagic) * P.fq_s.scale;            // the reference's row maximum, fl(scale * rel_max)
         if (P.base != 0) l = l + exp_acc(m * -1.0f);                  // softmax_1: + 1*exp(-max)  (softmax_1.py:18-20)
         mrl[j] = mr;
         pinv[j] = (1.0f / l) * P.fq_p.rscale;                        // e * this -> the probability's index (before rint)

@@ -21,6 +21,19 @@
 // that a lane ends up with 16 CONSECUTIVE keys of its query - the k order the V^T operand has).
 // Masks: none | analytic causal.  Everything else of the INT8 configuration (key padding, clipping, other head dims) runs
 // the fake-quant variants of the 16-bit / fp32 kernels on dequantised values.
+//
+// The vector arithmetic per score element is the cost of this kernel (round 2: 21.7 wave-instructions per element, the
+// launch VALU-issue bound), so the chain is written for the instruction count:
+//   * the offset terms ride the matrix cores: the accumulator starts at the query's integer constant ck sum_d a + D cq ck and
+//     a second MFMA of the same K fragment against an operand of cq in every byte adds cq sum_d b - the i32 accumulator IS
+//     sum_d (a + cq)(b + ck), exactly; no multiply-add per element;
+//   * index of the score by ONE fused multiply-add against 1.5 * 2^23: RN(S k1 + M) = M + rint(S k1) (ties to even on the
+//     exact product), clamped in that domain (v_med3 against M + lo, M + hi; a product too large for the trick is beyond the
+//     clamp on the same side) - differences of such values are the exact integer differences the exponent needs;
+//   * row maximum as v_max3 chains; the causal / tail test of a diagonal tile is one compare + select per element against a
+//     per-lane key limit, and only there.
+// DUMP variant (tests): the three index tensors are written out as uint8 (include/oeh.h: oeh_fq.dump_idx), scores for every
+// key (the reference quantises before the mask is added).
 #include "oeh_attn_fast.inl"
 
 namespace oeh {
@@ -29,7 +42,7 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int perm4(int x) { return (0x6C >> ((x & 3) * 2)) & 3; }  // {0,3,2,1}
 
-template <int NT, int OUT>
+template <int NT, int OUT, bool DUMP, bool CQ2>
 __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P) {
   constexpr int D = 64, KT = NT / 4, TILEB = 64 * 64, DT = 4;
   // The K and the V^T phases have eight MFMAs per wave and tile between two barriers: they run at the pace the tiles ARRIVE.
@@ -101,19 +114,24 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
     qf = *reinterpret_cast<const i4*>(qp);
   }
   const int ones = 0x01010101;
-  i4 ones4 = i4{ones, ones, ones, ones};
-  asm volatile("" : "+v"(ones4));  // one register quad for the whole kernel (the compiler would rebuild the constant before every use)
   int asum = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) asum = __builtin_amdgcn_sdot4(qf[j], ones, asum, false);
   asum += __shfl_xor(asum, 16);
   asum += __shfl_xor(asum, 32);
   const int cq = P.i8_cq, ck = P.i8_ck, cv = P.i8_cv, cp = P.i8_cp;   // 128 - zero point of q, k, v and of the probabilities
-  // y = (quotient of the score by the score grid's step) = k1 * (sum a b + cq ksum) + rq
-  const float k1 = P.i8_k1;
-  const float rq = (float)(ck * asum + D * cq * ck) * k1;
+  const float k1 = P.i8_k1;  // (quotient of the score by the score grid's step) = k1 * sum_d (a + cq)(b + ck)
+  // the query's part of the offsets, in the accumulator from the start: ck sum_d a + D cq ck (|.| < 2^23)
+  const int rowq = ck * asum + D * cq * ck;
+  i4 cinit = i4{rowq, rowq, rowq, rowq};
+  asm volatile("" : "+v"(cinit));
+  // ... and the key's part, cq sum_d b, by a second MFMA against cq in every byte (cq = 128, a q grid with zero point 0,
+  // does not fit a signed byte: the CQ2 variant adds 64 twice)
+  const int cqb = ((CQ2 ? 64 : cq) & 0xff) * 0x01010101;
+  i4 cq4 = i4{cqb, cqb, cqb, cqb};
+  asm volatile("" : "+v"(cq4));
 
-  // =========================== phase 1: S^T = K Q^T (i32), kept as integer-valued floats ===========================
+  // =========================== phase 1: S^T = K Q^T (i32, all offsets in), kept as integer-valued floats ===========================
   f4 s[NT];
   const int krow_base = 16 * (c >> 2) + (c & 3);                 // MFMA row c of sub-tile t holds key krow_base + 4 t
   const int kswz = (g ^ perm4(c >> 2)) << 4;                     // perm4((key >> 4) & 3), key >> 4 == c >> 2
@@ -124,55 +142,79 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
       barrier_mem();
       if (kt + PF < T) issue_next();
       const unsigned char* tb = lds + (kt % R) * TILEB;
-      i4 kf[4], acc[4], ks[4];
+      i4 kf[4], acc[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) kf[t] = *reinterpret_cast<const i4*>(tb + (krow_base + 4 * t) * 64 + kswz);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf[t], qf, i4{0, 0, 0, 0}, 0, 0, 0);
-        ks[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf[t], ones4, i4{0, 0, 0, 0}, 0, 0, 0);  // sum_d b of the lane's four keys (always: the
-      }                                                                                         // matrix pipe idles here, a branch per sub-tile costs more)
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf[t], qf, cinit, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf[t], cq4, acc[t], 0, 0, 0);
+      if constexpr (CQ2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf[t], cq4, acc[t], 0, 0, 0);
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         f4 f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) f[r] = (float)(acc[t][r] + __mul24(cq, ks[t][r]));  // |ksum| <= 64 * 128
+        for (int r = 0; r < 4; ++r) f[r] = (float)acc[t][r];
         s[kt * 4 + t] = f;
       }
     }
   }
 
   // =========================== phase 2: the chain on the quantiser grid ===========================
-  // element (kt, t, r) of lane (c, g) is key 64 kt + 16 g + 4 t + r of query q0 + c
+  // element (kt, t, r) of lane (c, g) is key 64 kt + 16 g + 4 t + r of query q0 + c.  rel = idx - zp is carried as
+  // M + rel, M = 1.5 * 2^23 (oeh_common.h: grid_rel_m); a key the row must not see carries a sentinel far below.
+  // (Measured and dropped: the quantiser of a tile right behind its MFMAs inside the K loop, and a tile's probability indices
+  // inside the V loop - vector work for the wave while its next tile is on the way: 22.7 and 26.0 us against 22.5 us for the
+  // separate passes; the second form spills.)
+  constexpr float MAGIC = kGridMagic;
   const int klimc = qrow + off;
-  const int klime = causal ? min(klimc, Sk - 1) : Sk - 1;
+  const int klime = causal ? min(klimc, Sk - 1) : Sk - 1;   // last key this lane's row sees
   const int kt_causal = causal ? (max(0, q0 + off + 1) >> 6) : KT;
   const int kt_tail = Sk >> 6;
-  const float slo = P.fq_s.lo, shi = P.fq_s.hi;
+  const float slo = MAGIC + P.fq_s.lo, shi = MAGIC + P.fq_s.hi;
+  const int klim_g = klime - 16 * g;                        // ... relative to the lane's first key of a tile
   float mr = RELMASK;
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     if (kt < n_kt) {
       const bool open_tile = kt < kt_causal && kt < kt_tail;
+      const int lim = klim_g - 64 * kt;                     // element (t, r) is masked when 4 t + r > lim
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int key0 = 64 * kt + 16 * g + 4 * t;
         f4 rel;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rel[r] = __builtin_amdgcn_fmed3f(__builtin_rintf(__builtin_fmaf(s[kt * 4 + t][r], k1, rq)), slo, shi);
+        for (int r = 0; r < 4; ++r) rel[r] = grid_rel_m(s[kt * 4 + t][r], k1, slo, shi);
+        if constexpr (DUMP) {
+          if (P.fq_s.dump != nullptr && qvalid) {
+            const int zi = (int)P.fq_s.zp - 0x4B400000;
+            const unsigned w = (unsigned)((int)f32_bits(rel[0]) + zi) | ((unsigned)((int)f32_bits(rel[1]) + zi) << 8) |
+                               ((unsigned)((int)f32_bits(rel[2]) + zi) << 16) | ((unsigned)((int)f32_bits(rel[3]) + zi) << 24);
+            const int key0 = 64 * kt + 16 * g + 4 * t;
+            if (key0 < Sk) *reinterpret_cast<unsigned*>(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0) = w;
+          }
+        }
         if (!open_tile) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (key0 + r > klime) rel[r] = RELMASK;
+          for (int r = 0; r < 4; ++r) rel[r] = (4 * t + r > lim) ? RELMASK : rel[r];
         }
         s[kt * 4 + t] = rel;
-        mr = __builtin_fmaxf(__builtin_fmaxf(mr, __builtin_fmaxf(rel[0], rel[1])), __builtin_fmaxf(rel[2], rel[3]));
       }
+      mr = max3_raw(mr, s[kt * 4][0], s[kt * 4][1]);
+      mr = max3_raw(mr, s[kt * 4][2], s[kt * 4][3]);
+      mr = max3_raw(mr, s[kt * 4 + 1][0], s[kt * 4 + 1][1]);
+      mr = max3_raw(mr, s[kt * 4 + 1][2], s[kt * 4 + 1][3]);
+      mr = max3_raw(mr, s[kt * 4 + 2][0], s[kt * 4 + 2][1]);
+      mr = max3_raw(mr, s[kt * 4 + 2][2], s[kt * 4 + 2][3]);
+      mr = max3_raw(mr, s[kt * 4 + 3][0], s[kt * 4 + 3][1]);
+      mr = max3_raw(mr, s[kt * 4 + 3][2], s[kt * 4 + 3][3]);
     }
   }
   mr = __builtin_fmaxf(mr, __shfl_xor(mr, 16));
   mr = __builtin_fmaxf(mr, __shfl_xor(mr, 32));
-  const float m = mr * P.fq_s.scale;
+  const float m = (mr - MAGIC) * P.fq_s.scale;               // the reference's row maximum, fl(scale * rel_max)
   const float c2 = P.fq_s.c2;
   f4 sum4 = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -205,6 +247,10 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
         unsigned w = 0u;
 #pragma unroll
         for (int r = 0; r < 4; ++r) w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(s[kt * 4 + t][r], cinv, pzp), r, w);
+        if constexpr (DUMP) {
+          const int key0 = 64 * kt + 16 * g + 4 * t;
+          if (P.fq_p.dump != nullptr && qvalid && key0 < Sk) *reinterpret_cast<unsigned*>(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0) = w;
+        }
         w ^= 0x80808080u;
         psum = __builtin_amdgcn_sdot4((int)w, ones, psum, false);
         s[kt * 4 + t][0] = bits_f32(w);
@@ -218,6 +264,8 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   i4 o[DT], vs[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) o[dt] = vs[dt] = i4{0, 0, 0, 0};
+  i4 ones4 = i4{ones, ones, ones, ones};
+  asm volatile("" : "+v"(ones4));  // one register quad for the phase (the compiler would rebuild the constant before every use)
   const int vswz = (g ^ perm4(c >> 2)) << 4;                      // perm4((d >> 2) & 3), d = 16 dt + c
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
@@ -254,13 +302,19 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) {
     float ov[4];
+    unsigned cw = 0u;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float x = so * (float)(o[dt][r] + __mul24(cp, vs[dt][r]) + rowc);  // |vsum| <= 512 * 128
-      if (P.fq_c.en && P.ctx_before_gate) x = fq_dequant(fq_index(x, P.fq_c), P.fq_c);
+      float cidx = 0.0f;
+      if (P.fq_c.en && P.ctx_before_gate) { cidx = fq_index(x, P.fq_c); x = fq_dequant(cidx, P.fq_c); }
       if (P.gate != nullptr) x = x * gatev;
-      if (P.fq_c.en && !P.ctx_before_gate) x = fq_dequant(fq_index(x, P.fq_c), P.fq_c);
+      if (P.fq_c.en && !P.ctx_before_gate) { cidx = fq_index(x, P.fq_c); x = fq_dequant(cidx, P.fq_c); }
       ov[r] = x;
+      if constexpr (DUMP) cw |= (unsigned)cidx << (8 * r);
+    }
+    if constexpr (DUMP) {
+      if (P.fq_c.en && P.fq_c.dump != nullptr && qvalid) *reinterpret_cast<unsigned*>(P.fq_c.dump + (((long)b * P.H + h) * P.Sq + qrow) * D + 16 * dt + 4 * g) = cw;
     }
     if constexpr (OUT32) {
       if (q0 + ce < P.Sq)
@@ -289,10 +343,24 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
 template <int NT>
 static int launch_i8_nt(const AttnParams& P, int out, hipStream_t st) {
   const unsigned grid = (unsigned)(P.nQT * P.nBHpad);
+  if (P.fq_s.dump != nullptr || P.fq_p.dump != nullptr || P.fq_c.dump != nullptr) {  // tests: the index tensors written out (fp32 output only)
+    if (out != IN_F32) return -95;
+    if (P.i8_cq == 128) hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F32, true, true>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F32, true, false>), dim3(grid), dim3(256), 0, st, P);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+  }
+  if (P.i8_cq == 128) {  // a q grid with zero point 0 (rare: the projections are two-sided)
+    switch (out) {
+      case IN_F16: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F16, false, true>), dim3(grid), dim3(256), 0, st, P); break;
+      case IN_BF16: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_BF16, false, true>), dim3(grid), dim3(256), 0, st, P); break;
+      default: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F32, false, true>), dim3(grid), dim3(256), 0, st, P); break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+  }
   switch (out) {
-    case IN_F16: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F16>), dim3(grid), dim3(256), 0, st, P); break;
-    case IN_BF16: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_BF16>), dim3(grid), dim3(256), 0, st, P); break;
-    default: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F32>), dim3(grid), dim3(256), 0, st, P); break;
+    case IN_F16: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F16, false, false>), dim3(grid), dim3(256), 0, st, P); break;
+    case IN_BF16: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_BF16, false, false>), dim3(grid), dim3(256), 0, st, P); break;
+    default: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F32, false, false>), dim3(grid), dim3(256), 0, st, P); break;
   }
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, (occupancy_hint<NT, D, IN>())) void oeh_attn_m
   // index dumps and must give the same bits): scores and probabilities quantised, multiplicative scale, masks none / causal.
   if constexpr (FQ == 1) {
     constexpr float RELMASK = -1.0e30f;
-    const float k1 = P.scale * P.fq_s.rscale, slo = P.fq_s.lo, shi = P.fq_s.hi;
+    const float k1 = P.scale * P.fq_s.rscale, slo = kGridMagic + P.fq_s.lo, shi = kGridMagic + P.fq_s.hi;
     const int klime = P.causal ? min(klim, P.Sk - 1) : P.Sk - 1;
     float mr = RELMASK;
 #pragma unroll
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, (occupancy_hint<NT, D, IN>())) void oeh_attn_m
         const int key0 = 16 * t + 4 * g;
         f4 rel;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rel[r] = __builtin_amdgcn_fmed3f(__builtin_rintf(s[t][r] * k1), slo, shi);
+        for (int r = 0; r < 4; ++r) rel[r] = grid_rel_m(s[t][r], k1, slo, shi) - kGridMagic;  // (oeh_common.h; here as the plain integer)
         if (dump_s && qvalid) dump4(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + key0, fq_dump_word(rel, P.fq_s), P.Sk - key0);
         if (t >= t_causal || t >= t_tail) {
 #pragma unroll

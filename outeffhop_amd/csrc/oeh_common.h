@@ -53,6 +53,15 @@ __device__ __forceinline__ float fq_rel(float x, const FqP& f) { return __builti
 // kernel: 55 vs 39 us on the INT8 OPT shape, 25.5 vs 13.9 us on BERT-base.  Packed fp32 buys no throughput on this chip
 // anyway: tools/pk_bench.hip times 16 scalar VALU operations at 37.7 cycles per wave and the same arithmetic as 8 packed
 // ones at 37.1 - a wave64 fp32 operation issues in ~2.3 cycles, a packed one in twice that.)
+// The grid chain's score index (oeh_attn_fast.inl FQ == 1, oeh_attn_i8.hip, the two-pass one-pass form, and the general kernel
+// that serves their index dumps - one formula, so that all of them give the same bits): idx - zp = clamp(rint(s k1)) by ONE
+// fused multiply-add against M = 1.5 * 2^23.  RN(s k1 + M) = M + (s k1 rounded to an integer, ties to even, from the EXACT
+// product) while |s k1| < 2^22; beyond that the sum is still on the same side of the clamp bounds M + lo, M + hi.  The result
+// is M + rel: exactly representable, differences of two such values are the exact integer differences.
+constexpr float kGridMagic = 12582912.0f;
+__device__ __forceinline__ float grid_rel_m(float s, float k1, float lo_m, float hi_m) {
+  return __builtin_amdgcn_fmed3f(__builtin_fmaf(s, k1, kGridMagic), lo_m, hi_m);
+}
 __device__ __forceinline__ f4 fq_rel4(f4 x, const FqP& f) { return f4{fq_rel(x[0], f), fq_rel(x[1], f), fq_rel(x[2], f), fq_rel(x[3], f)}; }
 __device__ __forceinline__ float fq_index(float x, const FqP& f) { return fq_rel(x, f) + f.zp; }
 __device__ __forceinline__ float fq_dequant(float idx, const FqP& f) { return f.scale * (idx - f.zp); }
