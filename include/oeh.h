@@ -216,6 +216,8 @@ int oeh_fake_quant_range(const void* x, void* y, int64_t n, int32_t dtype, const
  *   bias (optional, fp32 device array of H*64, may be NULL): x is a raw GEMM accumulator and the value that is quantised is
  *   alpha * x + bias[column] - the projection's weight scale and bias folded into this pass (oeh_split_pairs' GEMM);
  *   bias == NULL: x is quantised as it is (alpha ignored).
+ * x, out, y and bias must be 16-byte aligned, and so must the row and batch strides of x and y in bytes (16-byte vector
+ * accesses): OEH_EALIGN otherwise.
  * One launch per projection instead of fake-quant + index conversion + transpose copy. */
 int oeh_quantize_heads_i8(const void* x, int8_t* out, void* y, int64_t B, int32_t S, int32_t H, const int64_t x_stride[2],
                           const int64_t y_stride[2], int32_t dtype, float scale, float zero_point, int32_t transpose, float alpha,

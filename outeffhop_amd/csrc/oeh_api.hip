@@ -227,6 +227,7 @@ bool i8_eligible(const oeh_attn_desc* d, const void* q, const void* k, const voi
   if (d->clip || d->key_pad_mask != nullptr || d->full_mask != nullptr || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
   if (d->scale_div != 0.0f ? !(d->scale_div > 0.0f && std::isfinite(d->scale_div)) : !(d->scale > 0.0f && std::isfinite(d->scale))) return false;
   if (d->causal && (d->Sq > d->Sk || !(d->mask_min < -1.0e4f))) return false;
+  if (d->k_stride[2] <= 0 || d->k_stride[2] >= (1 << 24) || d->v_stride[2] <= 0 || d->v_stride[2] >= (1 << 24)) return false;  // 32-bit lane offsets inside a tile
   if (q != nullptr) {
     const int ob = elem_bytes(d->o_dtype);
     if (!aligned16(q, d->q_stride, 1) || !aligned16(k, d->k_stride, 1) || !aligned16(v, d->v_stride, 1) || !aligned16(o, d->o_stride, ob)) return false;
@@ -444,6 +445,10 @@ int oeh_quantize_heads_i8(const void* x, int8_t* out, void* y, int64_t B, int32_
   if (!transpose && y != nullptr && y_stride[0] != (int64_t)S * y_stride[1]) return OEH_ENOTSUP;
   if (transpose && (S & 15) != 0) return OEH_ENOTSUP;
   if ((reinterpret_cast<uintptr_t>(out) & 15) != 0) return OEH_EALIGN;
+  {  // 16-byte vector loads of the input rows and of the bias
+    const int eb = elem_bytes(dtype);
+    if (((reinterpret_cast<uintptr_t>(x) | (uintptr_t)(x_stride[0] * eb) | (uintptr_t)(x_stride[1] * eb) | reinterpret_cast<uintptr_t>(bias)) & 15) != 0) return OEH_EALIGN;
+  }
   if (y != nullptr && ((reinterpret_cast<uintptr_t>(y) | (uintptr_t)(y_stride[0] * elem_bytes(dtype)) | (uintptr_t)(y_stride[1] * elem_bytes(dtype))) & 15) != 0) return OEH_EALIGN;  // 16-byte value stores
   FqP f;
   std::memset(&f, 0, sizeof(f));

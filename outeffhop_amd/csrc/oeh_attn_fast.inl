@@ -415,14 +415,11 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
             }
             s[t] = rel;
           }
-          mr = max3_raw(mr, s[kt * 4][0], s[kt * 4][1]);
-          mr = max3_raw(mr, s[kt * 4][2], s[kt * 4][3]);
-          mr = max3_raw(mr, s[kt * 4 + 1][0], s[kt * 4 + 1][1]);
-          mr = max3_raw(mr, s[kt * 4 + 1][2], s[kt * 4 + 1][3]);
-          mr = max3_raw(mr, s[kt * 4 + 2][0], s[kt * 4 + 2][1]);
-          mr = max3_raw(mr, s[kt * 4 + 2][2], s[kt * 4 + 2][3]);
-          mr = max3_raw(mr, s[kt * 4 + 3][0], s[kt * 4 + 3][1]);
-          mr = max3_raw(mr, s[kt * 4 + 3][2], s[kt * 4 + 3][3]);
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub) {  // (v_max3 from the plain builtins: the operands are v_med3 / select results, known canonical)
+            mr = __builtin_fmaxf(__builtin_fmaxf(mr, s[kt * 4 + sub][0]), s[kt * 4 + sub][1]);
+            mr = __builtin_fmaxf(__builtin_fmaxf(mr, s[kt * 4 + sub][2]), s[kt * 4 + sub][3]);
+          }
         }
       }
       mr = __builtin_fmaxf(mr, __shfl_xor(mr, 16));
@@ -764,15 +761,9 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
       for (int r = 0; r < 4; ++r) {
         float x = o[dt][r];
         x = P.fq_p.scale * x;
-        if (P.fq_c.en && P.ctx_before_gate) {
-          const float idx = fq_index(x, P.fq_c);
-          x = fq_dequant(idx, P.fq_c);
-        }
+        if (P.fq_c.en && P.ctx_before_gate) x = P.fq_c.scale * fq_rel(x, P.fq_c);   // scale * (idx - zp): fq_dequant(fq_index()) without the + zp - zp
         if (P.gate != nullptr) x = x * rowscale;
-        if (P.fq_c.en && !P.ctx_before_gate) {
-          const float idx = fq_index(x, P.fq_c);
-          x = fq_dequant(idx, P.fq_c);
-        }
+        if (P.fq_c.en && !P.ctx_before_gate) x = P.fq_c.scale * fq_rel(x, P.fq_c);
         ov[r] = x;
       }
 

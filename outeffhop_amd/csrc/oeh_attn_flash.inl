@@ -787,9 +787,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     auto finish = [&](float x) {
       if constexpr (FQ2) {
         x = P.fq_p.scale * x;
-        if (P.fq_c.en && P.ctx_before_gate) x = fq_dequant(fq_index(x, P.fq_c), P.fq_c);
+        if (P.fq_c.en && P.ctx_before_gate) x = P.fq_c.scale * fq_rel(x, P.fq_c);
         if (P.gate != nullptr) x = x * rowscale;
-        if (P.fq_c.en && !P.ctx_before_gate) x = fq_dequant(fq_index(x, P.fq_c), P.fq_c);
+        if (P.fq_c.en && !P.ctx_before_gate) x = P.fq_c.scale * fq_rel(x, P.fq_c);
         return x;
       } else {
         return x * rowscale;

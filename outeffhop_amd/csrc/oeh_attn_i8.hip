@@ -80,20 +80,42 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   const signed char* vbase = reinterpret_cast<const signed char*>(P.v) + (long)b * P.vs_b + (long)h * P.vs_h;
   const int prow = wave * 16 + (lane >> 2), pch = lane & 3;
   const unsigned lds_base = lds_offset(lds);
+  // scalar base + constant per-lane byte offset (oeh_common.h: glds16_s): the bases advance by one tile per request, nothing
+  // is recomputed per lane (the first version rebuilt a clamped 64-bit address per request: ~2 vector instructions per score
+  // element of a kernel that is bound by them).  Only a ragged last tile (Sk not a multiple of 64) adjusts the lane offsets:
+  // K rows past Sk are redirected to row Sk - 1, V^T chunks past Sk to the last one (finite data, probability 0).
+  const unsigned koff = (unsigned)(prow * (int)P.ks_s + (pch ^ perm4(prow >> 4)) * 16);
+  const unsigned voff = (unsigned)(prow * (int)P.vs_s + (pch ^ perm4(prow >> 2)) * 16);
+  const signed char* kcur = kbase;
+  const signed char* vcur = vbase;
+  const int kstep = 64 * (int)P.ks_s;
   const int last_chunk = (Sk >> 4) - 1;  // (Sk is a multiple of 16: host)
-  int nx = 0;
+  int nx = 0, nx_slot = 0;
   auto issue_next = [&]() {
     const bool isv = nx >= n_kt;
     const int t = isv ? nx - n_kt : nx;
-    const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(((isv ? R : 0) + t % R) * TILEB + wave * 1024));
-    const signed char* src;
-    if (isv) {  // V^T: row = d, chunk = 16 keys; chunks past Sk are redirected to the last one (finite data, probability 0)
-      src = vbase + (long)prow * P.vs_s + (long)min(4 * t + (pch ^ perm4(prow >> 2)), last_chunk) * 16;
-    } else {    // K: row = key, chunk = 16 of the 64 head dims; rows past Sk are redirected to row Sk - 1
-      src = kbase + (long)min(64 * t + prow, Sk - 1) * P.ks_s + (pch ^ perm4(prow >> 4)) * 16;
+    const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(((isv ? R : 0) + nx_slot) * TILEB + wave * 1024));
+    const bool tail = 64 * t + 64 > Sk;  // wave-uniform
+    if (isv) {
+      unsigned vo = voff;
+      if (tail) {
+        const int over = 4 * t + (pch ^ perm4(prow >> 2)) - last_chunk;
+        if (over > 0) vo -= 16u * (unsigned)over;
+      }
+      glds16_s(vcur, vo, slot);
+      vcur += 64;
+    } else {
+      unsigned ko = koff;
+      if (tail) {
+        const int over = 64 * t + prow - (Sk - 1);
+        if (over > 0) ko -= (unsigned)(over * (int)P.ks_s);
+      }
+      glds16_s(kcur, ko, slot);
+      kcur += kstep;
     }
-    glds16(src, slot);
     ++nx;
+    nx_slot = (nx_slot == R - 1) ? 0 : nx_slot + 1;
+    if (nx == n_kt) nx_slot = 0;  // the V^T ring starts at its slot 0
   };
 #pragma unroll
   for (int p = 0; p < PF; ++p)
@@ -202,14 +224,11 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
         }
         s[kt * 4 + t] = rel;
       }
-      mr = max3_raw(mr, s[kt * 4][0], s[kt * 4][1]);
-      mr = max3_raw(mr, s[kt * 4][2], s[kt * 4][3]);
-      mr = max3_raw(mr, s[kt * 4 + 1][0], s[kt * 4 + 1][1]);
-      mr = max3_raw(mr, s[kt * 4 + 1][2], s[kt * 4 + 1][3]);
-      mr = max3_raw(mr, s[kt * 4 + 2][0], s[kt * 4 + 2][1]);
-      mr = max3_raw(mr, s[kt * 4 + 2][2], s[kt * 4 + 2][3]);
-      mr = max3_raw(mr, s[kt * 4 + 3][0], s[kt * 4 + 3][1]);
-      mr = max3_raw(mr, s[kt * 4 + 3][2], s[kt * 4 + 3][3]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {  // (v_max3 from the plain builtins: the operands are v_med3 / select results, known canonical - no
+        mr = __builtin_fmaxf(__builtin_fmaxf(mr, s[kt * 4 + t][0]), s[kt * 4 + t][1]);  // canonicalising v_max, and none of the
+        mr = __builtin_fmaxf(__builtin_fmaxf(mr, s[kt * 4 + t][2]), s[kt * 4 + t][3]);  // s_nop the compiler puts behind inline asm)
+      }
     }
   }
   mr = __builtin_fmaxf(mr, __shfl_xor(mr, 16));
@@ -306,12 +325,12 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float x = so * (float)(o[dt][r] + __mul24(cp, vs[dt][r]) + rowc);  // |vsum| <= 512 * 128
-      float cidx = 0.0f;
-      if (P.fq_c.en && P.ctx_before_gate) { cidx = fq_index(x, P.fq_c); x = fq_dequant(cidx, P.fq_c); }
+      float crel = 0.0f;  // idx - zp of the context quantiser: the dequantised value is scale * (idx - zp)
+      if (P.fq_c.en && P.ctx_before_gate) { crel = fq_rel(x, P.fq_c); x = P.fq_c.scale * crel; }
       if (P.gate != nullptr) x = x * gatev;
-      if (P.fq_c.en && !P.ctx_before_gate) { cidx = fq_index(x, P.fq_c); x = fq_dequant(cidx, P.fq_c); }
+      if (P.fq_c.en && !P.ctx_before_gate) { crel = fq_rel(x, P.fq_c); x = P.fq_c.scale * crel; }
       ov[r] = x;
-      if constexpr (DUMP) cw |= (unsigned)cidx << (8 * r);
+      if constexpr (DUMP) cw |= (unsigned)(crel + P.fq_c.zp) << (8 * r);
     }
     if constexpr (DUMP) {
       if (P.fq_c.en && P.fq_c.dump != nullptr && qvalid) *reinterpret_cast<unsigned*>(P.fq_c.dump + (((long)b * P.H + h) * P.Sq + qrow) * D + 16 * dt + 4 * g) = cw;

@@ -337,7 +337,8 @@ def quantize_heads_i8(x: torch.Tensor, spec: "FakeQuantSpec", H: int, transpose:
 
 def attn_fwd_i8(q: torch.Tensor, k: torch.Tensor, v_t: torch.Tensor, grids, *, fq: AttnFakeQuant, out_dtype=torch.float16,
                 softmax: SoftmaxSpec = SoftmaxSpec(), scale: float = 1.0, scale_div: float = 0.0, causal: bool = False, clamp_min: bool = False,
-                mask_min: Optional[float] = None, gate: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                mask_min: Optional[float] = None, gate: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                _prepared: Optional[list] = None) -> torch.Tensor:
     """The INT8 configuration on the integer matrix cores (`include/oeh.h`: dtype OEH_I8): q, k logical (B,H,S,64) int8 views of
     centred indices (`centre_indices`), v_t the TRANSPOSED values, a (B,H,64,Sk) int8 view with contiguous keys; `grids` =
     (q, k, v) QuantGrid; `fq` with scores and probabilities (8-bit) [and context].  Returns the logical (B,H,Sq,64) result in
@@ -380,6 +381,9 @@ def attn_fwd_i8(q: torch.Tensor, k: torch.Tensor, v_t: torch.Tensor, grids, *, f
     _fill_fq(fqd.probs, fq.probs)
     _fill_fq(fqd.ctx, fq.ctx)
     fqd.ctx_quant_before_gate = int(bool(fq.ctx_before_gate))
+    if _prepared is not None:  # hand back the prebuilt C call instead of launching (bench / A-B loops)
+        _prepared.extend([_lib.load().oeh_attn_fwd, (C.byref(d), _ptr(q), _ptr(k), _ptr(v_t), _ptr(out), C.byref(fqd)), (d, fqd, keep, q, k, v_t, out)])
+        return out
     with _on_device(dev):
         rc = _lib.load().oeh_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v_t), _ptr(out), C.byref(fqd), _stream())
     _lib.check(rc, "oeh_attn_fwd (INT8 storage)")
@@ -414,9 +418,12 @@ class PreparedAttn:
     """A fully built `oeh_attn_fwd` call (descriptor + pointers) for launch loops where Python argument
     marshalling would otherwise dominate: `p = PreparedAttn(q, k, v, causal=True, ...); p(); p.out`."""
 
-    def __init__(self, q, k, v, **kw):
+    def __init__(self, q, k, v, i8_grids=None, **kw):
         box = []
-        self.out = attn_fwd(q, k, v, _prepared=box, **kw)
+        if i8_grids is not None:  # INT8 storage: q, k int8 views, v transposed (attn_fwd_i8)
+            self.out = attn_fwd_i8(q, k, v, i8_grids, _prepared=box, **kw)
+        else:
+            self.out = attn_fwd(q, k, v, _prepared=box, **kw)
         self._fn, self._args, self._keep = box
 
     def __call__(self, stream: Optional[C.c_void_p] = None) -> None:
@@ -482,7 +489,8 @@ def fake_quant(x: torch.Tensor, spec: FakeQuantSpec, want_idx: bool = False):
     return (y, idx) if want_idx else y
 
 
-_calib_work = {}  # device index -> scratch buffer of the on-device percentile selection
+_calib_work = {}  # (device index, stream) -> scratch buffer of the on-device percentile selection (two calibrations on different
+                   # streams of one GPU must not share histograms: ADVICE r2)
 
 
 def percentile_ema(x: torch.Tensor, q_lo: float, q_hi: float, state: torch.Tensor, momentum: float = 0.9, first: bool = False) -> torch.Tensor:
@@ -494,9 +502,11 @@ def percentile_ema(x: torch.Tensor, q_lo: float, q_hi: float, state: torch.Tenso
     if state.dtype != torch.float64 or state.numel() != 2 or not state.is_contiguous():
         raise ValueError("state must be a contiguous float64 tensor of 2 elements")
     xc = x.detach().contiguous()
-    work = _calib_work.get(dev.index)
+    with _on_device(dev):
+        key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    work = _calib_work.get(key)
     if work is None:
-        work = _calib_work[dev.index] = torch.empty(_lib.CALIB_WORK_BYTES // 8, dtype=torch.int64, device=dev)
+        work = _calib_work[key] = torch.empty(_lib.CALIB_WORK_BYTES // 8, dtype=torch.int64, device=dev)
     with _on_device(dev):
         rc = _lib.load().oeh_percentile_ema(_ptr(xc), xc.numel(), _DT[x.dtype], float(q_lo), float(q_hi), float(momentum), int(bool(first)),
                                             _ptr(state), _ptr(work), _stream())

@@ -683,6 +683,14 @@ def gen_sparse_acts():
     x[0, 0, 1, :3] = 50.0     # a three-way tie far above the rest
     arrays = {"x": _np(x), "entmax15": _np(entmax15(x, dim=-1)), "entmax15_dim1": _np(entmax15(x, dim=1)),
               "sparsemax": _np(Sparsemax(dim=-1)(x)), "bisect_1p3": _np(entmax_bisect(x, 1.3)), "bisect_2p0": _np(entmax_bisect(x, 2.0))}
+    # gradients of the bisection form through the reference's own autograd Function: input and alpha
+    xg = (torch.randn(2, 3, 5, 11, generator=g) * 1.7).requires_grad_(True)
+    ag = EntmaxAlpha()
+    with torch.no_grad():
+        ag.alpha.fill_(-0.21)
+    w = torch.randn(2, 3, 5, 11, generator=g)
+    (ag(xg) * w).sum().backward()
+    arrays.update(grad_x=_np(xg.detach()), grad_w=_np(w), grad_alpha_param=_np(ag.alpha.detach()), grad_dx=_np(xg.grad), grad_dalpha=_np(ag.alpha.grad))
     ea = EntmaxAlpha().eval()
     with torch.no_grad():
         ea.alpha.fill_(0.37)

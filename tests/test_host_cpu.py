@@ -283,3 +283,45 @@ def test_sparse_activations_match_the_reference():
         oa.Association(mode="nope")
     sm = oa.Softmax_1(dim=-1)
     assert sm.extra_repr() == "dim=-1" and oa.Hopfield(32, 2).inner_attention.mode == "entmax"
+    # the bisection form trains through the closed-form Jacobian (input AND the learnable alpha), as the reference's
+    # EntmaxBisectFunction does - captured gradients of sum(w * EntmaxAlpha(x)); differentiating the bisection itself is wrong
+    xg = torch.from_numpy(g["grad_x"]).clone().requires_grad_(True)
+    eg = SA.EntmaxAlpha()
+    with torch.no_grad():
+        eg.alpha.copy_(torch.from_numpy(g["grad_alpha_param"]))
+    (eg(xg) * torch.from_numpy(g["grad_w"])).sum().backward()
+    np.testing.assert_allclose(xg.grad.numpy(), g["grad_dx"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(eg.alpha.grad.numpy(), g["grad_dalpha"], rtol=2e-4, atol=2e-6)
+    # ... and against central differences in float64 (an independent check of the closed forms)
+    x64 = (torch.from_numpy(g["grad_x"])[0, 0, :2].double()).requires_grad_(True)
+    a64 = torch.tensor([[1.37]], dtype=torch.float64, requires_grad=True)
+    w64 = torch.from_numpy(g["grad_w"])[0, 0, :2].double()
+    (SA.entmax_bisect(x64, a64, n_iter=80) * w64).sum().backward()
+    f = lambda xx, aa: float((SA._entmax_bisect_fwd(xx, aa, n_iter=80) * w64).sum())  # noqa: E731
+    h = 1e-6
+    num_a = (f(x64.detach(), a64.detach() + h) - f(x64.detach(), a64.detach() - h)) / (2 * h)
+    assert abs(num_a - float(a64.grad.sum())) <= 1e-5 * max(1.0, abs(num_a))
+    e = torch.zeros_like(x64.detach())
+    e[1, 4] = h
+    num_x = (f(x64.detach() + e, a64.detach()) - f(x64.detach() - e, a64.detach())) / (2 * h)
+    assert abs(num_x - float(x64.grad[1, 4])) <= 1e-5 * max(1.0, abs(num_x))
+
+
+def test_percentile_pair_is_numpys_tuple_form():
+    """`np.percentile(float32 data, (lo, hi))` - q as a tuple, as `range_estimators.py:92` calls it - returns
+    float64 values whose interpolation forms b - a in the DATA dtype (numpy 2.2.6; a scalar q returns float32 instead).  The host
+    twin of the device percentile (`quantization.percentile_pair`, same arithmetic as oeh_calib.hip: np_lerp) must equal it
+    bit for bit: small and large tensors, both tails, ties."""
+    from outeffhop_amd.quantization import percentile_pair
+
+    rng = np.random.default_rng(7)
+    for t in range(300):
+        n = int(rng.integers(2, 60)) if t % 3 else int(rng.integers(2000, 60000))
+        x = (rng.standard_normal(n) * rng.choice([1e-3, 1.0, 50.0])).astype(np.float32)
+        if t % 7 == 0:
+            x[: n // 2] = x[0]  # ties
+        P = float(rng.choice([99.999, 99.9, 99.0]))
+        want = np.percentile(x, (100 - P, P))
+        assert want.dtype == np.float64
+        got = percentile_pair(torch.from_numpy(x), 100 - P, P)
+        assert float(got[0]) == float(want[0]) and float(got[1]) == float(want[1]), (t, n, P, got, want)

@@ -21,7 +21,7 @@ from outeffhop_amd import _lib, ops
 
 
 def run(spec):
-    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, reps=1, graph=0, gmlp=-1, ab="")
+    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, reps=1, graph=0, gmlp=-1, ab="", i8=0)
     for item in spec.split(","):
         k, v = item.split("=")
         kv[k] = v if k in ("dtype", "ab") else int(v)
@@ -65,7 +65,19 @@ def run(spec):
     out = torch.empty(B, S, H, D, dtype=dt, device="cuda").permute(0, 2, 1, 3)
     kw = dict(softmax=spec_sm, causal=bool(kv["causal"]), clamp_min=bool(kv["causal"] or kv["full"]), key_pad_mask=pad, full_mask=full,
               gate=gate, fq=fq, mask_min=fmin, out=out, gate_mlp=gmlp)
-    calls = [ops.PreparedAttn(*st, **kw) for st in sets]
+    if kv["i8"]:  # INT8 storage on the integer matrix cores (dtype = the output's): random indices, v transposed
+        FQ = ops.FakeQuantSpec
+        kw = dict(softmax=spec_sm, causal=bool(kv["causal"]), clamp_min=bool(kv["causal"]), gate=gate, mask_min=fmin, out_dtype=dt, scale=D ** -0.5,
+                  fq=ops.AttnFakeQuant(FQ(0.08, 128.0), FQ(1.0 / 255.0, 0.0), FQ(0.02, 128.0)))
+        grids = (ops.QuantGrid(0.03, 131.0), ops.QuantGrid(0.03, 120.0), ops.QuantGrid(0.03, 128.0))
+        sets = []
+        for _ in range(nsets):
+            qi, ki, vi = (torch.randint(0, 256, (B, S, H * D), device="cuda", generator=g, dtype=torch.int32).to(torch.uint8) for _ in range(3))
+            sets.append((ops.centre_indices(qi).view(B, S, H, D).permute(0, 2, 1, 3), ops.centre_indices(ki).view(B, S, H, D).permute(0, 2, 1, 3),
+                         ops.centre_indices(vi).view(B, S, H, D).permute(0, 2, 3, 1).contiguous()))
+        calls = [ops.PreparedAttn(*st, i8_grids=grids, **kw) for st in sets]
+    else:
+        calls = [ops.PreparedAttn(*st, **kw) for st in sets]
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for i in range(10):
         calls[i % nsets](stream)
@@ -116,7 +128,7 @@ def run(spec):
         samples.append(e0.elapsed_time(e1) * 1e3 / n)
     us = float(np.median(samples))  # reps > 1: median of the repeats (boxes and clocks wander by a few %)
     alg = per_set
-    var = ops.attn_variant(B, H, S, S, D, dt, fq=bool(kv["int8"]), clip=bool(kv["clip"]))
+    var = "i8mfma" if kv["i8"] else ops.attn_variant(B, H, S, S, D, dt, fq=bool(kv["int8"]), clip=bool(kv["clip"]))
     print(f"{spec:60s} {us:8.2f} us  {alg / us / 1e3:8.1f} GB/s alg  frac {alg / us / 1e3 / 8000:.3f}  "
           f"{4 * B * H * S * S * D / us / 1e6:7.1f} TF(dense)  sets={nsets}  [{var}]", flush=True)
 
