@@ -13,7 +13,7 @@ from tests.test_host_cpu import Cfg, gate_kwargs
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
-TOL = dict(atol=2e-3, rtol=2e-3)
+TOL = dict(atol=5e-4, rtol=5e-4)  # fp32 modules through the fp32-storage kernels (operand pairs): the kernels' own 5e-4
 
 
 @pytest.fixture(scope="module")
@@ -174,51 +174,72 @@ def _qparams(oa):
     return {**oa.val_qparams(cfg), "quant_dict": {}}
 
 
+# Measured on MI355X (round 3; the prints below, against the reference's captured module I/O in tests/golden/int8_attn.npz), all
+# eight cases of either family, `default` and `plain` alike: calibrated deltas within 4e-7 relative of the reference's, EVERY
+# output on the reference's grid point (0 outputs off, max error 0.00 steps).  The bounds leave room for one-in-a-thousand
+# single steps at rounding boundaries on other boxes / library versions, nothing more (round 2 accepted 5 % / 15 % and 2-3 steps).
+INT8_MODULE_LIMITS = {
+    # family: (relative error of a calibrated delta, share of outputs more than half an output-grid step off, largest error in steps)
+    "bert": (2e-6, 1e-3, 1.05),
+    "opt": (2e-6, 1e-3, 1.05),
+}
+
+
+@pytest.mark.parametrize("accel", ["default", "plain"])
 @pytest.mark.parametrize("fam", ["bert", "opt"])
-def test_int8_modules_calibrate_fix_eval(oa, fam):
-    """The reference's INT8 validate flow on the module: 4 calibration batches in estimate_ranges state (device-side
-    percentile + EMA), fix_ranges, then the fused fake-quant kernel; ranges and outputs vs the reference's."""
+def test_int8_modules_calibrate_fix_eval(oa, fam, accel):
+    """The reference's INT8 validate flow on the module (quantized_bert.py:221-440, quantized_opt.py:54-274): 4 calibration
+    batches in estimate_ranges state (device-side percentile + EMA), fix_ranges, then the fused kernels; calibrated ranges and
+    the eval output against the reference's captured ones.  `default`: what ships - QuantLinear as one fp16 GEMM on operand
+    pairs (PAIR_GEMM) and, for OPT, the integer-matrix-core attention (INT8_STORAGE); `plain`: torch's fp32 GEMMs and the
+    fake-quant kernels on float values.  The measured numbers are printed and bounded by about twice
+    their values: the module's output passes through three (BERT) / five (OPT: + out_proj and its output quantiser) rounding
+    stages after the first quantiser, each of which can move a value that sits on a rounding boundary by one grid step."""
+    from outeffhop_amd import quantization as Q
+
     g = load_golden("int8_attn.npz")
     calib = [torch.from_numpy(g[f"calib{i}"]).cuda() for i in range(4)]
     evalx = torch.from_numpy(g["eval"]).cuda()
     bmask, omask = torch.from_numpy(g["bert_mask"]).cuda(), torch.from_numpy(g["opt_mask"]).cuda()
-    for meta in json.loads(str(g["meta_json"])):
-        pre = f"{fam}{meta['tag']}"
-        sd = {k[len(pre) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre + ".w.")}
-        if fam == "bert":
-            org = oa.BertSelfAttentionWithExtras(Cfg(), softmax_fn=oa.SOFTMAX_MAPPING[meta["softmax"]], **gate_kwargs(meta["gate"]))
-            org.load_state_dict(sd, strict=True)
-            qm = oa.QuantizedBertSelfAttentionWithExtras(org.cuda(), **_qparams(oa)).cuda().eval()
-            fwd = lambda x: qm(x, attention_mask=bmask)[0]  # noqa: E731
-        else:
-            org = oa.OPTAttentionWithExtras(128, 2, is_decoder=True, softmax_fn=oa.SOFTMAX_MAPPING[meta["softmax"]], **gate_kwargs(meta["gate"]))
-            org.load_state_dict(sd, strict=True)
-            qm = oa.QuantizedOPTAttentionWithExtras(org.cuda(), **_qparams(oa)).cuda().eval()
-            fwd = lambda x: qm(x, attention_mask=omask)[0]  # noqa: E731
-        qm.set_quant_state(weight_quant=True, act_quant=True)
-        with torch.no_grad():
-            for c in calib:
-                fwd(c)
-            qm.fix_ranges()
-            assert qm._fq(fam == "opt") is not None
-            out = fwd(evalx)
-        # calibrated ranges agree with the reference's (fp32 GEMM order / fp16-free path: tight)
-        for name in ("attn_scores_act_quantizer", "attn_probs_act_quantizer", "context_act_quantizer"):
-            qz = getattr(qm, name).activation_quantizer.quantizer
-            ref_d = float(g[f"{pre}.q.{name}.activation_quantizer.delta"])
-            assert abs(float(qz.delta) - ref_d) <= 2e-3 * ref_d, (pre, name, float(qz.delta), ref_d)
-        # eval output: on the 8-bit output grid; the fused kernel sees fp16-rounded q/k/v so a small share of
-        # elements lands one step off, the rest agrees to rounding
-        ref = g[f"{pre}.out"]
-        got = out.float().cpu().numpy()
-        if fam == "bert":
-            step = float(g[f"{pre}.q.context_act_quantizer.activation_quantizer.delta"])
+    keep = (Q.PAIR_GEMM, Q.INT8_STORAGE)
+    if accel == "plain":
+        Q.PAIR_GEMM, Q.INT8_STORAGE = False, False
+    lim_d, lim_off, lim_steps = INT8_MODULE_LIMITS[fam]
+    try:
+        for meta in json.loads(str(g["meta_json"])):
+            pre = f"{fam}{meta['tag']}"
+            sd = {k[len(pre) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre + ".w.")}
+            if fam == "bert":
+                org = oa.BertSelfAttentionWithExtras(Cfg(), softmax_fn=oa.SOFTMAX_MAPPING[meta["softmax"]], **gate_kwargs(meta["gate"]))
+                org.load_state_dict(sd, strict=True)
+                qm = oa.QuantizedBertSelfAttentionWithExtras(org.cuda(), **_qparams(oa)).cuda().eval()
+                fwd = lambda x: qm(x, attention_mask=bmask)[0]  # noqa: E731
+            else:
+                org = oa.OPTAttentionWithExtras(128, 2, is_decoder=True, softmax_fn=oa.SOFTMAX_MAPPING[meta["softmax"]], **gate_kwargs(meta["gate"]))
+                org.load_state_dict(sd, strict=True)
+                qm = oa.QuantizedOPTAttentionWithExtras(org.cuda(), **_qparams(oa)).cuda().eval()
+                fwd = lambda x: qm(x, attention_mask=omask)[0]  # noqa: E731
+            qm.set_quant_state(weight_quant=True, act_quant=True)
+            with torch.no_grad():
+                for c in calib:
+                    fwd(c)
+                qm.fix_ranges()
+                assert qm._fq(fam == "opt") is not None
+                out = fwd(evalx)
+            d_err = 0.0
+            for name in ("attn_scores_act_quantizer", "attn_probs_act_quantizer", "context_act_quantizer"):
+                qz = getattr(qm, name).activation_quantizer.quantizer
+                ref_d = float(g[f"{pre}.q.{name}.activation_quantizer.delta"])
+                d_err = max(d_err, abs(float(qz.delta) - ref_d) / ref_d)
+            ref = g[f"{pre}.out"]
+            got = out.float().cpu().numpy()
+            step = float(g[f"{pre}.q.context_act_quantizer.activation_quantizer.delta"] if fam == "bert" else g[f"{pre}.q.out_proj.activation_quantizer.delta"])
             err = np.abs(got - ref)
-            assert err.max() <= 2.05 * step and (err > 0.5 * step).mean() < 0.05, (pre, err.max(), step, (err > 0.5 * step).mean())
-        else:
-            step = float(g[f"{pre}.q.out_proj.activation_quantizer.delta"])
-            err = np.abs(got - ref)
-            assert err.max() <= 3.05 * step and (err > 0.5 * step).mean() < 0.15, (pre, err.max(), step, (err > 0.5 * step).mean())
+            off, steps = float((err > 0.5 * step).mean()), float(err.max() / step)
+            print(f"int8 module {pre} [{accel}]: calibrated delta rel err {d_err:.2e}, outputs > half a step off {off:.2e}, max error {steps:.2f} steps")
+            assert d_err <= lim_d and off <= lim_off and steps <= lim_steps, (pre, accel, d_err, off, steps)
+    finally:
+        Q.PAIR_GEMM, Q.INT8_STORAGE = keep
 
 
 def test_gated_modules_in_16bit_use_the_in_kernel_predictor(oa):
@@ -430,11 +451,13 @@ def test_opt_consecutive_batches_with_different_padding(oa, quantised):
         with torch.no_grad():
             fused = m(x, attention_mask=mask)[0]
             seen = m(x, attention_mask=mask, output_attentions=True)[0]
-        tol = dict(atol=2e-3, rtol=2e-3)
-        if quantised:  # outputs sit on an 8-bit grid: allow a step for the few elements at a rounding boundary
+        tol = dict(atol=5e-4, rtol=5e-4)
+        if quantised:  # outputs sit on an 8-bit grid: a step for the few elements at a rounding boundary (measured: printed)
             step = float(m.out_proj.activation_quantizer.quantizer.delta) if hasattr(m.out_proj, "activation_quantizer") else 0.05
             err = (fused - seen).abs()
-            assert float(err.max()) <= 3.05 * step and float((err > 0.5 * step).float().mean()) < 0.1, (trial, float(err.max()), step)
+            steps, off = float(err.max()) / step, float((err > 0.5 * step).float().mean())
+            print(f"quantised OPT, batch {trial}: fused vs observable path max {steps:.2f} steps, {off:.2e} of the outputs more than half a step apart")
+            assert steps <= 1.05 and off <= 1e-3, (trial, steps, off)  # measured: 0.00 steps, 0 outputs apart
         else:
             _close(fused, seen.cpu().numpy(), f"batch {trial} fused vs observable", tol)
             # the reference op chain on the module's own projections
