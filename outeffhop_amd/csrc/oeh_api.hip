@@ -204,6 +204,7 @@ bool small_eligible(const oeh_attn_desc* d, const void* q, const void* k, const 
 unsigned long long* g_stamps = nullptr;  // tools/timeline.py only
 int g_variant_off = 0;                   // tools/microbench.py only: bit (1 << Variant) disables a variant
 int g_flash_mq = 0;                      // tools/microbench.py only: force query blocks per wave
+int g_head_group = 0;                    // tools/microbench.py only (OEH_HEAD_GROUP): block order of the fp32-storage kernels in groups of heads
 int g_place = 0;                         // tools/microbench.py only: 1 = plain block order in the one-pass kernel (no snake placement)
 
 // query blocks (16 rows) per wave of the one-pass kernel: 2 (128-row workgroups) once that still gives every CU two
@@ -287,6 +288,7 @@ void fill_params(AttnParams& P, const oeh_attn_desc* d, const void* q, const voi
   }
   P.stamps = g_stamps;
   P.snake = (g_place & 1) ? 0 : 1;
+  P.head_major = g_head_group;
   P.nQT = (d->Sq + 63) / 64;
   P.nBH = d->B * d->H;
   P.nBHpad = (P.nBH + 7) & ~7;
@@ -479,6 +481,7 @@ static bool debug_hooks_on() {
 int oeh_debug_set_variant(int off_mask, int flash_mq_force) {
   if (!debug_hooks_on()) return OEH_ENOTSUP;
   g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force; g_place = (off_mask >> 9) & 1;
+  { const char* e = std::getenv("OEH_HEAD_GROUP"); g_head_group = e != nullptr ? (std::atoi(e) & ~7) : 0; }
   return OEH_OK;
 }
 int oeh_debug_set_stamps(void* device_buffer) {

@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
   float* lds_pad = reinterpret_cast<float*>(lds + RINGB);
 
   const int bid = blockIdx.x;  // (snake_block_id measured 3-4 % slower here: 8 q tiles per head, not all workgroups resident)
-  const int qt_rev = bid / P.nBHpad;
-  const int bh = bid - qt_rev * P.nBHpad;
+  int qt_rev, bh;
+  block_to_tile(bid, P.nBHpad, P.nQT, SRC32 ? P.head_major : 0, qt_rev, bh);
   if (bh >= P.nBH) return;
   const int qt = P.nQT - 1 - qt_rev;
   const int b = bh / P.H, h = bh - b * P.H;

@@ -87,9 +87,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   __shared__ __attribute__((aligned(16))) float lds_padrow[PAD ? PADROW : 4];
   __shared__ int lds_last[4];
 
-  const int bid = P.snake ? snake_block_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int qt_rev = bid / P.nBHpad;
-  const int bh = bid - qt_rev * P.nBHpad;
+  const int bid = (P.snake && !(SRC32 && P.head_major)) ? snake_block_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  int qt_rev, bh;
+  block_to_tile(bid, P.nBHpad, P.nQT, SRC32 ? P.head_major : 0, qt_rev, bh);
   if (bh >= P.nBH) return;
   const int b = bh / P.H, h = bh - b * P.H;
 

@@ -45,6 +45,8 @@ struct AttnParams {
   int nQT;                    // q tiles (64 rows) per (b,h)
   int nBH, nBHpad;            // B*H and B*H rounded up to a multiple of 8 (XCD affinity of a head's q tiles)
   int skip_ok;                // causal tiles above the diagonal may be skipped (see oeh_api.hip)
+  int head_major;             // fp32-storage kernels: block order in groups of this many heads (0 = all heads' heaviest q tiles first;
+                              // oeh_common.h: block_to_tile)
   int snake;                  // one-pass kernel: every second row of 256 block ids walked backwards (snake_block_id, oeh_common.h)
   unsigned long long* stamps; // diagnostic builds only: per-wave s_memtime stamps (null in production)
 };

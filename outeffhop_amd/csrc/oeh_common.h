@@ -276,6 +276,23 @@ __device__ __forceinline__ int snake_block_id(int bid, const int nblocks) {
   return bid;
 }
 
+// Block id -> (position of the q tile in the head's heaviest-first list, head).  Plain (group = 0): all heads' heaviest q
+// tiles first, id = qt_rev * nBHpad + head.  Grouped: the heads in groups of `group` (a multiple of 8: blocks b and b + 8 share
+// an XCD, so a head keeps its XCD), heaviest q tiles first INSIDE a group - id = (head / group) * group * nQT + qt_rev * group
+// + head % group - so that all q tiles of a head are dispatched within group * nQT ids of each other.
+__device__ __forceinline__ void block_to_tile(const int bid, const int nBHpad, const int nQT, const int group, int& qt_rev, int& bh) {
+  if (group > 0) {
+    const int per = group * nQT;
+    const int grp = bid / per, rem = bid - grp * per;
+    const int gsz = min(group, nBHpad - grp * group);  // the last group may be smaller
+    qt_rev = rem / gsz;
+    bh = grp * group + (rem - qt_rev * gsz);
+  } else {
+    qt_rev = bid / nBHpad;
+    bh = bid - qt_rev * nBHpad;
+  }
+}
+
 // byte offset of an LDS object inside the workgroup's allocation (what M0 / ds_* addresses are made of)
 __device__ __forceinline__ unsigned lds_offset(const void* p) {
   return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p;

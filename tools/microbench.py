@@ -21,11 +21,12 @@ from outeffhop_amd import _lib, ops
 
 
 def run(spec):
-    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, reps=1, graph=0, gmlp=-1, ab="", i8=0)
+    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, reps=1, graph=0, gmlp=-1, ab="", i8=0, hg=0)
     for item in spec.split(","):
         k, v = item.split("=")
         kv[k] = v if k in ("dtype", "ab") else int(v)
     B, H, S, D = kv["B"], kv["H"], kv["S"], kv["D"]
+    os.environ["OEH_HEAD_GROUP"] = str(kv["hg"])  # fp32-storage kernels: block order in groups of this many heads (debug hook)
     _lib.load().oeh_debug_set_variant(kv["off"], kv["mq"])
     dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[kv["dtype"]]
     eb = 4 if dt == torch.float32 else 2
