@@ -55,6 +55,13 @@ WORKLOADS = {
                     desc="STanHop Association B*data_dim=224 L=S=28 H=4 E=64 fp32 softmax1, (B,L,H,E) layout: one wave per (batch, head)"),
     "bert_softmax1": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=False, gate=False,
                           desc="BERT-base attention core B=32 H=12 S=128 d=64 fp16 key-padding mask softmax1"),
+    # BASELINE config 2's shape with the INT8 configuration (quantized_bert.py:363,374,434: scores / sqrt(d) quantised before the
+    # key-padding mask, probabilities, context after the gate): fp16 storage (fake-quant variant of the full-row kernel) and INT8 storage
+    "bert_int8": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=True, gate=False,
+                      desc="BERT-base attention core B=32 H=12 S=128 d=64 fp16 key-padding mask softmax1 + 3 fused INT8 fake-quantisers"),
+    "bert_int8_i8": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=True, gate=False, i8=True,
+                         desc="BERT-base attention core B=32 H=12 S=128 d=64 key-padding mask softmax1, q/k/v as int8 indices of 8-bit grids "
+                              "(v transposed), both products on v_mfma_i32_16x16x64_i8, 3 fused INT8 quantisers, fp32 output"),
     "bert_gated": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=False, gate=True,
                        desc="BERT-base gated attention core B=32/GPU H=12 S=128 d=64 fp16: per-token gate from per-head MLPs "
                             "64->16->1 on the layer input, evaluated inside the attention kernel (gate_hidden ... of oeh_attn_desc)"),
@@ -407,7 +414,8 @@ def main():
         return pad_
 
     view = lambda t: t.to(dev).to(sdt).view(B, S, H, d).permute(0, 2, 1, 3)  # noqa: E731  (B,H,S,d) view of (B,S,E)
-    I8_GRIDS = ((0.03 * d ** -0.5, 131.0), (0.035, 124.0), (0.03, 128.0))  # (scale, zero point) of q (OPT's scaling folded in), k, v
+    Q_UNDO = d ** 0.5 if w["order"] == "opt" else 1.0  # OPT: q arrives scaled by head_dim^-0.5; its grid's scale carries the factor
+    I8_GRIDS = ((0.03 / Q_UNDO, 131.0), (0.035, 124.0), (0.03, 128.0))  # (scale, zero point) of q, k, v
 
     def view_i8(t, undo=1.0, transpose=False):
         """Synthetic INT8 storage: the centred index idx - 128 a unit-variance projection lands on with a grid step of 0.03."""
@@ -419,7 +427,7 @@ def main():
     for q, k, v, gi in gen_layers(rank, L):
         o = torch.empty(B, S, H, d, dtype=sdt, device=dev).permute(0, 2, 1, 3)
         if w.get("i8"):
-            sets.append((view_i8(q, undo=d ** 0.5), view_i8(k), view_i8(v, transpose=True), o))
+            sets.append((view_i8(q, undo=Q_UNDO), view_i8(k), view_i8(v, transpose=True), o))
         else:
             sets.append((view(q), view(k), view(v), o))
         if gi is not None:
@@ -576,7 +584,7 @@ def main():
                     o_ = torch.empty(B, S, H, d, dtype=sdt, device=dev).permute(0, 2, 1, 3)
                     hd_ = None if gi_ is None else gi_.to(dev)
                     if w.get("i8"):
-                        args_, keep_ = make_call(view_i8(q_, undo=d ** 0.5), view_i8(k_), view_i8(v_, transpose=True), o_, pad=pr, hd=hd_)
+                        args_, keep_ = make_call(view_i8(q_, undo=Q_UNDO), view_i8(k_), view_i8(v_, transpose=True), o_, pad=pr, hd=hd_)
                     else:
                         args_, keep_ = make_call(view(q_), view(k_), view(v_), o_, pad=pr, hd=hd_)
                     if fwd(*args_, stream) != 0:
@@ -594,7 +602,7 @@ def main():
         layer_tokens = world * B * S * L * a.steps
         kern_s = dev_ms * 1e-3 / launches
         elt = 4 if w.get("fp32") else 2
-        alg_bytes = (3 * B * H * S * d * 1 + B * H * S * d * 4) if w.get("i8") else 4 * B * H * S * d * elt + (B * S * 4 if pad is not None else 0) + (B * S * H * d * elt if gate is not None else 0)  # + gate input (hidden states)
+        alg_bytes = (3 * B * H * S * d * 1 + B * H * S * d * 4 + (B * S * 4 if pad is not None else 0)) if w.get("i8") else 4 * B * H * S * d * elt + (B * S * 4 if pad is not None else 0) + (B * S * H * d * elt if gate is not None else 0)  # + gate input (hidden states)
         achieved = alg_bytes / kern_s / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")

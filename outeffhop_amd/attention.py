@@ -296,6 +296,34 @@ def classify_causal(mask: torch.Tensor):
     return res
 
 
+_padbool_cache = {}  # id(mask) -> (weakref to the mask tensor, its version counter, result)
+
+
+def pad_is_boolean(mask: torch.Tensor) -> bool:
+    """True when an additive mask holds only 0 (visible) and values <= -1e4 (hidden) - HF's extended masks hold 0 / finfo.min.
+    The integer-matrix-core attention (`ops.attn_fwd_i8`) DROPS a padded key instead of adding the mask value to its score, which
+    is the reference's result exactly for such masks.  One pass (and one host read) per distinct mask tensor object - HF hands
+    the same tensor to every layer -, remembered like `classify_causal` does: by the identity of the live object and its
+    version counter, never by address."""
+    key = id(mask)
+    hit = _padbool_cache.get(key)
+    if hit is not None:
+        if hit[0]() is mask and hit[1] == mask._version:
+            return hit[2]
+        del _padbool_cache[key]
+    res = bool(((mask == 0) | (mask <= -1.0e4)).all())
+
+    def _forget(dead, _k=key):
+        ent = _padbool_cache.get(_k)
+        if ent is not None and ent[0] is dead:
+            del _padbool_cache[_k]
+
+    if len(_padbool_cache) > 64:
+        _padbool_cache.clear()
+    _padbool_cache[key] = (weakref.ref(mask, _forget), mask._version, res)
+    return res
+
+
 def attention_core(
     q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, softmax_fn, scale: float = 1.0, scale_div: float = 0.0,
     attention_mask: Optional[torch.Tensor] = None, clamp_min: bool = False, detect_causal: bool = False,

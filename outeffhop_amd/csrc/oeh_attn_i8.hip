@@ -19,8 +19,11 @@
 // like the 16-bit kernels; the 16-B chunk of a row is XOR-swizzled with {0,3,2,1}[row group] so that ds_read_b128 of either
 // operand is conflict-free (the row groups differ: keys are dealt to MFMA rows as key = 16 (row >> 2) + 4 t + (row & 3) so
 // that a lane ends up with 16 CONSECUTIVE keys of its query - the k order the V^T operand has).
-// Masks: none | analytic causal.  Everything else of the INT8 configuration (key padding, clipping, other head dims) runs
-// the fake-quant variants of the 16-bit / fp32 kernels on dequantised values.
+// Masks: none | analytic causal | a key-padding vector (PAD variants: BERT's (B,1,1,S) mask, OPT's padded batches) whose
+// entries are 0 or <= -1e4 (HF's extended masks: 0 / finfo.min - the host checks it once per mask tensor): a padded key
+// carries the sentinel like a causally hidden one, its exponential is exactly 0 as in the reference.  Everything else of the
+// INT8 configuration (clipping, other head dims, arbitrary additive masks) runs the fake-quant variants of the 16-bit / fp32
+// kernels on dequantised values.
 //
 // The vector arithmetic per score element is the cost of this kernel (round 2: 21.7 wave-instructions per element, the
 // launch VALU-issue bound), so the chain is written for the instruction count:
@@ -42,7 +45,7 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int perm4(int x) { return (0x6C >> ((x & 3) * 2)) & 3; }  // {0,3,2,1}
 
-template <int NT, int OUT, bool DUMP, bool CQ2>
+template <int NT, int OUT, bool DUMP, bool CQ2, bool PAD>
 __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P) {
   constexpr int D = 64, KT = NT / 4, TILEB = 64 * 64, DT = 4;
   // The K and the V^T phases have eight MFMAs per wave and tile between two barriers: they run at the pace the tiles ARRIVE.
@@ -52,6 +55,9 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   constexpr float RELMASK = -1.0e30f;
   constexpr bool OUT32 = (OUT == IN_F32);
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * R * TILEB];
+  // PAD: per key +big (visible), the sentinel (padded) or -inf (key >= Sk: not even a masked key - a fully masked row of the
+  // vanilla softmax is uniform over the Sk keys, as in the reference): rel = min(rel, flag), one instruction per element
+  __shared__ __attribute__((aligned(16))) float lds_pad[PAD ? NT * 16 : 4];
 
   const int bid = blockIdx.x;
   const int qt_rev = bid / P.nBHpad;
@@ -141,6 +147,13 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   for (int j = 0; j < 4; ++j) asum = __builtin_amdgcn_sdot4(qf[j], ones, asum, false);
   asum += __shfl_xor(asum, 16);
   asum += __shfl_xor(asum, 32);
+  if constexpr (PAD) {  // (compiler-visible loads: its wait for them also covers the first transfers, which the first tile wait needs anyway)
+    for (int i = threadIdx.x; i < NT * 16; i += 256) {
+      float f = -__builtin_inff();
+      if (i < Sk) f = load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + i) < -1.0e4f ? RELMASK : 3.0e38f;
+      lds_pad[i] = f;
+    }
+  }
   const int cq = P.i8_cq, ck = P.i8_ck, cv = P.i8_cv, cp = P.i8_cp;   // 128 - zero point of q, k, v and of the probabilities
   const float k1 = P.i8_k1;  // (quotient of the score by the score grid's step) = k1 * sum_d (a + cq)(b + ck)
   // the query's part of the offsets, in the accumulator from the start: ck sum_d a + D cq ck (|.| < 2^23)
@@ -195,9 +208,9 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   const int klimc = qrow + off;
   const int klime = causal ? min(klimc, Sk - 1) : Sk - 1;   // last key this lane's row sees
   const int kt_causal = causal ? (max(0, q0 + off + 1) >> 6) : KT;
-  const int kt_tail = Sk >> 6;
+  const int kt_tail = PAD ? KT : (Sk >> 6);                 // (PAD: the flags carry the tail)
   const float slo = MAGIC + P.fq_s.lo, shi = MAGIC + P.fq_s.hi;
-  const int klim_g = klime - 16 * g;                        // ... relative to the lane's first key of a tile
+  const int klim_g = (PAD ? (causal ? klimc : Sk - 1) : klime) - 16 * g;   // ... relative to the lane's first key of a tile
   float mr = RELMASK;
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
@@ -221,6 +234,11 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
         if (!open_tile) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) rel[r] = (4 * t + r > lim) ? RELMASK : rel[r];
+        }
+        if constexpr (PAD) {
+          const f4 flag = *reinterpret_cast<const f4*>(&lds_pad[64 * kt + 16 * g + 4 * t]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rel[r] = __builtin_fminf(rel[r], flag[r]);
         }
         s[kt * 4 + t] = rel;
       }
@@ -359,27 +377,31 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   }
 }
 
+template <int NT, int OUT, bool DUMP>
+static void launch_i8_variant(const AttnParams& P, unsigned grid, hipStream_t st) {
+  const bool cq2 = P.i8_cq == 128;  // a q grid with zero point 0 (rare: the projections are two-sided)
+  const bool pad = P.pad != nullptr;
+  if (cq2) {
+    if (pad) hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, OUT, DUMP, true, true>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, OUT, DUMP, true, false>), dim3(grid), dim3(256), 0, st, P);
+  } else {
+    if (pad) hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, OUT, DUMP, false, true>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, OUT, DUMP, false, false>), dim3(grid), dim3(256), 0, st, P);
+  }
+}
+
 template <int NT>
 static int launch_i8_nt(const AttnParams& P, int out, hipStream_t st) {
   const unsigned grid = (unsigned)(P.nQT * P.nBHpad);
   if (P.fq_s.dump != nullptr || P.fq_p.dump != nullptr || P.fq_c.dump != nullptr) {  // tests: the index tensors written out (fp32 output only)
     if (out != IN_F32) return -95;
-    if (P.i8_cq == 128) hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F32, true, true>), dim3(grid), dim3(256), 0, st, P);
-    else hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F32, true, false>), dim3(grid), dim3(256), 0, st, P);
-    return hipGetLastError() == hipSuccess ? 0 : -5;
-  }
-  if (P.i8_cq == 128) {  // a q grid with zero point 0 (rare: the projections are two-sided)
-    switch (out) {
-      case IN_F16: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F16, false, true>), dim3(grid), dim3(256), 0, st, P); break;
-      case IN_BF16: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_BF16, false, true>), dim3(grid), dim3(256), 0, st, P); break;
-      default: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F32, false, true>), dim3(grid), dim3(256), 0, st, P); break;
-    }
+    launch_i8_variant<NT, IN_F32, true>(P, grid, st);
     return hipGetLastError() == hipSuccess ? 0 : -5;
   }
   switch (out) {
-    case IN_F16: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F16, false, false>), dim3(grid), dim3(256), 0, st, P); break;
-    case IN_BF16: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_BF16, false, false>), dim3(grid), dim3(256), 0, st, P); break;
-    default: hipLaunchKernelGGL((oeh_attn_i8_kernel<NT, IN_F32, false, false>), dim3(grid), dim3(256), 0, st, P); break;
+    case IN_F16: launch_i8_variant<NT, IN_F16, false>(P, grid, st); break;
+    case IN_BF16: launch_i8_variant<NT, IN_BF16, false>(P, grid, st); break;
+    default: launch_i8_variant<NT, IN_F32, false>(P, grid, st); break;
   }
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -338,13 +338,14 @@ def quantize_heads_i8(x: torch.Tensor, spec: "FakeQuantSpec", H: int, transpose:
 def attn_fwd_i8(q: torch.Tensor, k: torch.Tensor, v_t: torch.Tensor, grids, *, fq: AttnFakeQuant, out_dtype=torch.float16,
                 softmax: SoftmaxSpec = SoftmaxSpec(), scale: float = 1.0, scale_div: float = 0.0, causal: bool = False, clamp_min: bool = False,
                 mask_min: Optional[float] = None, gate: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                _prepared: Optional[list] = None) -> torch.Tensor:
+                key_pad_mask: Optional[torch.Tensor] = None, _prepared: Optional[list] = None) -> torch.Tensor:
     """The INT8 configuration on the integer matrix cores (`include/oeh.h`: dtype OEH_I8): q, k logical (B,H,S,64) int8 views of
     centred indices (`centre_indices`), v_t the TRANSPOSED values, a (B,H,64,Sk) int8 view with contiguous keys; `grids` =
     (q, k, v) QuantGrid; `fq` with scores and probabilities (8-bit) [and context].  Returns the logical (B,H,Sq,64) result in
-    `out_dtype`, stored (B,Sq,H,64)-contiguous.  Raises OehError(-95) for what this path does not take (key padding, clipping,
-    other head dims ...): the caller then runs `attn_fwd(..., fq=...)` on the dequantised values."""
-    dev = _need_gpu(q, k, v_t, gate, out)
+    `out_dtype`, stored (B,Sq,H,64)-contiguous.  `key_pad_mask`: (B,Sk) additive, entries 0 or <= -1e4 ONLY (HF's extended
+    masks; the caller vouches for it - `attention.pad_is_boolean`).  Raises OehError(-95) for what this path does not take
+    (clipping, other head dims, full additive masks ...): the caller then runs `attn_fwd(..., fq=...)` on the dequantised values."""
+    dev = _need_gpu(q, k, v_t, gate, out, key_pad_mask)
     if q.dtype != torch.int8 or k.dtype != torch.int8 or v_t.dtype != torch.int8:
         raise ValueError("q, k, v_t must be int8 (centred indices)")
     B, H, Sq, D = q.shape
@@ -368,6 +369,15 @@ def attn_fwd_i8(q: torch.Tensor, k: torch.Tensor, v_t: torch.Tensor, grids, *, f
     d.causal, d.clamp_min = int(bool(causal)), int(bool(clamp_min))
     d.mask_min = float(torch.finfo(torch.float32).min if mask_min is None else mask_min)
     keep = []
+    if key_pad_mask is not None:
+        pm = key_pad_mask
+        if pm.dtype not in (torch.float16, torch.float32):
+            pm = pm.float()
+        pm = pm.reshape(B, Sk) if pm.numel() == B * Sk else pm.reshape(1, Sk).expand(B, Sk)
+        if pm.stride(1) != 1:
+            pm = pm.contiguous()
+        keep.append(pm)
+        d.key_pad_mask, d.key_pad_dtype, d.key_pad_stride = pm.data_ptr(), _DT[pm.dtype], pm.stride(0)
     if gate is not None:
         g = gate.to(torch.float32)
         while g.dim() < 4:

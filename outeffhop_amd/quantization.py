@@ -27,7 +27,8 @@ from torch import nn
 
 from . import ops
 from ._lib import OehError as _OehError
-from .attention import AttentionGateType, BaseEnumOptions, GateBookkeeping, GateState, attention_core, classify_causal, unfused_core
+from .attention import (AttentionGateType, BaseEnumOptions, GateBookkeeping, GateState, attention_core, classify_causal, pad_is_boolean, split_mask,
+                        unfused_core)
 from .ops import AttnFakeQuant, FakeQuantSpec
 from .softmax import spec_of
 
@@ -673,6 +674,72 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
         return AttnFakeQuant(trio[0].fixed_spec(), trio[1].fixed_spec(), trio[2].fixed_spec(), ctx_before_gate=ctx_before_gate)
 
 
+
+    def _qkv_pair_weights(self, lins):
+        """The three projections' operand-pair weights (`QuantLinear._pair_weights`) side by side, (2K, 3E) fp16, and their fp32
+        weight scales; rebuilt when any of the three was (a changed weight or weight range rebuilds that projection's own cache)."""
+        parts = [m._pair_weights() for m in lins]
+        hit = self.__dict__.get("_qkv_pair_cache")
+        if hit is None or any(a is not b for a, (b, _) in zip(hit[0], parts)):
+            hit = (tuple(p[0] for p in parts), torch.cat([p[0] for p in parts], dim=1).contiguous())
+            self.__dict__["_qkv_pair_cache"] = hit
+        return hit[1], [p[1] for p in parts]
+
+    def _int8_storage_core(self, hidden_states, lins, H, head_dim, *, scale, scale_div, causal, padvec, mask_min, gate, fq, want_values):
+        """SURVEY 8f-3: the q/k/v projections are QuantLinear - their outputs ARE 8-bit indices on calibrated grids
+        (hijacker.py:78-127; quantized_opt.py:67-75, quantized_bert.py:236-238) - so the attention core takes the indices
+        themselves and runs both products on the integer matrix cores (`ops.attn_fwd_i8`, include/oeh.h dtype OEH_I8).  Applies
+        when the three output quantisers are 8-bit with frozen ranges, head_dim = 64, the softmax is not clipped and the mask is
+        none / causal / a key-padding vector of 0 / finfo.min entries (`padvec`, vouched for by the caller); returns the
+        merged context (B, T, E) and the (k, v) float values (`want_values`: a decoder's cache), or None -> the caller runs the
+        fake-quant path on floats."""
+        if not INT8_STORAGE or not hidden_states.is_cuda or head_dim != 64:
+            return None
+        spec = spec_of(self.softmax_fn)
+        bsz, tgt_len, _ = hidden_states.shape
+        if spec is None or spec.clip or tgt_len % 16 != 0 or tgt_len > 512 or fq.probs is None or fq.probs.qmax != 255.0 or fq.scores is None:
+            return None
+        if not all(isinstance(m, QuantLinear) and m._qa and m.activation_quantizer.is_fixed and m.activation_quantizer.quantizer.n_bits == 8
+                   and m.activation_function is None for m in lins):
+            return None
+        E = H * head_dim
+        outs, grids = [], []
+        pairs, acc3 = None, None
+        if all(m.pair_gemm_ok(hidden_states) and m.bias is not None for m in lins):
+            # fp32 model: the input as fp16 operand pairs, split once, and ONE fp16 GEMM against the three integer weight
+            # matrices side by side (SURVEY 8f-1); each projection's weight scale and bias are folded into its quantiser pass
+            pairs = ops.split_pairs(hidden_states.reshape(-1, hidden_states.shape[-1]))
+            ww3, scales3 = self._qkv_pair_weights(lins)
+            acc3 = torch.mm(pairs, ww3, out_dtype=torch.float32).view(bsz, tgt_len, 3 * E)
+        for n_, m in enumerate(lins):  # GEMM, then ONE kernel: centred int8 indices in the core's layout (v transposed) [+ the cache's floats]
+            alpha, qbias = 1.0, None
+            if acc3 is not None:
+                res, alpha, qbias = acc3[..., n_ * E:(n_ + 1) * E], scales3[n_], m.bias.detach()
+            elif m.pair_gemm_ok(hidden_states) and m.bias is not None:
+                if pairs is None:
+                    pairs = ops.split_pairs(hidden_states.reshape(-1, hidden_states.shape[-1]))
+                res, alpha, qbias = m.linear_pairs(hidden_states, pairs, raw=True)
+                qbias = qbias.detach()
+            else:
+                w, b = m.get_params()
+                res = nn.functional.linear(hidden_states.contiguous(), w.contiguous(), bias=b)
+            sp = m.activation_quantizer.quantizer.spec()
+            outs.append(ops.quantize_heads_i8(res, sp, H, transpose=(n_ == 2), want_values=(n_ > 0 and want_values), alpha=alpha, bias=qbias))
+            grids.append(ops.QuantGrid.of(sp))
+        qc = outs[0]
+        kc, yk = outs[1] if want_values else (outs[1], None)
+        vt, yv = outs[2] if want_values else (outs[2], None)
+        try:
+            out = ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, out_dtype=hidden_states.dtype, softmax=spec, scale=scale, scale_div=scale_div, causal=causal,
+                                  clamp_min=causal or padvec is not None, mask_min=mask_min, gate=gate, key_pad_mask=padvec)
+        except _OehError as e:
+            if e.code != -95:
+                raise
+            return None
+        self.__dict__["_i8_calls"] = self.__dict__.get("_i8_calls", 0) + 1  # (tests: which core ran)
+        return out.permute(0, 2, 1, 3).reshape(bsz, tgt_len, E), (yk, yv)
+
+
 class QuantizedBertSelfAttentionWithExtras(_QuantAttnBase):
     """quantized_bert.py:221-440: fake-quant on scores (after /sqrt(d), before the mask), on probs, and on the context
     AFTER gating and head merge; the gate is applied without gate_scaling_factor (:422)."""
@@ -697,6 +764,28 @@ class QuantizedBertSelfAttentionWithExtras(_QuantAttnBase):
                 past_key_value=None, output_attentions=False):
         if self.position_embedding_type in ("relative_key", "relative_key_query"):
             raise NotImplementedError("relative position embeddings are not on the quantised MI355X path")
+        if (encoder_hidden_states is None and past_key_value is None and head_mask is None and not output_attentions
+                and not (self.training and self.dropout.p > 0.0)):
+            # self-attention in inference: query / key / value are QuantLinear (quantized_bert.py:236-238) - their outputs are 8-bit
+            # indices, and the whole core (scores / sqrt(d) -> fq -> + mask -> softmax -> fq -> P V -> gate -> fq) runs on them
+            fq8 = self._fq(ctx_before_gate=False)
+            pad8, ok = None, fq8 is not None
+            if ok and attention_mask is not None:
+                B_, T_ = hidden_states.shape[0], hidden_states.shape[1]
+                pad8, full8 = split_mask(attention_mask, B_, T_, T_)
+                ok = full8 is None and pad_is_boolean(attention_mask)
+            if ok:
+                gate8 = GateState.evaluate(self, hidden_states, self.num_attention_heads)
+                mdt = attention_mask.dtype if attention_mask is not None and attention_mask.is_floating_point() else hidden_states.dtype
+                done = self._int8_storage_core(hidden_states, (self.query, self.key, self.value), self.num_attention_heads, self.attention_head_size,
+                                               scale=1.0, scale_div=float(np.sqrt(self.attention_head_size)), causal=False, padvec=pad8,
+                                               mask_min=float(torch.finfo(mdt).min), gate=gate8, fq=fq8, want_values=self.is_decoder)
+                if done is not None:
+                    context, (yk, yv) = done
+                    outputs = (context,)
+                    if self.is_decoder:
+                        outputs = outputs + ((self.transpose_for_scores(yk), self.transpose_for_scores(yv)),)
+                    return outputs
         q = self.transpose_for_scores(self.query(hidden_states))
         src = hidden_states if encoder_hidden_states is None else encoder_hidden_states
         if encoder_hidden_states is not None:
@@ -754,75 +843,6 @@ class QuantizedOPTAttentionWithExtras(_QuantAttnBase):
     def _shape(self, tensor, seq_len, bsz):
         return tensor.view(bsz, seq_len, self.num_heads, self.head_dim).transpose(1, 2).contiguous()
 
-    def _qkv_pair_weights(self):
-        """The three projections' operand-pair weights (`QuantLinear._pair_weights`) side by side, (2K, 3E) fp16, and their fp32
-        weight scales; rebuilt when any of the three was (a changed weight or weight range rebuilds that projection's own cache)."""
-        parts = [m._pair_weights() for m in (self.q_proj, self.k_proj, self.v_proj)]
-        hit = self.__dict__.get("_qkv_pair_cache")
-        if hit is None or any(a is not b for a, (b, _) in zip(hit[0], parts)):
-            hit = (tuple(p[0] for p in parts), torch.cat([p[0] for p in parts], dim=1).contiguous())
-            self.__dict__["_qkv_pair_cache"] = hit
-        return hit[1], [p[1] for p in parts]
-
-    def _int8_storage_core(self, hidden_states, attention_mask, gate, fq):
-        """SURVEY 8f-3: the q/k/v projections are QuantLinear - their outputs ARE 8-bit indices on calibrated grids
-        (hijacker.py:78-127) - so the attention core can take the indices themselves and run both products on the integer
-        matrix cores (`ops.attn_fwd_i8`, include/oeh.h dtype OEH_I8).  Applies when the three output quantisers are 8-bit with
-        frozen ranges, head_dim = 64, the softmax is not clipped and the mask is None or purely causal (no padded keys);
-        returns (merged context, (k, v) floats for the cache) or None -> the caller runs the fake-quant path on floats."""
-        if not INT8_STORAGE or not hidden_states.is_cuda or self.head_dim != 64:
-            return None
-        spec = spec_of(self.softmax_fn)
-        bsz, tgt_len, _ = hidden_states.shape
-        if spec is None or spec.clip or tgt_len % 16 != 0 or tgt_len > 512 or fq.probs is None or fq.probs.qmax != 255.0 or fq.scores is None:
-            return None
-        lins = (self.q_proj, self.k_proj, self.v_proj)
-        if not all(isinstance(m, QuantLinear) and m._qa and m.activation_quantizer.is_fixed and m.activation_quantizer.quantizer.n_bits == 8
-                   and m.activation_function is None for m in lins):
-            return None
-        causal = False
-        if attention_mask is not None:
-            causal, padvec = classify_causal(attention_mask)
-            if not causal or padvec is not None:
-                return None
-        H = self.num_heads
-        outs, grids = [], []
-        pairs, acc3 = None, None
-        if all(m.pair_gemm_ok(hidden_states) and m.bias is not None for m in lins):
-            # fp32 model: the input as fp16 operand pairs, split once, and ONE fp16 GEMM against the three integer weight
-            # matrices side by side (SURVEY 8f-1); each projection's weight scale and bias are folded into its quantiser pass
-            pairs = ops.split_pairs(hidden_states.reshape(-1, hidden_states.shape[-1]))
-            ww3, scales3 = self._qkv_pair_weights()
-            acc3 = torch.mm(pairs, ww3, out_dtype=torch.float32).view(bsz, tgt_len, 3 * self.embed_dim)
-        for n_, m in enumerate(lins):  # GEMM, then ONE kernel: centred int8 indices in the core's layout (v transposed) [+ the cache's floats]
-            alpha, qbias = 1.0, None
-            if acc3 is not None:
-                res, alpha, qbias = acc3[..., n_ * self.embed_dim:(n_ + 1) * self.embed_dim], scales3[n_], m.bias.detach()
-            elif m.pair_gemm_ok(hidden_states) and m.bias is not None:
-                if pairs is None:
-                    pairs = ops.split_pairs(hidden_states.reshape(-1, hidden_states.shape[-1]))
-                res, alpha, qbias = m.linear_pairs(hidden_states, pairs, raw=True)
-                qbias = qbias.detach()
-            else:
-                w, b = m.get_params()
-                res = nn.functional.linear(hidden_states.contiguous(), w.contiguous(), bias=b)
-            sp = m.activation_quantizer.quantizer.spec()
-            outs.append(ops.quantize_heads_i8(res, sp, H, transpose=(n_ == 2), want_values=(n_ > 0 and self.is_decoder), alpha=alpha, bias=qbias))
-            grids.append(ops.QuantGrid.of(sp))
-        qc = outs[0]
-        kc, yk = outs[1] if self.is_decoder else (outs[1], None)
-        vt, yv = outs[2] if self.is_decoder else (outs[2], None)
-        mdt = attention_mask.dtype if attention_mask is not None and attention_mask.is_floating_point() else hidden_states.dtype
-        try:
-            out = ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, out_dtype=hidden_states.dtype, softmax=spec, scale=self.scaling, causal=causal,
-                                  clamp_min=attention_mask is not None, mask_min=float(torch.finfo(mdt).min), gate=gate)
-        except _OehError as e:
-            if e.code != -95:
-                raise
-            return None
-        cache = (self._heads(yk, bsz), self._heads(yv, bsz)) if self.is_decoder else None
-        return out.permute(0, 2, 1, 3).reshape(bsz, tgt_len, self.embed_dim), cache
-
     def forward(self, hidden_states, key_value_states=None, past_key_value=None, attention_mask=None, layer_head_mask=None,
                 output_attentions=False):
         bsz, tgt_len, _ = hidden_states.size()
@@ -831,11 +851,20 @@ class QuantizedOPTAttentionWithExtras(_QuantAttnBase):
             if fq8 is not None:
                 if attention_mask is not None and attention_mask.size() != (bsz, 1, tgt_len, tgt_len):
                     raise ValueError(f"Attention mask should be of size {(bsz, 1, tgt_len, tgt_len)}, but is {attention_mask.size()}")
-                gate8 = GateState.evaluate(self, hidden_states, self.num_heads)
-                done = self._int8_storage_core(hidden_states, attention_mask, gate8, fq8)
-                if done is not None:
-                    merged, kv = done
-                    return self.out_proj(merged), None, (kv if self.is_decoder else past_key_value)
+                ok, causal8, pad8 = True, False, None
+                if attention_mask is not None:  # HF's decoder mask: causal, plus finfo.min columns for padded keys (checked once per tensor)
+                    causal8, pad8 = classify_causal(attention_mask)
+                    ok = causal8
+                if ok:
+                    gate8 = GateState.evaluate(self, hidden_states, self.num_heads)
+                    mdt = attention_mask.dtype if attention_mask is not None and attention_mask.is_floating_point() else hidden_states.dtype
+                    done = self._int8_storage_core(hidden_states, (self.q_proj, self.k_proj, self.v_proj), self.num_heads, self.head_dim,
+                                                   scale=self.scaling, scale_div=0.0, causal=causal8, padvec=pad8, mask_min=float(torch.finfo(mdt).min),
+                                                   gate=gate8, fq=fq8, want_values=self.is_decoder)
+                    if done is not None:
+                        merged, (yk, yv) = done
+                        kv = (self._heads(yk, bsz), self._heads(yv, bsz)) if self.is_decoder else past_key_value
+                        return self.out_proj(merged), None, kv
         q = self._heads(self.q_proj(hidden_states) * self.scaling, bsz)
         if key_value_states is not None and past_key_value is not None:
             k, v = past_key_value[0], past_key_value[1]

@@ -1197,6 +1197,63 @@ def test_int8_storage_on_the_integer_matrix_cores(ops, S, causal, base, out_dtyp
         ops.attn_fwd_i8(qc, kc, vt, grids, fq=ops.AttnFakeQuant(FQ(*d_s), ops.FakeQuantSpec(1 / 127.0, 0.0, 127.0), None), scale=scaling)
 
 
+@pytest.mark.parametrize("order,causal,base", [("bert", False, 1), ("bert", False, 0), ("opt", True, 1), ("opt", True, 0)])
+def test_int8_storage_key_padding_and_bert_order(ops, order, causal, base):
+    """the integer-matrix-core kernel with a key-padding vector (its PAD variants), in BERT order (scores
+    divided by sqrt(d), `quantized_bert.py:363`; context quantised AFTER the gate, `:434`) and in OPT order with padded keys on
+    top of the causal mask (HF's decoder mask for a padded batch) - against the oracle on the dequantised values, incl. a
+    right-padded, a left-padded and a fully padded sample (softmax_1: exactly the zero point's value; vanilla softmax: uniform
+    over all keys, as the reference gives)."""
+    B, H, D, S = 4, 3, 64, 176
+    fmin = float(np.finfo(np.float32).min)
+    g = torch.Generator().manual_seed(91 + base)
+    x = [torch.randn((B, S, H * D), generator=g).numpy() * s_ for s_ in (1.0, 1.2, 0.9)]
+    (qi, qd, qg), (ki, kd, kg), (vi, vd, vg) = (_quantise_to_grid(t) for t in x)
+    heads = lambda t: np.ascontiguousarray(t.reshape(B, S, H, D).transpose(0, 2, 1, 3))  # noqa: E731
+    padm = _pad_mask(B, S, [S, 121, S, 0], fmin)
+    padm[2, :37] = fmin  # left padding
+    if order == "bert":
+        okw = dict(scale=8.0, scale_is_divisor=True)
+        qdh = heads(qd)
+        kkw = dict(scale_div=8.0)
+    else:
+        okw = dict()
+        qdh = heads(qd) * np.float32(D ** -0.5)
+        kkw = dict(scale=D ** -0.5)
+    kdh, vdh = heads(kd), heads(vd)
+    common = dict(base=base, causal=causal, clamp_min=True, pad_mask=padm, **okw)
+    ctx_fp, fp = O.attn_core(qdh, kdh, vdh, want=("scores", "probs"), **common)
+    vis = padm[:, None, None, :] == 0
+    d_s = O.quant_range_to_params(*np.percentile(fp["scores"][np.broadcast_to(vis, fp["scores"].shape)], (0.001, 99.999)))
+    d_p = O.quant_range_to_params(*np.percentile(fp["probs"], (0.001, 99.999)))
+    d_c = O.quant_range_to_params(*np.percentile(ctx_fp, (0.001, 99.999)))
+    gate = torch.rand((B, H, S, 1), generator=g)
+    before = order == "opt"
+    want = O.attn_core(qdh, kdh, vdh, fq_scores=d_s, fq_probs=d_p, fq_ctx=d_c, ctx_quant_before_gate=before, gate=gate.numpy(), **common)
+    FQ = ops.FakeQuantSpec.from_delta
+    fq = ops.AttnFakeQuant(FQ(*d_s), FQ(*d_p), FQ(*d_c), ctx_before_gate=before)
+    dev = lambda t: torch.from_numpy(t).cuda()  # noqa: E731
+    qc = ops.centre_indices(dev(qi)).view(B, S, H, D).permute(0, 2, 1, 3)
+    kc = ops.centre_indices(dev(ki)).view(B, S, H, D).permute(0, 2, 1, 3)
+    vt = ops.centre_indices(dev(vi)).view(B, S, H, D).permute(0, 2, 3, 1).contiguous()
+    grids = (ops.QuantGrid(*qg), ops.QuantGrid(*kg), ops.QuantGrid(*vg))
+    got = ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, out_dtype=torch.float32, softmax=ops.SoftmaxSpec(base, False, 0.0, 1.0), causal=causal,
+                          clamp_min=True, mask_min=fmin, gate=gate.cuda(), key_pad_mask=dev(padm), **kkw)
+    step = float(np.float32(d_c[0])) * (1.0 if before else 1.0)
+    err = np.abs(_np32(got) - want)
+    off = float((err > 1e-6).mean())
+    assert err.max() <= 1.01 * step + 1e-6 and off <= 5e-4, f"max err {err.max():.3e} (step {step:.3e}), {off:.2e} of the outputs off their grid point"
+    # the fake-quant kernels on the dequantised fp32 values: the same results up to those rare steps
+    ref = ops.attn_fwd(dev(qdh), dev(kdh), dev(vdh), softmax=ops.SoftmaxSpec(base, False, 0.0, 1.0), causal=causal, clamp_min=True, mask_min=fmin,
+                       gate=gate.cuda(), fq=fq, key_pad_mask=dev(padm), **({"scale_div": 8.0} if order == "bert" else {}))
+    d2 = (got - ref).abs()
+    assert float(d2.max()) <= 1.01 * step + 1e-6 and float((d2 > 1e-6 + 1e-3 * ref.abs()).float().mean()) <= 5e-4
+    # a mask value that is neither 0 nor <= -1e4 is the caller's to keep away (attention.pad_is_boolean); a full additive mask is refused
+    from outeffhop_amd._lib import OehError
+    with pytest.raises((OehError, TypeError)):
+        ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, softmax=ops.SoftmaxSpec(1, True, -0.025, 1.1), key_pad_mask=dev(padm), **kkw)
+
+
 def test_int8_storage_indices_match_the_reference_capture(ops):
     """VERDICT r2 next #3a / missing #4: the reference's captured QuantLinear outputs (tests/golden/int8_attn.npz: q_lin / k_lin /
     v_lin of `quantized_opt.py:67-75`, on the captured q_proj / k_proj / v_proj activation grids) are turned into the 8-bit indices

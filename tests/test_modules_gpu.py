@@ -531,10 +531,74 @@ def test_quantised_opt_uses_the_int8_storage_core(oa, monkeypatch):
         err = (a - b_).abs()
         assert float(err.max()) <= 2.05 * step and float((err > 0.5 * step).float().mean()) < 5e-3, (float(err.max()), step)
     assert torch.equal(past8[0], pastf[0]) and torch.equal(past8[1], pastf[1])
-    # a mask with padded keys is not the integer path's: the fake-quant kernels run (no call)
+    # a batch with padded keys (causal + finfo.min columns) runs the integer core too (its key-padding variant), same outputs
+    # as the fake-quant kernels on floats up to rare single steps; a mask that is not causal + padding does not
+    padded = _decoder_mask(B, T, [T, T - 5, T - 40], torch.float32, dev)
     with torch.no_grad():
-        qm(x, attention_mask=_decoder_mask(B, T, [T, T - 5, T], torch.float32, dev))
-    assert len(calls) == 2
+        monkeypatch.setattr(Q, "INT8_STORAGE", True)
+        outp8, _, _ = qm(x, attention_mask=padded)
+        assert len(calls) == 3
+        monkeypatch.setattr(Q, "INT8_STORAGE", False)
+        outpf, _, _ = qm(x, attention_mask=padded)
+        monkeypatch.setattr(Q, "INT8_STORAGE", True)
+        odd = padded.clone()
+        odd[0, 0, 5, 2] = -3.0  # an additive value that is neither 0 nor finfo.min
+        qm(x, attention_mask=odd)
+        assert len(calls) == 3
+    err = (outp8 - outpf).abs()
+    assert float(err.max()) <= 2.05 * step and float((err > 0.5 * step).float().mean()) < 5e-3, (float(err.max()), step)
+
+
+def test_quantised_bert_uses_the_int8_storage_core(oa, monkeypatch):
+    """VERDICT r2 missing #2 / next #5: QuantizedBertSelfAttentionWithExtras (quantized_bert.py:236-238: query / key / value are
+    QuantLinear; :363 scores / sqrt(d) quantised before the mask; :374 probabilities; :434 context quantised AFTER the gate and
+    the head merge) on the integer matrix cores: with and without a key-padding mask, with a per-token gate; same module output
+    as the fake-quant kernels on float values up to rare single steps of the context grid; a fully padded sample gives zeros
+    (softmax_1) on both paths."""
+    from outeffhop_amd import ops, quantization as Q
+
+    torch.manual_seed(22)
+    dev = torch.device("cuda:0")
+    B, T = 4, 80
+
+    class C12:
+        hidden_size, num_attention_heads, attention_probs_dropout_prob, position_embedding_type, is_decoder = 256, 4, 0.0, "absolute", False
+        max_position_embeddings = 512
+
+    for gate in ("nogate", "tok_linear"):
+        org = oa.BertSelfAttentionWithExtras(C12(), softmax_fn=oa.SOFTMAX_MAPPING["softmax1"], **gate_kwargs(gate)).to(dev).eval()
+        qm = oa.QuantizedBertSelfAttentionWithExtras(org, **_qparams(oa)).to(dev).eval()
+        qm.set_quant_state(weight_quant=True, act_quant=True)
+        fmin = torch.finfo(torch.float32).min
+        mask = torch.zeros(B, 1, 1, T, device=dev)
+        mask[1, ..., 61:] = fmin
+        mask[2, ..., 7:] = fmin
+        mask[3] = fmin  # a sample without a single visible key
+        with torch.no_grad():
+            for _ in range(3):
+                qm(torch.randn(B, T, 256, device=dev), attention_mask=mask)
+            qm.fix_ranges()
+            x = torch.randn(B, T, 256, device=dev)
+            calls = []
+            real = ops.attn_fwd_i8
+            monkeypatch.setattr(ops, "attn_fwd_i8", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+            monkeypatch.setattr(Q, "INT8_STORAGE", True)
+            o8 = qm(x, attention_mask=mask)[0]
+            o8n = qm(x)[0]
+            assert len(calls) == 2, "the BERT module did not reach the integer matrix cores"
+            monkeypatch.setattr(Q, "INT8_STORAGE", False)
+            of = qm(x, attention_mask=mask)[0]
+            ofn = qm(x)[0]
+            assert len(calls) == 2
+            monkeypatch.setattr(ops, "attn_fwd_i8", real)
+        step = float(qm.context_act_quantizer.activation_quantizer.quantizer.delta)
+        for a, b_ in ((o8, of), (o8n, ofn)):
+            err = (a - b_).abs()
+            off = float((err > 0.5 * step).float().mean())
+            print(f"quantised BERT [{gate}]: int8-storage core vs fake-quant on floats: max {float(err.max()) / step:.2f} steps, {off:.2e} of the outputs apart")
+            assert float(err.max()) <= 1.05 * step and off < 2e-3, (gate, float(err.max()), step, off)
+        zero_idx = float(qm.context_act_quantizer.activation_quantizer.quantizer.zero_float)
+        assert float(o8[3].abs().max()) <= step * abs(round(zero_idx) - zero_idx) + 1e-6  # softmax_1 of a fully padded row: 0 (on the grid)
 
 
 def test_quantlinear_operand_pair_gemm(oa, monkeypatch):
