@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OEH_ABI_VERSION 3
+#define OEH_ABI_VERSION 4
 
 /* error codes (negative errno style) */
 #define OEH_OK 0
@@ -204,6 +204,30 @@ int oeh_percentile_ema(const void* x, int64_t n, int32_t dtype, double q_lo, dou
  * scale = float32(max(delta, eps)), zero_point = clamp(rint(zero), 0, 2^n_bits - 1)), then y = scale * (idx - zero_point). */
 int oeh_fake_quant_range(const void* x, void* y, int64_t n, int32_t dtype, const double* xmin_xmax, int32_t n_bits, double eps,
                          void* stream);
+
+/* Range estimation of the attention core's activation quantisers WITHOUT materialising the (B,H,Sq,Sk) tensors.  In
+ * Qstates.estimate_ranges the reference hands the whole score tensor and then the whole probability tensor to np.percentile
+ * (range_estimators.py:83-106 from quantized_opt.py:154,182 / quantized_bert.py:363,374; 201 MB each per OPT-125m layer and
+ * batch).  This entry point RECOMPUTES the values tile by tile - fp32 throughout, both products on the fp32 matrix-core
+ * instruction, the elementwise chain in the reference's op order - and feeds them to the exact radix selection of
+ * oeh_percentile_ema, once per selection pass; nothing of size Sq x Sk is stored.  `desc` as for oeh_attn_fwd (dtype
+ * OEH_F16 | OEH_BF16 | OEH_F32, D in {32, 64, 128}, any Sq / Sk, masks key_pad_mask / full_mask / causal, scale or scale_div,
+ * softmax_base, clip; gate fields are ignored):
+ *   which == OEH_CALIB_SCORES : state <- percentile pair [+ running average] of the scaled scores (before quantiser and masks)
+ *   which == OEH_CALIB_PROBS  : scores fake-quantised on the grid of `scores_range` (NULL: not quantised), masks, softmax, clip;
+ *                               state <- percentile pair [+ running average] of the probabilities
+ *   which == OEH_CALIB_CONTEXT: ... probabilities fake-quantised on the grid of `probs_range` (NULL: not), P V -> ctx_out
+ *                               (fp32, o_stride of desc in fp32 elements); no statistics (state / work unused) - the context is
+ *                               small, its quantiser runs oeh_percentile_ema / oeh_fake_quant_range on it
+ * scores_range / probs_range: device double[2] = (x_min, x_max), e.g. the `state` of the previous call; the grids are derived
+ * in the kernel as oeh_fake_quant_range does (n_bits, eps).  q_lo, q_hi, momentum, first, state, work: as oeh_percentile_ema.
+ * No host synchronisation; safe under hipGraph capture. */
+#define OEH_CALIB_SCORES 0
+#define OEH_CALIB_PROBS 1
+#define OEH_CALIB_CONTEXT 2
+int oeh_attn_calibrate(const oeh_attn_desc* desc, const void* q, const void* k, const void* v, float* ctx_out, int32_t which,
+                       const double* scores_range, const double* probs_range, int32_t n_bits, double eps, double q_lo, double q_hi,
+                       double momentum, int32_t first, double* state, void* work, void* stream);
 
 /* The producer side of the INT8-storage attention core (oeh_attn_fwd with dtype OEH_I8): a QuantLinear projection's output
  * quantiser (hijacker.py:78-127; AsymmetricUniformQuantizer.forward, uniform_quantizers.py:119-148) that writes what the core

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OEH_LIB: explicit path of another build of the same library (A/B timing of compiler flags; tools/ only)
 LIB_PATH = os.environ.get("OEH_LIB") or os.path.join(_HERE, "lib", "liboeh_hip.so")
 
-ABI_VERSION = 3  # include/oeh.h: OEH_ABI_VERSION
+ABI_VERSION = 4  # include/oeh.h: OEH_ABI_VERSION
 CALIB_WORK_BYTES = 36864  # include/oeh.h: OEH_CALIB_WORK_BYTES
 OEH_F16, OEH_BF16, OEH_F32, OEH_I8 = 0, 1, 2, 3
 OEH_SOFTMAX_VANILLA, OEH_SOFTMAX_ONE = 0, 1
@@ -60,7 +60,7 @@ class oeh_attn_desc(C.Structure):
 
 # every symbol include/oeh.h declares (tests/test_abi.py checks the .so exports exactly these)
 EXPORTS = (
-    "oeh_attn_fwd", "oeh_softmax_rows", "oeh_fake_quant", "oeh_gate_fwd", "oeh_minmax", "oeh_percentile_ema", "oeh_fake_quant_range", "oeh_quantize_heads_i8", "oeh_split_pairs", "oeh_split_triples",
+    "oeh_attn_fwd", "oeh_softmax_rows", "oeh_fake_quant", "oeh_gate_fwd", "oeh_minmax", "oeh_percentile_ema", "oeh_fake_quant_range", "oeh_attn_calibrate", "oeh_quantize_heads_i8", "oeh_split_pairs", "oeh_split_triples",
     "oeh_abi_version", "oeh_build_info", "oeh_strerror", "oeh_attn_variant",
 )
 
@@ -99,6 +99,8 @@ def load() -> C.CDLL:
     lib.oeh_percentile_ema.restype = C.c_int
     lib.oeh_fake_quant_range.argtypes = [vp, vp, i64, i32, vp, i32, f64, vp]
     lib.oeh_fake_quant_range.restype = C.c_int
+    lib.oeh_attn_calibrate.argtypes = [C.POINTER(oeh_attn_desc), vp, vp, vp, vp, i32, vp, vp, i32, f64, f64, f64, f64, i32, vp, vp, vp]
+    lib.oeh_attn_calibrate.restype = C.c_int
     lib.oeh_quantize_heads_i8.argtypes = [vp, vp, vp, i64, i32, i32, C.POINTER(i64), C.POINTER(i64), i32, f32, f32, i32, f32, vp, vp]
     lib.oeh_quantize_heads_i8.restype = C.c_int
     lib.oeh_split_pairs.argtypes = [vp, vp, i64, i32, i64, vp]

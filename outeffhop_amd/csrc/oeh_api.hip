@@ -30,6 +30,8 @@ int launch_minmax(const void* x, long n, int in, float* out2, hipStream_t st);
 int launch_percentile_ema(const void* x, long n, int in, double q_lo, double q_hi, double momentum, int first, double* state, void* work,
                           hipStream_t st);
 int launch_fake_quant_range(const void* x, void* y, long n, int in, const double* range, float qmax, double eps, hipStream_t st);
+int launch_attn_calibrate(const AttnParams& P, int in, int which, const double* s_range, const double* p_range, float qmax, double eps, double q_lo,
+                          double q_hi, double momentum, int first, double* state, void* work, hipStream_t st);
 int launch_split_pairs(const float* x, void* out, long rows, int K, long x_sr, hipStream_t st);
 int launch_split_triples(const float* x, void* out, long rows, int K, long x_sr, hipStream_t st);
 int launch_quantize_heads_i8(const void* x, signed char* out, void* y, long B, int S, int H, long x_sb, long x_ss, long y_sb, long y_ss, int in,
@@ -437,6 +439,31 @@ int oeh_fake_quant_range(const void* x, void* y, int64_t n, int32_t dtype, const
   if (x == nullptr || y == nullptr || xmin_xmax == nullptr || n < 0 || !dtype_ok(dtype) || n_bits < 1 || n_bits > 16 || !(eps > 0.0)) return OEH_EINVAL;
   if (n == 0) return OEH_OK;
   return oeh::launch_fake_quant_range(x, y, n, dtype, xmin_xmax, (float)((1 << n_bits) - 1), eps, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oeh_attn_calibrate(const oeh_attn_desc* desc, const void* q, const void* k, const void* v, float* ctx_out, int32_t which,
+                       const double* scores_range, const double* probs_range, int32_t n_bits, double eps, double q_lo, double q_hi,
+                       double momentum, int32_t first, double* state, void* work, void* stream) {
+  if (desc == nullptr || q == nullptr || k == nullptr) return OEH_EINVAL;
+  if (which < OEH_CALIB_SCORES || which > OEH_CALIB_CONTEXT || n_bits < 1 || n_bits > 16 || !(eps > 0.0)) return OEH_EINVAL;
+  if (which == OEH_CALIB_CONTEXT ? (v == nullptr || ctx_out == nullptr) : (state == nullptr || work == nullptr)) return OEH_EINVAL;
+  if (desc->B <= 0 || desc->H <= 0 || desc->Sq <= 0 || desc->Sk <= 0 || !dtype_ok(desc->dtype)) return OEH_EINVAL;
+  if (desc->softmax_base != OEH_SOFTMAX_VANILLA && desc->softmax_base != OEH_SOFTMAX_ONE) return OEH_EINVAL;
+  if (desc->key_pad_mask != nullptr && desc->key_pad_dtype != OEH_F16 && desc->key_pad_dtype != OEH_F32) return OEH_EINVAL;
+  if (desc->full_mask != nullptr && desc->full_mask_dtype != OEH_F16 && desc->full_mask_dtype != OEH_F32) return OEH_EINVAL;
+  if (!(desc->D == 32 || desc->D == 64 || desc->D == 128)) return OEH_ENOTSUP;
+  if (which != OEH_CALIB_CONTEXT) {
+    if (!(q_lo >= 0.0 && q_lo <= 100.0 && q_hi >= 0.0 && q_hi <= 100.0) || !(momentum >= 0.0 && momentum <= 1.0)) return OEH_EINVAL;
+    if ((int64_t)desc->B * desc->H * desc->Sq * desc->Sk >= ((int64_t)1 << 32)) return OEH_ENOTSUP;
+    if ((reinterpret_cast<uintptr_t>(work) & 7) != 0 || (reinterpret_cast<uintptr_t>(state) & 7) != 0) return OEH_EALIGN;
+  }
+  const int eb = elem_bytes(desc->dtype);
+  if (!aligned16(q, desc->q_stride, eb) || !aligned16(k, desc->k_stride, eb)) return OEH_EALIGN;
+  if (which == OEH_CALIB_CONTEXT && (!aligned16(v, desc->v_stride, eb) || !aligned16(ctx_out, desc->o_stride, 4))) return OEH_EALIGN;
+  AttnParams P;
+  fill_params(P, desc, q, k, v, ctx_out, nullptr);
+  return oeh::launch_attn_calibrate(P, desc->dtype, which, scores_range, probs_range, (float)((1 << n_bits) - 1), eps, q_lo, q_hi, momentum, first ? 1 : 0,
+                                    state, work, reinterpret_cast<hipStream_t>(stream));
 }
 
 int oeh_quantize_heads_i8(const void* x, int8_t* out, void* y, int64_t B, int32_t S, int32_t H, const int64_t x_stride[2], const int64_t y_stride[2],

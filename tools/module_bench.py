@@ -101,10 +101,19 @@ def quantised():
             qm(torch.randn(B, S, E, device=dev), attention_mask=mask)  # calibration batches (percentile 99.999 + running average, on the device)
         torch.cuda.synchronize()
         print(f"calibration: 2 batches in {(time.perf_counter() - t0) * 1e3:.1f} ms (incl. first-call overheads)")
-        t0 = time.perf_counter()
-        qm(torch.randn(B, S, E, device=dev), attention_mask=mask)
-        torch.cuda.synchronize()
-        print(f"calibration: one more batch {(time.perf_counter() - t0) * 1e3:.1f} ms")
+        for fused in (True, False):  # estimate_ranges: oeh_attn_calibrate (no (B,H,S,S) tensors) vs the observable path (materialised)
+            Q.FUSED_CALIBRATION = fused
+            xs = [torch.randn(B, S, E, device=dev) for _ in range(3)]
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            t0 = time.perf_counter()
+            for x_ in xs:
+                qm(x_, attention_mask=mask)
+            torch.cuda.synchronize()
+            print(f"calibration, {'in-kernel statistics (oeh_attn_calibrate)' if fused else 'materialised score tensors':42s}: "
+                  f"{(time.perf_counter() - t0) * 1e3 / 3:.2f} ms per batch, peak extra memory {(torch.cuda.max_memory_allocated() - base) / 1e6:.0f} MB")
+        Q.FUSED_CALIBRATION = True
         qm.fix_ranges()
         x = torch.randn(B, S, E, device=dev)
         for i8 in (False, True):
