@@ -116,6 +116,8 @@ bool is_pow2(float x) {
 // multiplicative scale (a power-of-two divisor is the same multiply, exactly); fake-quant is its FQ variant.
 bool fast_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
   if (d->dtype == OEH_F32 || d->full_mask != nullptr) return false;
+  // the LDS-DMA streams address a tile as scalar base + 32-bit lane byte offsets (up to 64 rows of the sequence stride)
+  if (d->q_stride[2] >= (1 << 24) || d->k_stride[2] >= (1 << 24) || d->v_stride[2] >= (1 << 24) || d->q_stride[2] < 0 || d->k_stride[2] < 0 || d->v_stride[2] < 0) return false;
   if (any_fq(fq)) {  // the FQ variant: scores and probabilities both quantised (the reference's configuration), no in-kernel predictor
     if (!(fq->scores.enable && fq->probs.enable) || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
     if (fq->scores.dump_idx != nullptr || fq->probs.dump_idx != nullptr || fq->ctx.dump_idx != nullptr) return false;  // test-only dumps: general kernel

@@ -92,31 +92,30 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   // K rows past Sk are redirected to row Sk - 1, V^T chunks past Sk to the last one (finite data, probability 0).
   const unsigned koff = (unsigned)(prow * (int)P.ks_s + (pch ^ perm4(prow >> 4)) * 16);
   const unsigned voff = (unsigned)(prow * (int)P.vs_s + (pch ^ perm4(prow >> 2)) * 16);
+  // the lane offsets of the ragged LAST tile (Sk not a multiple of 64), formed once: K rows past Sk -> row Sk - 1, V^T chunks past
+  // Sk -> the last chunk; a request then costs one select on a wave-uniform condition, no per-lane arithmetic
+  unsigned koff_tail = koff, voff_tail = voff;
+  {
+    const int t_last = (Sk - 1) >> 6;
+    const int over_k = 64 * t_last + prow - (Sk - 1);
+    if (over_k > 0) koff_tail -= (unsigned)(over_k * (int)P.ks_s);
+    const int over_v = 4 * t_last + (pch ^ perm4(prow >> 2)) - ((Sk >> 4) - 1);  // (Sk is a multiple of 16: host)
+    if (over_v > 0) voff_tail -= 16u * (unsigned)over_v;
+  }
   const signed char* kcur = kbase;
   const signed char* vcur = vbase;
   const int kstep = 64 * (int)P.ks_s;
-  const int last_chunk = (Sk >> 4) - 1;  // (Sk is a multiple of 16: host)
   int nx = 0, nx_slot = 0;
   auto issue_next = [&]() {
     const bool isv = nx >= n_kt;
     const int t = isv ? nx - n_kt : nx;
     const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(((isv ? R : 0) + nx_slot) * TILEB + wave * 1024));
-    const bool tail = 64 * t + 64 > Sk;  // wave-uniform
+    const bool tail = 64 * t + 64 > Sk;  // wave-uniform: only the last tile of a ragged Sk
     if (isv) {
-      unsigned vo = voff;
-      if (tail) {
-        const int over = 4 * t + (pch ^ perm4(prow >> 2)) - last_chunk;
-        if (over > 0) vo -= 16u * (unsigned)over;
-      }
-      glds16_s(vcur, vo, slot);
+      glds16_s(vcur, tail ? voff_tail : voff, slot);
       vcur += 64;
     } else {
-      unsigned ko = koff;
-      if (tail) {
-        const int over = 64 * t + prow - (Sk - 1);
-        if (over > 0) ko -= (unsigned)(over * (int)P.ks_s);
-      }
-      glds16_s(kcur, ko, slot);
+      glds16_s(kcur, tail ? koff_tail : koff, slot);
       kcur += kstep;
     }
     ++nx;
