@@ -297,6 +297,8 @@ void fill_params(AttnParams& P, const oeh_attn_desc* d, const void* q, const voi
   P.nQT = (d->Sq + 63) / 64;
   P.nBH = d->B * d->H;
   P.nBHpad = (P.nBH + 7) & ~7;
+  P.magic_nbh = (unsigned)(0x100000000ULL / (unsigned long long)P.nBHpad > 0xffffffffULL ? 0xffffffffULL : 0x100000000ULL / (unsigned long long)P.nBHpad);
+  P.magic_h = (unsigned)(0x100000000ULL / (unsigned long long)P.H > 0xffffffffULL ? 0xffffffffULL : 0x100000000ULL / (unsigned long long)P.H);
   // Causal tiles strictly above the diagonal contribute exactly 0 to P@V (and nothing to the row statistics)
   // and may be skipped when: masked probabilities are exactly 0 before the clip and the clip maps 0 to 0
   // (gamma <= 0); the row can never be fully masked under vanilla softmax (which would make it uniform over
@@ -354,6 +356,7 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
     P.i8_k1 = (float)((double)desc->q_grid.scale * (double)desc->k_grid.scale * mult / (double)fq->scores.scale);
     P.i8_so = (float)((double)fq->probs.scale * (double)desc->v_grid.scale);
     P.nBHpad = (P.nBH + 15) & ~15;  // head pairs on one XCD (oeh_attn_i8.hip)
+    P.magic_nbh = (unsigned)(0x100000000ULL / (unsigned long long)P.nBHpad);
     return oeh::launch_attn_i8(P, desc->o_dtype, st);
   }
   if (var == V_FLASH) {

@@ -87,12 +87,23 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
   __shared__ __attribute__((aligned(16))) unsigned char lds[RINGB + NT * 16 * 4];
   float* lds_pad = reinterpret_cast<float*>(lds + RINGB);
 
+  // The kernel arguments the prologue needs, requested in ONE round of scalar loads at entry (the compiler loads an argument where it
+  // is first used: several dependent rounds of ~300 cycles each in front of the first LDS-DMA request, on every wave), and the
+  // block id decoded without integer divisions (oeh_common.h: div_magic): 15.43 -> 14.80 us on the headline launch of the one-pass
+  // kernel, same treatment here.
+  if constexpr (!SRC32) {
+    asm volatile("" ::"s"(P.q), "s"(P.k), "s"(P.v), "s"(P.nBHpad), "s"(P.nQT), "s"(P.nBH), "s"(P.H), "s"(P.Sq), "s"(P.Sk), "s"(P.skip_ok),
+                 "s"(P.magic_nbh), "s"(P.magic_h), "s"(P.qs_b), "s"(P.qs_h), "s"(P.qs_s), "s"(P.ks_b), "s"(P.ks_h), "s"(P.ks_s), "s"(P.vs_b), "s"(P.vs_h),
+                 "s"(P.vs_s), "s"(P.stamps), "s"(P.pad));
+  }
   const int bid = blockIdx.x;  // (snake_block_id measured 3-4 % slower here: 8 q tiles per head, not all workgroups resident)
   int qt_rev, bh;
-  block_to_tile(bid, P.nBHpad, P.nQT, SRC32 ? P.head_major : 0, qt_rev, bh);
+  if (SRC32 && P.head_major) block_to_tile(bid, P.nBHpad, P.nQT, P.head_major, qt_rev, bh);
+  else div_magic((unsigned)bid, (unsigned)P.nBHpad, P.magic_nbh, qt_rev, bh);
   if (bh >= P.nBH) return;
   const int qt = P.nQT - 1 - qt_rev;
-  const int b = bh / P.H, h = bh - b * P.H;
+  int b, h;
+  div_magic((unsigned)bh, (unsigned)P.H, P.magic_h, b, h);
 
   if constexpr (SRC32) fp16_overflow_clamp();  // out-of-range fp32 operands saturate (oeh_common.h)
   const int tid = threadIdx.x;

@@ -87,11 +87,20 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   __shared__ __attribute__((aligned(16))) float lds_padrow[PAD ? PADROW : 4];
   __shared__ int lds_last[4];
 
-  const int bid = (P.snake && !(SRC32 && P.head_major)) ? snake_block_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  // The kernel arguments the prologue needs, requested in ONE round of scalar loads at entry (the compiler loads an argument where it
+  // is first used: four dependent rounds of ~300 cycles each in front of the first LDS-DMA request, every wave of every workgroup).
+  if constexpr (!SRC32) {
+    asm volatile("" ::"s"(P.q), "s"(P.k), "s"(P.v), "s"(P.nBHpad), "s"(P.nQT), "s"(P.nBH), "s"(P.H), "s"(P.Sq), "s"(P.Sk), "s"(P.causal), "s"(P.snake),
+                 "s"(P.magic_nbh), "s"(P.magic_h), "s"(P.qs_b), "s"(P.qs_h), "s"(P.qs_s), "s"(P.ks_b), "s"(P.ks_h), "s"(P.ks_s), "s"(P.vs_b), "s"(P.vs_h),
+                 "s"(P.vs_s), "s"(P.stamps));
+  }
+  const int bid = (P.snake && !(SRC32 && P.head_major)) ? snake_block_id(blockIdx.x, P.nQT * P.nBHpad) : (int)blockIdx.x;  // (= gridDim.x, without the hidden-argument load)
   int qt_rev, bh;
-  block_to_tile(bid, P.nBHpad, P.nQT, SRC32 ? P.head_major : 0, qt_rev, bh);
+  if (SRC32 && P.head_major) block_to_tile(bid, P.nBHpad, P.nQT, P.head_major, qt_rev, bh);
+  else div_magic((unsigned)bid, (unsigned)P.nBHpad, P.magic_nbh, qt_rev, bh);
   if (bh >= P.nBH) return;
-  const int b = bh / P.H, h = bh - b * P.H;
+  int b, h;
+  div_magic((unsigned)bh, (unsigned)P.H, P.magic_h, b, h);
 
   if constexpr (SRC32) fp16_overflow_clamp();  // out-of-range fp32 operands saturate (oeh_common.h)
   const int tid = threadIdx.x;

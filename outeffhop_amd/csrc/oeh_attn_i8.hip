@@ -59,16 +59,22 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   // vanilla softmax is uniform over the Sk keys, as in the reference): rel = min(rel, flag), one instruction per element
   __shared__ __attribute__((aligned(16))) float lds_pad[PAD ? NT * 16 : 4];
 
+  // (kernel arguments of the prologue in one round of scalar loads, block id decoded without integer divisions: oeh_attn_fast.inl)
+  asm volatile("" ::"s"(P.q), "s"(P.k), "s"(P.v), "s"(P.nBHpad), "s"(P.nQT), "s"(P.nBH), "s"(P.H), "s"(P.Sq), "s"(P.Sk), "s"(P.skip_ok), "s"(P.causal),
+               "s"(P.magic_nbh), "s"(P.magic_h), "s"(P.qs_b), "s"(P.qs_h), "s"(P.qs_s), "s"(P.ks_b), "s"(P.ks_h), "s"(P.ks_s), "s"(P.vs_b), "s"(P.vs_h),
+               "s"(P.vs_s), "s"(P.i8_cq), "s"(P.i8_ck), "s"(P.i8_k1));
   const int bid = blockIdx.x;
-  const int qt_rev = bid / P.nBHpad;
+  int qt_rev, bhr_;
+  div_magic((unsigned)bid, (unsigned)P.nBHpad, P.magic_nbh, qt_rev, bhr_);
   // Blocks b and b + 8 run on one XCD.  In the (B,S,H*64) int8 layout two neighbouring heads share every 128-byte line
   // of q and k, so heads 2i and 2i+1 are given block ids 8 apart (nBHpad is a multiple of 16): the second half of a line is
   // an L2 hit instead of a second HBM fetch (57 -> 4x MB per launch on the OPT shape against 44 MB algorithmic).
-  const int bhr = bid - qt_rev * P.nBHpad;
+  const int bhr = bhr_;
   const int bh = (bhr & ~15) | ((bhr & 7) << 1) | ((bhr >> 3) & 1);
   if (bh >= P.nBH) return;
   const int qt = P.nQT - 1 - qt_rev;
-  const int b = bh / P.H, h = bh - b * P.H;
+  int b, h;
+  div_magic((unsigned)bh, (unsigned)P.H, P.magic_h, b, h);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;

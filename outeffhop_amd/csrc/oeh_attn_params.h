@@ -44,6 +44,7 @@ struct AttnParams {
   // launch geometry
   int nQT;                    // q tiles (64 rows) per (b,h)
   int nBH, nBHpad;            // B*H and B*H rounded up to a multiple of 8 (XCD affinity of a head's q tiles)
+  unsigned magic_nbh, magic_h;  // floor(2^32 / nBHpad), floor(2^32 / H): block id -> (q tile, batch, head) without integer divisions (oeh_common.h: div_magic)
   int skip_ok;                // causal tiles above the diagonal may be skipped (see oeh_api.hip)
   int head_major;             // fp32-storage kernels: block order in groups of this many heads (0 = all heads' heaviest q tiles first;
                               // oeh_common.h: block_to_tile)

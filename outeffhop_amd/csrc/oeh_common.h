@@ -276,6 +276,17 @@ __device__ __forceinline__ int snake_block_id(int bid, const int nblocks) {
   return bid;
 }
 
+// n / d and n % d for a wave-uniform n < 2^31 with m = floor(2^32 / d) from the host: the product's high word is the quotient or one
+// below it, one correction step makes it exact (an integer division is ~30 scalar instructions and a v_rcp round trip, and the
+// kernels do two of them before they can issue their first load).
+__device__ __forceinline__ void div_magic(const unsigned n, const unsigned d, const unsigned m, int& q, int& r) {
+  unsigned qq = __umulhi(n, m);
+  unsigned rr = n - qq * d;
+  if (rr >= d) { qq += 1u; rr -= d; }
+  q = (int)qq;
+  r = (int)rr;
+}
+
 // Block id -> (position of the q tile in the head's heaviest-first list, head).  Plain (group = 0): all heads' heaviest q
 // tiles first, id = qt_rev * nBHpad + head.  Grouped: the heads in groups of `group` (a multiple of 8: blocks b and b + 8 share
 // an XCD, so a head keeps its XCD), heaviest q tiles first INSIDE a group - id = (head / group) * group * nQT + qt_rev * group
