@@ -88,6 +88,13 @@ int validate(const oeh_attn_desc* d, const void* q, const void* k, const void* v
       if (!(ss[i] > 0.0f) || !(zs[i] >= 0.0f && zs[i] <= 255.0f) || zs[i] != std::nearbyint(zs[i])) return OEH_EINVAL;
   }
   if (d->softmax_base != OEH_SOFTMAX_VANILLA && d->softmax_base != OEH_SOFTMAX_ONE) return OEH_EINVAL;
+  {  // strides are element counts in [0, 2^32): the kernels form batch / head offsets from 32-bit products (views with negative
+     // strides are not a layout any caller of the reference produces)
+    const int64_t* sts[4] = {d->q_stride, d->k_stride, d->v_stride, d->o_stride};
+    for (const int64_t* st : sts)
+      for (int i = 0; i < 3; ++i)
+        if (st[i] < 0 || st[i] >= ((int64_t)1 << 32)) return OEH_ENOTSUP;
+  }
   if (d->key_pad_mask != nullptr && d->key_pad_dtype != OEH_F16 && d->key_pad_dtype != OEH_F32) return OEH_EINVAL;
   if (d->full_mask != nullptr && d->full_mask_dtype != OEH_F16 && d->full_mask_dtype != OEH_F32) return OEH_EINVAL;
   if (d->gate == nullptr && d->gate_hidden != nullptr) {

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
   if constexpr (!SRC32) {
     asm volatile("" ::"s"(P.q), "s"(P.k), "s"(P.v), "s"(P.nBHpad), "s"(P.nQT), "s"(P.nBH), "s"(P.H), "s"(P.Sq), "s"(P.Sk), "s"(P.skip_ok),
                  "s"(P.magic_nbh), "s"(P.magic_h), "s"(P.qs_b), "s"(P.qs_h), "s"(P.qs_s), "s"(P.ks_b), "s"(P.ks_h), "s"(P.ks_s), "s"(P.vs_b), "s"(P.vs_h),
-                 "s"(P.vs_s), "s"(P.stamps), "s"(P.pad));
+                 "s"(P.vs_s), "s"(P.pad));
   }
   const int bid = blockIdx.x;  // (snake_block_id measured 3-4 % slower here: 8 q tiles per head, not all workgroups resident)
   int qt_rev, bh;
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
   const int T = 2 * n_kt;  // tiles in the K-then-V stream
 
   // ---- LDS-DMA source addressing: lane -> (row inside the piece, swizzled chunk)
-  const unsigned short* kbase = reinterpret_cast<const unsigned short*>(P.k) + (long)b * P.ks_b + (long)h * P.ks_h;
-  const unsigned short* vbase = reinterpret_cast<const unsigned short*>(P.v) + (long)b * P.vs_b + (long)h * P.vs_h;
+  const unsigned short* kbase = reinterpret_cast<const unsigned short*>(P.k) + bh_offset(b, P.ks_b, h, P.ks_h);
+  const unsigned short* vbase = reinterpret_cast<const unsigned short*>(P.v) + bh_offset(b, P.vs_b, h, P.vs_h);
   // Per-lane source offsets of this wave's G pieces inside a tile (row of the piece, swizzled 16-B chunk); a tile
   // further on is +64 rows.  Rows past Sk (last tile only) are redirected to row Sk-1.
   const int prow = lane / CPR, pch = lane % CPR;
@@ -166,12 +166,16 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
     }
   };
 
-  unsigned long long* stamp = nullptr;  // diagnostic builds of tools/timeline.py only
+#ifdef OEH_TIMELINE  // diagnostic build of tools/timeline.py only (see oeh_attn_flash.inl)
+  unsigned long long* stamp = nullptr;
   if (P.stamps != nullptr) stamp = P.stamps + ((long)bid * 4 + wave) * 32;
 #define OEH_STAMP(slot)                                                                               \
   do {                                                                                                \
     if (stamp != nullptr && lane == 0) stamp[(slot)] = __builtin_amdgcn_s_memtime();                  \
   } while (0)
+#else
+#define OEH_STAMP(slot) do { } while (0)
+#endif
   OEH_STAMP(0);
   // ---- Q rides the LDS-DMA stream, first, as a K-shaped tile in the V ring's last slot (first used by V tile R-1, long
   // after the operands below are in registers): the bytes in front of the first MFMA are Q + K tile 0, requested together,
@@ -181,8 +185,8 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
     if constexpr (SRC32) {
       const bool isv = i >= n_kt;
       const int t = isv ? i - n_kt : i;
-      const float* src = isv ? reinterpret_cast<const float*>(P.v) + (long)b * P.vs_b + (long)h * P.vs_h
-                             : reinterpret_cast<const float*>(P.k) + (long)b * P.ks_b + (long)h * P.ks_h;
+      const float* src = isv ? reinterpret_cast<const float*>(P.v) + bh_offset(b, P.vs_b, h, P.vs_h)
+                             : reinterpret_cast<const float*>(P.k) + bh_offset(b, P.ks_b, h, P.ks_h);
       const long srow = isv ? P.vs_s : P.ks_s;
 #pragma unroll
       for (int j = 0; j < G; ++j) {
@@ -210,13 +214,13 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
   u4 qf[KS], ql[SRC32 ? KS : 1];  // Q^T operands of this lane's query row (SRC32: the hi / lo pair)
   if constexpr (SRC32) {  // Q: global -> registers in the operand layout (row q0 + c, elements 32 ks + 8 g ..), no LDS round trip
     const int qr = min(qrow, P.Sq - 1);  // rows past Sq: finite data, never stored
-    const float* qp = reinterpret_cast<const float*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h + (long)qr * P.qs_s + 8 * g;
+    const float* qp = reinterpret_cast<const float*>(P.q) + bh_offset(b, P.qs_b, h, P.qs_h) + (long)qr * P.qs_s + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
       split8(__builtin_nontemporal_load(reinterpret_cast<const f4*>(qp + 32 * ks)), __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp + 32 * ks + 4)), qf[ks], ql[ks]);
     load_tile(0);
   } else {
-    const unsigned short* qbase = reinterpret_cast<const unsigned short*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h;
+    const unsigned short* qbase = reinterpret_cast<const unsigned short*>(P.q) + bh_offset(b, P.qs_b, h, P.qs_h);
     const unsigned qslot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((2 * R - 1) * TILEB + wave * G * 1024));
 #pragma unroll
     for (int j = 0; j < G; ++j) {
@@ -784,7 +788,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
     }
     if constexpr (OUT32) {  // fp32 output straight from the accumulators (fp32 storage)
       if (q0 + ce < P.Sq)
-        store_wt16(reinterpret_cast<float*>(P.o) + (long)b * P.os_b + (long)h * P.os_h + (long)(q0 + ce) * P.os_s + 16 * dt + 4 * ge,
+        store_wt16(reinterpret_cast<float*>(P.o) + bh_offset(b, P.os_b, h, P.os_h) + (long)(q0 + ce) * P.os_s + 16 * dt + 4 * ge,
                    u4{f32_bits(ov[0]), f32_bits(ov[1]), f32_bits(ov[2]), f32_bits(ov[3])});
     } else {
     u2 w;
@@ -800,7 +804,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes, before it reads them back
   if constexpr (!OUT32) {
-    unsigned short* obase = reinterpret_cast<unsigned short*>(P.o) + (long)b * P.os_b + (long)h * P.os_h;
+    unsigned short* obase = reinterpret_cast<unsigned short*>(P.o) + bh_offset(b, P.os_b, h, P.os_h);
     const int lr = lane_e / CPR, lc = lane_e % CPR;
     static_assert(16 % RPP == 0 || RPP % 16 == 0, "store passes tile the 16-row block");
 #pragma unroll

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   if constexpr (!SRC32) {
     asm volatile("" ::"s"(P.q), "s"(P.k), "s"(P.v), "s"(P.nBHpad), "s"(P.nQT), "s"(P.nBH), "s"(P.H), "s"(P.Sq), "s"(P.Sk), "s"(P.causal), "s"(P.snake),
                  "s"(P.magic_nbh), "s"(P.magic_h), "s"(P.qs_b), "s"(P.qs_h), "s"(P.qs_s), "s"(P.ks_b), "s"(P.ks_h), "s"(P.ks_s), "s"(P.vs_b), "s"(P.vs_h),
-                 "s"(P.vs_s), "s"(P.stamps));
+                 "s"(P.vs_s));
   }
   const int bid = (P.snake && !(SRC32 && P.head_major)) ? snake_block_id(blockIdx.x, P.nQT * P.nBHpad) : (int)blockIdx.x;  // (= gridDim.x, without the hidden-argument load)
   int qt_rev, bh;
@@ -129,7 +129,10 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     tm0[j] = ((causal ? min(rb[j] + off, Sk - 1) : Sk - 1) + 1) >> 6;
   }
 
-  unsigned long long* stamp = nullptr;  // diagnostic runs of tools/timeline.py only
+  // In-kernel stamps exist only in the diagnostic build of tools/timeline.py (make ... EXTRA=-DOEH_TIMELINE): even a never-taken
+  // `if (stamp != nullptr)` per site is a scalar compare + branch on every wave's critical path (three sites per tile).
+#ifdef OEH_TIMELINE
+  unsigned long long* stamp = nullptr;
   if (P.stamps != nullptr) stamp = P.stamps + ((long)bid * 4 + wave) * 32;
 #define OEH_STAMP(slot)                                                                \
   do {                                                                                 \
@@ -140,11 +143,14 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     stamp[30] = __builtin_amdgcn_s_memrealtime();
     stamp[29] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
   }
+#else
+#define OEH_STAMP(slot) do { } while (0)
+#endif
 
   // ---- LDS-DMA stream of (K tile, V tile) stages, strictly in order: the scalar base pointers advance by 64 rows per
   // stage, the per-lane byte offsets (row of the piece, swizzled 16-B chunk) never change
-  const unsigned char* const kbase0 = reinterpret_cast<const unsigned char*>(P.k) + 2 * ((long)b * P.ks_b + (long)h * P.ks_h);
-  const unsigned char* const vbase0 = reinterpret_cast<const unsigned char*>(P.v) + 2 * ((long)b * P.vs_b + (long)h * P.vs_h);
+  const unsigned char* const kbase0 = reinterpret_cast<const unsigned char*>(P.k) + 2 * (bh_offset(b, P.ks_b, h, P.ks_h));
+  const unsigned char* const vbase0 = reinterpret_cast<const unsigned char*>(P.v) + 2 * (bh_offset(b, P.vs_b, h, P.vs_h));
   const unsigned char* kcur = kbase0;
   const unsigned char* vcur = vbase0;
   const int prow = lane / CPR, pch = lane % CPR;
@@ -192,8 +198,8 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   f4 kreg[SRC32 ? G : 1][2], vreg[SRC32 ? G : 1][2];
   auto load_regs = [&](const int t) {
     if constexpr (SRC32) {
-      const float* ksrc = reinterpret_cast<const float*>(P.k) + (long)b * P.ks_b + (long)h * P.ks_h;
-      const float* vsrc = reinterpret_cast<const float*>(P.v) + (long)b * P.vs_b + (long)h * P.vs_h;
+      const float* ksrc = reinterpret_cast<const float*>(P.k) + bh_offset(b, P.ks_b, h, P.ks_h);
+      const float* vsrc = reinterpret_cast<const float*>(P.v) + bh_offset(b, P.vs_b, h, P.vs_h);
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         const int row = piece_row(j);
@@ -227,14 +233,14 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
 #pragma unroll
     for (int j = 0; j < MQ; ++j) {
       const int qr = min(rb[j] + c, Sq - 1);  // rows past Sq: finite data, never stored
-      const float* qp = reinterpret_cast<const float*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h + (long)qr * P.qs_s + 8 * g;
+      const float* qp = reinterpret_cast<const float*>(P.q) + bh_offset(b, P.qs_b, h, P.qs_h) + (long)qr * P.qs_s + 8 * g;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         split8(__builtin_nontemporal_load(reinterpret_cast<const f4*>(qp + 32 * ks)), __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp + 32 * ks + 4)), qf[j][ks], ql[j][ks]);
     }
     load_regs(0);
   } else {
-    const unsigned char* qbase = reinterpret_cast<const unsigned char*>(P.q) + 2 * ((long)b * P.qs_b + (long)h * P.qs_h);
+    const unsigned char* qbase = reinterpret_cast<const unsigned char*>(P.q) + 2 * (bh_offset(b, P.qs_b, h, P.qs_h));
     const unsigned qslot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((R - 1) * STAGEB + wave * G * 1024));
 #pragma unroll
     for (int t = 0; t < MQ; ++t) {
@@ -269,6 +275,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     issue_next();
     if (!GATE && 1 < n_kt) issue_next();
   }
+
   if constexpr (GATE) {  // weights: hidden unit 16 tau + c, inputs 8g.. of each 32-wide k-step; b1 / w2 of units 16 tau + 4g..4g+3
     const int mm = P.g_units > 0 ? P.g_units : 1;  // <= 64 (host)
     g_mt = (mm + 15) >> 4;
@@ -806,7 +813,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     };
     if constexpr (OUT32) {  // fp32 output straight from the accumulators (fp32 storage): 16 B per lane, 64 B per row and instruction
       if (qrow < Sq) {
-        float* orow = reinterpret_cast<float*>(P.o) + (long)b * P.os_b + (long)h * P.os_h + (long)qrow * P.os_s + 4 * ge;
+        float* orow = reinterpret_cast<float*>(P.o) + bh_offset(b, P.os_b, h, P.os_h) + (long)qrow * P.os_s + 4 * ge;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           f4 ov;
@@ -832,7 +839,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes, before it reads them back
   if constexpr (!OUT32) {
-    unsigned short* obase = reinterpret_cast<unsigned short*>(P.o) + (long)b * P.os_b + (long)h * P.os_h;
+    unsigned short* obase = reinterpret_cast<unsigned short*>(P.o) + bh_offset(b, P.os_b, h, P.os_h);
     const int lr = lane_e / CPR, lc = lane_e % CPR;
     static_assert(16 % RPP == 0, "a store pass stays inside one query block");
 #pragma unroll
@@ -844,7 +851,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     }
   }
   OEH_STAMP(3);
+#ifdef OEH_TIMELINE
   if (stamp != nullptr && lane == 0) stamp[31] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 #undef OEH_STAMP
 

@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   const int T = 2 * n_kt;
 
   // ---- LDS-DMA stream, K tiles then V^T tiles, one 1-KiB piece per wave and tile: lane -> (row of the piece, 16-B chunk)
-  const signed char* kbase = reinterpret_cast<const signed char*>(P.k) + (long)b * P.ks_b + (long)h * P.ks_h;
-  const signed char* vbase = reinterpret_cast<const signed char*>(P.v) + (long)b * P.vs_b + (long)h * P.vs_h;
+  const signed char* kbase = reinterpret_cast<const signed char*>(P.k) + bh_offset(b, P.ks_b, h, P.ks_h);
+  const signed char* vbase = reinterpret_cast<const signed char*>(P.v) + bh_offset(b, P.vs_b, h, P.vs_h);
   const int prow = wave * 16 + (lane >> 2), pch = lane & 3;
   const unsigned lds_base = lds_offset(lds);
   // scalar base + constant per-lane byte offset (oeh_common.h: glds16_s): the bases advance by one tile per request, nothing
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   // ---- Q: global -> registers in the B-operand layout (query q0 + c, head dims 16 g ..), and its row sum
   i4 qf;
   {
-    const signed char* qp = reinterpret_cast<const signed char*>(P.q) + (long)b * P.qs_b + (long)h * P.qs_h + (long)min(qrow, P.Sq - 1) * P.qs_s + 16 * g;
+    const signed char* qp = reinterpret_cast<const signed char*>(P.q) + bh_offset(b, P.qs_b, h, P.qs_h) + (long)min(qrow, P.Sq - 1) * P.qs_s + 16 * g;
     qf = *reinterpret_cast<const i4*>(qp);
   }
   const int ones = 0x01010101;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
     }
     if constexpr (OUT32) {
       if (q0 + ce < P.Sq)
-        store_wt16(reinterpret_cast<float*>(P.o) + (long)b * P.os_b + (long)h * P.os_h + (long)(q0 + ce) * P.os_s + 16 * dt + 4 * ge,
+        store_wt16(reinterpret_cast<float*>(P.o) + bh_offset(b, P.os_b, h, P.os_h) + (long)(q0 + ce) * P.os_s + 16 * dt + 4 * ge,
                    u4{f32_bits(ov[0]), f32_bits(ov[1]), f32_bits(ov[2]), f32_bits(ov[3])});
     } else {
       u2 w;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   }
   if constexpr (!OUT32) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    unsigned short* obase = reinterpret_cast<unsigned short*>(P.o) + (long)b * P.os_b + (long)h * P.os_h;
+    unsigned short* obase = reinterpret_cast<unsigned short*>(P.o) + bh_offset(b, P.os_b, h, P.os_h);
     const int lr = lane_e >> 3, lc = lane_e & 7;  // 8 chunks of 16 B per 128-B row, 8 rows per pass
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {

@@ -276,6 +276,13 @@ __device__ __forceinline__ int snake_block_id(int bid, const int nblocks) {
   return bid;
 }
 
+// b * stride_b + h * stride_h in elements, for strides the host has checked to lie in [0, 2^32) (oeh_api.hip: validate): two
+// 32 x 32 -> 64-bit products (s_mul_i32 + s_mul_hi_u32 each) instead of two 64 x 64-bit ones with their sign handling - six of
+// these sit in front of a kernel's first load.
+__device__ __forceinline__ long bh_offset(const int b, const long sb, const int h, const long sh) {
+  return (long)((unsigned long)(unsigned)b * (unsigned long)(unsigned)sb + (unsigned long)(unsigned)h * (unsigned long)(unsigned)sh);
+}
+
 // n / d and n % d for a wave-uniform n < 2^31 with m = floor(2^32 / d) from the host: the product's high word is the quotient or one
 // below it, one correction step makes it exact (an integer division is ~30 scalar instructions and a v_rcp round trip, and the
 // kernels do two of them before they can issue their first load).

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box): per-wave s_memtime timeline of the one-pass attention kernel: timeline.py causal B S [off_bits] [MQ].
+Needs the stamped build: `make -C outeffhop_amd/csrc timeline` (-> outeffhop_amd/lib/timeline/liboeh_hip.so; the production
+kernels carry no stamp code), loaded here through OEH_LIB.
 Never quote run times from this build path: the stamps perturb the schedule; read the SHARES."""
 import ctypes as C
 import os
 import sys
 import os as _os
 _os.environ.setdefault("OEH_DEBUG_HOOKS", "1")  # include/oeh_debug.h
+_os.environ.setdefault("OEH_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "outeffhop_amd", "lib", "timeline", "liboeh_hip.so"))
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
