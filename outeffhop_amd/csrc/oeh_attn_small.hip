@@ -43,14 +43,20 @@ __global__ __launch_bounds__(256, 2) void oeh_attn_small_kernel(const AttnParams
   // P.nQT query blocks of 16 rows per wave: all of them (one wave per problem), or ONE (P.nQT == 1: a wave per problem and
   // 16-row block, the waves of a problem next to each other in a workgroup so that their K / V loads meet in the CU's cache) -
   // chosen by the launcher when whole problems would leave most SIMDs without a wave
+  // (the arguments of the prologue in one round of scalar loads, no integer divisions: oeh_attn_fast.inl / oeh_common.h: div_magic;
+  // magic_nbh carries floor(2^32 / waves-per-problem) here, set by the launcher)
+  asm volatile("" ::"s"(P.q), "s"(P.k), "s"(P.v), "s"(P.o), "s"(P.nQT), "s"(P.nBH), "s"(P.H), "s"(P.Sq), "s"(P.Sk), "s"(P.magic_nbh), "s"(P.magic_h),
+               "s"(P.qs_b), "s"(P.qs_h), "s"(P.qs_s), "s"(P.ks_b), "s"(P.ks_h), "s"(P.ks_s), "s"(P.vs_b), "s"(P.vs_h), "s"(P.vs_s));
   const int nqb = (P.Sq + 15) >> 4;
   const int per = (P.nQT == 1) ? nqb : 1;       // waves per problem
   const int wg = blockIdx.x * 4 + wave;
-  const int bh = wg / per;
+  int bh, wrem;
+  div_magic((unsigned)wg, (unsigned)per, P.magic_nbh, bh, wrem);
   if (bh >= P.nBH) return;
-  const int qb0 = (wg - bh * per) * 16;
+  const int qb0 = wrem * 16;
   const int q_end = (P.nQT == 1) ? min(P.Sq, qb0 + 16) : P.Sq;
-  const int b = bh / P.H, h = bh - b * P.H;
+  int b, h;
+  div_magic((unsigned)bh, (unsigned)P.H, P.magic_h, b, h);
   const int c = lane & 15, g = lane >> 4;
   const int Sk = P.Sk, Sq = P.Sq;
 
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void oeh_attn_small_kernel(const AttnParams
   //      V (A operand of O^T = V^T P^T: row = d 16dt + c, k-slot g <-> key 16t + 4g + r), once, in registers
   f4 kf[ST][ET], vf[ST][ET];
   {
-    const long kb = (long)b * P.ks_b + (long)h * P.ks_h, vb = (long)b * P.vs_b + (long)h * P.vs_h;
+    const long kb = bh_offset(b, P.ks_b, h, P.ks_h), vb = bh_offset(b, P.vs_b, h, P.vs_h);
 #pragma unroll
     for (int t = 0; t < ST; ++t) {
       const int key = min(16 * t + c, Sk - 1);  // rows past Sk: finite data, masked below
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void oeh_attn_small_kernel(const AttnParams
 
   for (int q0 = qb0; q0 < q_end; q0 += 16) {
     const int qrow = q0 + c;
-    const long qoff = (long)b * P.qs_b + (long)h * P.qs_h + (long)min(qrow, Sq - 1) * P.qs_s + 4 * g;
+    const long qoff = bh_offset(b, P.qs_b, h, P.qs_h) + (long)min(qrow, Sq - 1) * P.qs_s + 4 * g;
     f4 qf[ET];
 #pragma unroll
     for (int j = 0; j < ET; ++j) qf[j] = load4_f32<IN>(P.q, qoff + 16 * j);
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void oeh_attn_small_kernel(const AttnParams
         for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[t][dt][r], s[t][r], o, 0, 0, 0);
       if (P.gate != nullptr) o = o * gatev;
       if (qrow < Sq) {
-        const long ooff = (long)b * P.os_b + (long)h * P.os_h + (long)qrow * P.os_s + 16 * dt + 4 * g;
+        const long ooff = bh_offset(b, P.os_b, h, P.os_h) + (long)qrow * P.os_s + 16 * dt + 4 * g;
         if constexpr (IN == IN_F32) {
           *reinterpret_cast<f4*>(reinterpret_cast<float*>(P.o) + ooff) = o;
         } else {
@@ -159,6 +165,7 @@ static int launch_small_et_st(const AttnParams& P, int in, hipStream_t st) {
   const long nqb = (P.Sq + 15) / 16;
   Q.nQT = (nqb > 1 && (long)P.nBH < 2048) ? 1 : 0;
   const long waves = Q.nQT == 1 ? (long)P.nBH * nqb : (long)P.nBH;
+  Q.magic_nbh = Q.nQT == 1 ? (unsigned)(0x100000000ULL / (unsigned long long)nqb) : 0xffffffffu;  // floor(2^32 / waves per problem)
   const unsigned grid = (unsigned)((waves + 3) / 4);
   switch (in) {
     case IN_F16: hipLaunchKernelGGL((oeh_attn_small_kernel<ET, ST, IN_F16>), dim3(grid), dim3(256), 0, st, Q); break;
