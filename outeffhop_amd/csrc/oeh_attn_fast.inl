@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
   // is first used: several dependent rounds of ~300 cycles each in front of the first LDS-DMA request, on every wave), and the
   // block id decoded without integer divisions (oeh_common.h: div_magic): 15.43 -> 14.80 us on the headline launch of the one-pass
   // kernel, same treatment here.
-  if constexpr (!SRC32) {
+  {
     asm volatile("" ::"s"(P.q), "s"(P.k), "s"(P.v), "s"(P.nBHpad), "s"(P.nQT), "s"(P.nBH), "s"(P.H), "s"(P.Sq), "s"(P.Sk), "s"(P.skip_ok),
                  "s"(P.magic_nbh), "s"(P.magic_h), "s"(P.qs_b), "s"(P.qs_h), "s"(P.qs_s), "s"(P.ks_b), "s"(P.ks_h), "s"(P.ks_s), "s"(P.vs_b), "s"(P.vs_h),
                  "s"(P.vs_s), "s"(P.pad));

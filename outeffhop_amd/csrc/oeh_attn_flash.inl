@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
 
   // The kernel arguments the prologue needs, requested in ONE round of scalar loads at entry (the compiler loads an argument where it
   // is first used: four dependent rounds of ~300 cycles each in front of the first LDS-DMA request, every wave of every workgroup).
-  if constexpr (!SRC32) {
+  {
     asm volatile("" ::"s"(P.q), "s"(P.k), "s"(P.v), "s"(P.nBHpad), "s"(P.nQT), "s"(P.nBH), "s"(P.H), "s"(P.Sq), "s"(P.Sk), "s"(P.causal), "s"(P.snake),
                  "s"(P.magic_nbh), "s"(P.magic_h), "s"(P.qs_b), "s"(P.qs_h), "s"(P.qs_s), "s"(P.ks_b), "s"(P.ks_h), "s"(P.ks_s), "s"(P.vs_b), "s"(P.vs_h),
                  "s"(P.vs_s));
