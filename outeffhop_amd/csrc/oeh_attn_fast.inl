@@ -768,20 +768,20 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
   if constexpr (GATE) rowscale = rowscale * gate_row;
   constexpr int XM = (CPR < 8 ? CPR : 8) - 1;
   unsigned char* ebase = lds + wave * (16 * ROWB);
+  float xs[FQ ? DT * 4 : 1];
+  if constexpr (FQ) {  // [scale of the quantised P] [fq] gate [fq]: the general kernel's epilogue chain, in whole passes (oeh_common.h: ctx_chain)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xs[dt * 4 + r] = P.fq_p.scale * o[dt][r];
+    ctx_chain<DT * 4>(xs, P.fq_c, P.ctx_before_gate, P.gate != nullptr, rowscale);
+  }
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) {
     float ov[4];
-    if constexpr (FQ) {  // [scale of the quantised P] [fq] gate [fq]: the general kernel's epilogue chain
+    if constexpr (FQ) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float x = o[dt][r];
-        x = P.fq_p.scale * x;
-        if (P.fq_c.en && P.ctx_before_gate) x = P.fq_c.scale * fq_rel(x, P.fq_c);   // scale * (idx - zp): fq_dequant(fq_index()) without the + zp - zp
-        if (P.gate != nullptr) x = x * rowscale;
-        if (P.fq_c.en && !P.ctx_before_gate) x = P.fq_c.scale * fq_rel(x, P.fq_c);
-        ov[r] = x;
-      }
-
+      for (int r = 0; r < 4; ++r) ov[r] = xs[dt * 4 + r];
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) ov[r] = o[dt][r] * rowscale;

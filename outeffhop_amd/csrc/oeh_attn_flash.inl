@@ -799,18 +799,25 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     if constexpr (TP != 0) rowscale = 1.0f;  // the clipped probabilities / the probability indices went into the product as they are
     if (P.gate != nullptr && qrow < Sq) rowscale = rowscale * P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
     if constexpr (GATE) rowscale = rowscale * gate_row[j];
-    // TP = 2: [scale of the quantised P] [context quantiser] gate [context quantiser] - the full-row kernel's epilogue chain
-    auto finish = [&](float x) {
-      if constexpr (FQ2) {
-        x = P.fq_p.scale * x;
-        if (P.fq_c.en && P.ctx_before_gate) x = P.fq_c.scale * fq_rel(x, P.fq_c);
-        if (P.gate != nullptr) x = x * rowscale;
-        if (P.fq_c.en && !P.ctx_before_gate) x = P.fq_c.scale * fq_rel(x, P.fq_c);
-        return x;
-      } else {
-        return x * rowscale;
-      }
-    };
+    // TP = 2: [scale of the quantised P] [context quantiser] gate [context quantiser] - the full-row kernel's epilogue chain,
+    // in whole passes over the block's values (oeh_common.h: ctx_chain), written back into the accumulators
+    if constexpr (FQ2) {
+      float xs[DT * 4];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = o[j][dt][r];
+          if constexpr (SRC32) x = __builtin_fmaf(ox[j][dt][r], kSplitDown, x);
+          xs[dt * 4 + r] = P.fq_p.scale * x;
+        }
+      ctx_chain<DT * 4>(xs, P.fq_c, P.ctx_before_gate, P.gate != nullptr, rowscale);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[j][dt][r] = xs[dt * 4 + r];
+    }
+    auto finish = [&](float x) { return FQ2 ? x : x * rowscale; };
     if constexpr (OUT32) {  // fp32 output straight from the accumulators (fp32 storage): 16 B per lane, 64 B per row and instruction
       if (qrow < Sq) {
         float* orow = reinterpret_cast<float*>(P.o) + bh_offset(b, P.os_b, h, P.os_h) + (long)qrow * P.os_s + 4 * ge;
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
         for (int dt = 0; dt < DT; ++dt) {
           f4 ov;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ov[r] = finish(__builtin_fmaf(ox[j][dt][r], kSplitDown, o[j][dt][r]));
+          for (int r = 0; r < 4; ++r) ov[r] = finish(FQ2 ? o[j][dt][r] : __builtin_fmaf(ox[j][dt][r], kSplitDown, o[j][dt][r]));
           store_wt16(orow + 16 * dt, u4{f32_bits(ov[0]), f32_bits(ov[1]), f32_bits(ov[2]), f32_bits(ov[3])});
         }
       }

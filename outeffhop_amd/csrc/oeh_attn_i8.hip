@@ -341,21 +341,22 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   const int ce = lane_e & 15, ge = lane_e >> 4;
   constexpr int ROWB = 2 * D;
   unsigned char* ebase = lds + wave * (16 * ROWB);  // 16-bit output: staged through the (idle) K ring, whole rows stored
+  float xs[DT * 4], crel[DUMP ? DT * 4 : 1];
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt) {
-    float ov[4];
-    unsigned cw = 0u;
+  for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float x = so * (float)(o[dt][r] + __mul24(cp, vs[dt][r]) + rowc);  // |vsum| <= 512 * 128
-      float crel = 0.0f;  // idx - zp of the context quantiser: the dequantised value is scale * (idx - zp)
-      if (P.fq_c.en && P.ctx_before_gate) { crel = fq_rel(x, P.fq_c); x = P.fq_c.scale * crel; }
-      if (P.gate != nullptr) x = x * gatev;
-      if (P.fq_c.en && !P.ctx_before_gate) { crel = fq_rel(x, P.fq_c); x = P.fq_c.scale * crel; }
-      ov[r] = x;
-      if constexpr (DUMP) cw |= (unsigned)(crel + P.fq_c.zp) << (8 * r);
+      xs[dt * 4 + r] = so * (float)(o[dt][r] + __mul24(cp, vs[dt][r]) + rowc);  // |vsum| <= 512 * 128
+      if constexpr (DUMP) crel[dt * 4 + r] = 0.0f;
     }
+  ctx_chain<DT * 4, DUMP>(xs, P.fq_c, P.ctx_before_gate, P.gate != nullptr, gatev, crel);  // (idx - zp of the context quantiser for the dumps)
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    const float* ov = &xs[dt * 4];
     if constexpr (DUMP) {
+      unsigned cw = 0u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cw |= (unsigned)(crel[dt * 4 + r] + P.fq_c.zp) << (8 * r);
       if (P.fq_c.en && P.fq_c.dump != nullptr && qvalid) *reinterpret_cast<unsigned*>(P.fq_c.dump + (((long)b * P.H + h) * P.Sq + qrow) * D + 16 * dt + 4 * g) = cw;
     }
     if constexpr (OUT32) {

@@ -62,6 +62,37 @@ constexpr float kGridMagic = 12582912.0f;
 __device__ __forceinline__ float grid_rel_m(float s, float k1, float lo_m, float hi_m) {
   return __builtin_amdgcn_fmed3f(__builtin_fmaf(s, k1, kGridMagic), lo_m, hi_m);
 }
+// The epilogue chain [context quantiser] gate [context quantiser] over a lane's N context values, in WHOLE passes under
+// wave-uniform branches.  Written per element with the three conditions inline the compiler turns them into selects and
+// evaluates BOTH quantisers for every element (21 vector instructions per element where 10 do: a quarter of the int8 core's
+// vector instructions were this epilogue).  The opaque asm in a pass keeps it a branch.  rel (tests' index dumps): idx - zp.
+template <int N, bool WANT_REL = false>
+__device__ __forceinline__ void ctx_chain(float (&x)[N], const FqP& fc, const int before_gate, const bool gated, const float gatev, float* rel = nullptr) {
+  const bool first = fc.en && (before_gate || !gated), last = fc.en && !before_gate && gated;
+  if (first) {
+    asm volatile("");
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const float r = fq_rel(x[i], fc);
+      if constexpr (WANT_REL) rel[i] = r;
+      x[i] = fc.scale * r;
+    }
+  }
+  if (gated) {
+    asm volatile("");
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = x[i] * gatev;
+  }
+  if (last) {
+    asm volatile("");
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const float r = fq_rel(x[i], fc);
+      if constexpr (WANT_REL) rel[i] = r;
+      x[i] = fc.scale * r;
+    }
+  }
+}
 __device__ __forceinline__ f4 fq_rel4(f4 x, const FqP& f) { return f4{fq_rel(x[0], f), fq_rel(x[1], f), fq_rel(x[2], f), fq_rel(x[3], f)}; }
 __device__ __forceinline__ float fq_index(float x, const FqP& f) { return fq_rel(x, f) + f.zp; }
 __device__ __forceinline__ float fq_dequant(float idx, const FqP& f) { return f.scale * (idx - f.zp); }
