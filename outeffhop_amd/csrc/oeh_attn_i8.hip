@@ -222,31 +222,36 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
     if (kt < n_kt) {
       const bool open_tile = kt < kt_causal && kt < kt_tail;
       const int lim = klim_g - 64 * kt;                     // element (t, r) is masked when 4 t + r > lim
+      auto quantise = [&](auto masked_c) {  // (the tile's body twice, not a test per four elements)
+        constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        f4 rel;
+        for (int t = 0; t < 4; ++t) {
+          f4 rel;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rel[r] = grid_rel_m(s[kt * 4 + t][r], k1, slo, shi);
-        if constexpr (DUMP) {
-          if (P.fq_s.dump != nullptr && qvalid) {
-            const int zi = (int)P.fq_s.zp - 0x4B400000;
-            const unsigned w = (unsigned)((int)f32_bits(rel[0]) + zi) | ((unsigned)((int)f32_bits(rel[1]) + zi) << 8) |
-                               ((unsigned)((int)f32_bits(rel[2]) + zi) << 16) | ((unsigned)((int)f32_bits(rel[3]) + zi) << 24);
-            const int key0 = 64 * kt + 16 * g + 4 * t;
-            if (key0 < Sk) *reinterpret_cast<unsigned*>(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0) = w;
+          for (int r = 0; r < 4; ++r) rel[r] = grid_rel_m(s[kt * 4 + t][r], k1, slo, shi);
+          if constexpr (DUMP) {
+            if (P.fq_s.dump != nullptr && qvalid) {
+              const int zi = (int)P.fq_s.zp - 0x4B400000;
+              const unsigned w = (unsigned)((int)f32_bits(rel[0]) + zi) | ((unsigned)((int)f32_bits(rel[1]) + zi) << 8) |
+                                 ((unsigned)((int)f32_bits(rel[2]) + zi) << 16) | ((unsigned)((int)f32_bits(rel[3]) + zi) << 24);
+              const int key0 = 64 * kt + 16 * g + 4 * t;
+              if (key0 < Sk) *reinterpret_cast<unsigned*>(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0) = w;
+            }
           }
-        }
-        if (!open_tile) {
+          if constexpr (MASKED) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) rel[r] = (4 * t + r > lim) ? RELMASK : rel[r];
-        }
-        if constexpr (PAD) {
-          const f4 flag = *reinterpret_cast<const f4*>(&lds_pad[64 * kt + 16 * g + 4 * t]);
+            for (int r = 0; r < 4; ++r) rel[r] = (4 * t + r > lim) ? RELMASK : rel[r];
+          }
+          if constexpr (PAD) {
+            const f4 flag = *reinterpret_cast<const f4*>(&lds_pad[64 * kt + 16 * g + 4 * t]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) rel[r] = __builtin_fminf(rel[r], flag[r]);
+            for (int r = 0; r < 4; ++r) rel[r] = __builtin_fminf(rel[r], flag[r]);
+          }
+          s[kt * 4 + t] = rel;
         }
-        s[kt * 4 + t] = rel;
-      }
+      };
+      if (open_tile) quantise(std::false_type{});
+      else quantise(std::true_type{});
 #pragma unroll
       for (int t = 0; t < 4; ++t) {  // (v_max3 from the plain builtins: the operands are v_med3 / select results, known canonical - no
         mr = __builtin_fmaxf(__builtin_fmaxf(mr, s[kt * 4 + t][0]), s[kt * 4 + t][1]);  // canonicalising v_max, and none of the
@@ -303,9 +308,14 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   psum += __shfl_xor(psum, 32);
 
   // =========================== phase 3: O^T = V^T P^T (i32) and the key sums of V^T ===========================
+  // sum_k (v + cv)(p + cp) = o + cp vsum + cv psum + n cv cp: the query's constant cv psum + n cv cp is what the accumulators start at
+  const int rowc = cv * psum + 64 * n_kt * cv * cp;
   i4 o[DT], vs[DT];
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt) o[dt] = vs[dt] = i4{0, 0, 0, 0};
+  for (int dt = 0; dt < DT; ++dt) {
+    o[dt] = i4{rowc, rowc, rowc, rowc};
+    vs[dt] = i4{0, 0, 0, 0};
+  }
   i4 ones4 = i4{ones, ones, ones, ones};
   asm volatile("" : "+v"(ones4));  // one register quad for the phase (the compiler would rebuild the constant before every use)
   const int vswz = (g ^ perm4(c >> 2)) << 4;                      // perm4((d >> 2) & 3), d = 16 dt + c
@@ -330,9 +340,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   }
 
   // =========================== epilogue: offsets back, [fq] gate [fq], store ===========================
-  // lane (c, g) holds O[q0 + c][16 dt + 4 g + r];  sum_k (v + cv)(p + cp) = o + cp vsum + cv psum + n cv cp
-  const int nkeys = 64 * n_kt;
-  const int rowc = cv * psum + nkeys * cv * cp;
+  // lane (c, g) holds O[q0 + c][16 dt + 4 g + r] (+ the row constant);  cp vsum is still to add
   const float so = P.i8_so;  // scale_p * scale_v
   float gatev = 1.0f;
   if (P.gate != nullptr && qvalid) gatev = P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      xs[dt * 4 + r] = so * (float)(o[dt][r] + __mul24(cp, vs[dt][r]) + rowc);  // |vsum| <= 512 * 128
+      xs[dt * 4 + r] = so * (float)(o[dt][r] + __mul24(cp, vs[dt][r]));  // |vsum| <= 512 * 128
       if constexpr (DUMP) crel[dt * 4 + r] = 0.0f;
     }
   ctx_chain<DT * 4, DUMP>(xs, P.fq_c, P.ctx_before_gate, P.gate != nullptr, gatev, crel);  // (idx - zp of the context quantiser for the dumps)
