@@ -65,6 +65,12 @@ typedef struct oeh_fq_desc {
   oeh_fq ctx;                    /* on P@V;                                              dump shape (B,H,Sq,D)  */
   int32_t ctx_quant_before_gate; /* 1: OPT order (quantized_opt.py:210 then gate :224-261);
                                     0: BERT order (gate quantized_bert.py:389-426 then quant :434) */
+  int32_t ctx_emit_index;        /* 1: o receives the context quantiser's INTEGERS idx - zero_point (exact in every output
+                                    dtype, |.| <= 255) instead of scale * (idx - zero_point).  For a consumer that is a
+                                    QuantLinear (OPT's out_proj, quantized_opt.py:271 - integer weights): the projection is
+                                    then ONE 16-bit GEMM of integers, exact products, with scale_ctx * scale_w folded into its
+                                    output pass - no fp32 GEMM, no operand pairs.  Needs ctx.enable and the quantiser as the
+                                    last op of the core (no gate after it), else OEH_EINVAL. */
 } oeh_fq_desc;
 
 /* Attention problem descriptor.  Tensors are (B,H,S,D) VIEWS given by element strides for

@@ -33,7 +33,7 @@ class oeh_fq(C.Structure):
 
 
 class oeh_fq_desc(C.Structure):
-    _fields_ = [("scores", oeh_fq), ("probs", oeh_fq), ("ctx", oeh_fq), ("ctx_quant_before_gate", C.c_int32)]
+    _fields_ = [("scores", oeh_fq), ("probs", oeh_fq), ("ctx", oeh_fq), ("ctx_quant_before_gate", C.c_int32), ("ctx_emit_index", C.c_int32)]
 
 
 class oeh_grid(C.Structure):

@@ -62,6 +62,7 @@ FqP make_fq(const oeh_fq* f) {
     r.hi = f->qmax - f->zero_point;
     r.dump = f->dump_idx;
     r.c2 = scale_log2e(f->scale);
+    r.oscale = f->scale;
   }
   return r;
 }
@@ -94,6 +95,10 @@ int validate(const oeh_attn_desc* d, const void* q, const void* k, const void* v
     for (const int64_t* st : sts)
       for (int i = 0; i < 3; ++i)
         if (st[i] < 0 || st[i] >= ((int64_t)1 << 32)) return OEH_ENOTSUP;
+  }
+  if (fq != nullptr && fq->ctx_emit_index) {  // the integers idx - zp instead of values: only where the context quantiser is the last op
+    const bool gated = d->gate != nullptr || d->gate_hidden != nullptr;
+    if (!fq->ctx.enable || (gated && fq->ctx_quant_before_gate)) return OEH_EINVAL;
   }
   if (d->key_pad_mask != nullptr && d->key_pad_dtype != OEH_F16 && d->key_pad_dtype != OEH_F32) return OEH_EINVAL;
   if (d->full_mask != nullptr && d->full_mask_dtype != OEH_F16 && d->full_mask_dtype != OEH_F32) return OEH_EINVAL;
@@ -297,6 +302,7 @@ void fill_params(AttnParams& P, const oeh_attn_desc* d, const void* q, const voi
   if (fq != nullptr) {
     P.fq_s = make_fq(&fq->scores); P.fq_p = make_fq(&fq->probs); P.fq_c = make_fq(&fq->ctx);
     P.ctx_before_gate = fq->ctx_quant_before_gate ? 1 : 0;
+    if (fq->ctx_emit_index) P.fq_c.oscale = 1.0f;  // (validate(): the context quantiser is the last op)
   }
   P.stamps = g_stamps;
   P.snake = (g_place & 1) ? 0 : 1;

@@ -101,13 +101,13 @@ __global__ __launch_bounds__(128) void oeh_attn_generic_kernel(const AttnParams 
     if (P.fq_c.en && P.ctx_before_gate) {
       const float idx = fq_index(x, P.fq_c);
       if (P.fq_c.dump) P.fq_c.dump[(((long)b * P.H + h) * P.Sq + qi) * P.D + d] = (unsigned char)idx;
-      x = fq_dequant(idx, P.fq_c);
+      x = fq_out(idx, P.fq_c);
     }
     if (P.gate) x = x * gatev;
     if (P.fq_c.en && !P.ctx_before_gate) {
       const float idx = fq_index(x, P.fq_c);
       if (P.fq_c.dump) P.fq_c.dump[(((long)b * P.H + h) * P.Sq + qi) * P.D + d] = (unsigned char)idx;
-      x = fq_dequant(idx, P.fq_c);
+      x = fq_out(idx, P.fq_c);
     }
     op[d] = In<IN>::from_f32(x);
   }

@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256, (occupancy_hint<NT, D, IN>())) void oeh_attn_m
         if (P.fq_c.en && P.ctx_before_gate) {
           const float idx = fq_index(x, P.fq_c);
           dump_word |= ((unsigned int)idx) << (8 * r);
-          x = fq_dequant(idx, P.fq_c);
+          x = fq_out(idx, P.fq_c);
         }
       }
       if (P.gate != nullptr) x = x * gatev;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, (occupancy_hint<NT, D, IN>())) void oeh_attn_m
         if (P.fq_c.en && !P.ctx_before_gate) {
           const float idx = fq_index(x, P.fq_c);
           dump_word |= ((unsigned int)idx) << (8 * r);
-          x = fq_dequant(idx, P.fq_c);
+          x = fq_out(idx, P.fq_c);
         }
       }
       ov[r] = x;

@@ -29,6 +29,8 @@ struct FqP {
   float scale, rscale, zp, qmax;  // rscale = RN(1/scale), formed by the host (oeh_api.hip: make_fq)
   float lo, hi;                   // -zp and qmax - zp: the grid relative to the zero point
   float c2;                       // RN(scale * log2(e)), formed in double by the host: exp(scale * d) = exp2(d * c2) for grid differences d
+  float oscale;                   // what a quantised value is written out as: oscale * (idx - zp); = scale, or 1 for the context quantiser
+                                  // with oeh_fq_desc.ctx_emit_index (the integers themselves: include/oeh.h)
   unsigned char* dump;
 };
 
@@ -75,7 +77,7 @@ __device__ __forceinline__ void ctx_chain(float (&x)[N], const FqP& fc, const in
     for (int i = 0; i < N; ++i) {
       const float r = fq_rel(x[i], fc);
       if constexpr (WANT_REL) rel[i] = r;
-      x[i] = fc.scale * r;
+      x[i] = fc.oscale * r;
     }
   }
   if (gated) {
@@ -89,13 +91,14 @@ __device__ __forceinline__ void ctx_chain(float (&x)[N], const FqP& fc, const in
     for (int i = 0; i < N; ++i) {
       const float r = fq_rel(x[i], fc);
       if constexpr (WANT_REL) rel[i] = r;
-      x[i] = fc.scale * r;
+      x[i] = fc.oscale * r;
     }
   }
 }
 __device__ __forceinline__ f4 fq_rel4(f4 x, const FqP& f) { return f4{fq_rel(x[0], f), fq_rel(x[1], f), fq_rel(x[2], f), fq_rel(x[3], f)}; }
 __device__ __forceinline__ float fq_index(float x, const FqP& f) { return fq_rel(x, f) + f.zp; }
 __device__ __forceinline__ float fq_dequant(float idx, const FqP& f) { return f.scale * (idx - f.zp); }
+__device__ __forceinline__ float fq_out(float idx, const FqP& f) { return f.oscale * (idx - f.zp); }  // (the context quantiser's written value)
 __device__ __forceinline__ unsigned int fq_dump_word(f4 rel, const FqP& f) {  // four uint8 indices (test dumps)
   return (unsigned int)(rel[0] + f.zp) | ((unsigned int)(rel[1] + f.zp) << 8) | ((unsigned int)(rel[2] + f.zp) << 16) | ((unsigned int)(rel[3] + f.zp) << 24);
 }

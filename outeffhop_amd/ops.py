@@ -52,6 +52,7 @@ class AttnFakeQuant:
     probs: Optional[FakeQuantSpec] = None
     ctx: Optional[FakeQuantSpec] = None
     ctx_before_gate: bool = True  # OPT order; False = BERT order (quantise after the gate)
+    ctx_emit_index: bool = False  # the output holds the context quantiser's integers idx - zp (include/oeh.h: ctx_emit_index)
 
 
 def _need_gpu(*ts):
@@ -217,6 +218,7 @@ def attn_fwd(
         _fill_fq(fqd.probs, fq.probs)
         _fill_fq(fqd.ctx, fq.ctx)
         fqd.ctx_quant_before_gate = int(bool(fq.ctx_before_gate))
+        fqd.ctx_emit_index = int(bool(fq.ctx_emit_index))
     lib = _lib.load()
     _warn_if_any_shape_kernel(lib, d, fqd, softmax)
     if _prepared is not None:  # hand back the prebuilt C call instead of launching (bench / hipGraph loops)
@@ -391,6 +393,7 @@ def attn_fwd_i8(q: torch.Tensor, k: torch.Tensor, v_t: torch.Tensor, grids, *, f
     _fill_fq(fqd.probs, fq.probs)
     _fill_fq(fqd.ctx, fq.ctx)
     fqd.ctx_quant_before_gate = int(bool(fq.ctx_before_gate))
+    fqd.ctx_emit_index = int(bool(fq.ctx_emit_index))
     if _prepared is not None:  # hand back the prebuilt C call instead of launching (bench / A-B loops)
         _prepared.extend([_lib.load().oeh_attn_fwd, (C.byref(d), _ptr(q), _ptr(k), _ptr(v_t), _ptr(out), C.byref(fqd)), (d, fqd, keep, q, k, v_t, out)])
         return out

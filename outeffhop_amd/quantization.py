@@ -18,6 +18,7 @@ everything on the device (the reference copies each (B,H,S,S) tensor to the host
 from __future__ import annotations
 
 import copy
+import dataclasses
 from enum import Enum
 from typing import Optional
 
@@ -579,6 +580,29 @@ class QuantLinear(QuantizedModule, nn.Linear):
                                   bias=bias.detach(), want_indices=False)
         return y.view(*x.shape[:-1], self.out_features)
 
+    def index_gemm_ok(self, like) -> bool:
+        """`linear_index` applies: what `pair_gemm_ok` asks of the weights, for an fp32 model on the GPU."""
+        return self.pair_gemm_ok(like) and self.bias is not None and self.activation_function is None
+
+    def linear_index(self, rel, xscale: float, out_dtype=torch.float32):
+        """This projection of x = xscale * rel, `rel` the INTEGERS idx - zp of the producer's 8-bit quantiser as a 16-bit float
+        tensor (`ops.attn_fwd_i8(..., fq.ctx_emit_index)`): x W_q^T = (xscale * w_scale) * (rel . Iw), ONE fp16 GEMM of integers
+        with exact products and fp32 accumulation - half the operand-pair GEMM and no split pass - then scale, bias and the
+        frozen output quantiser in one pass over the accumulator (the reference: a float GEMM of the dequantised values,
+        quantized_opt.py:271; the two agree to fp32 rounding of the sum)."""
+        ww, s32 = self._pair_weights()
+        K = self.in_features
+        acc = torch.mm(rel.reshape(-1, K), ww[:K], out_dtype=torch.float32)
+        alpha = float(np.float32(xscale) * np.float32(s32))
+        shape = (*rel.shape[:-1], self.out_features)
+        aq = self.activation_quantizer
+        if (self._qa and self.out_features % 64 == 0 and aq.is_fixed and type(aq.quantizer) is AsymmetricUniformQuantizer and aq.quantizer.n_bits == 8):
+            y = ops.quantize_heads_i8(acc.view(1, -1, self.out_features), aq.quantizer.spec(), self.out_features // 64, want_values=True,
+                                      alpha=alpha, bias=self.bias.detach(), want_indices=False)
+            return y.view(shape).to(out_dtype)
+        res = torch.add(self.bias.detach(), acc, alpha=alpha).view(shape).to(out_dtype)
+        return aq(res) if self._qa else res
+
     def forward(self, x, offsets=None):
         weight, bias = self.get_params()
         if self.pair_gemm_ok(x):
@@ -732,14 +756,17 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
             self.__dict__["_qkv_pair_cache"] = hit
         return hit[1], [p[1] for p in parts]
 
-    def _int8_storage_core(self, hidden_states, lins, H, head_dim, *, scale, scale_div, causal, padvec, mask_min, gate, fq, want_values):
+    def _int8_storage_core(self, hidden_states, lins, H, head_dim, *, scale, scale_div, causal, padvec, mask_min, gate, fq, want_values,
+                           consumer=None):
         """the q/k/v projections are QuantLinear - their outputs ARE 8-bit indices on calibrated grids
         (hijacker.py:78-127; quantized_opt.py:67-75, quantized_bert.py:236-238) - so the attention core takes the indices
         themselves and runs both products on the integer matrix cores (`ops.attn_fwd_i8`, include/oeh.h dtype OEH_I8).  Applies
         when the three output quantisers are 8-bit with frozen ranges, head_dim = 64, the softmax is not clipped and the mask is
         none / causal / a key-padding vector of 0 / finfo.min entries (`padvec`, vouched for by the caller); returns the
         merged context (B, T, E) and the (k, v) float values (`want_values`: a decoder's cache), or None -> the caller runs the
-        fake-quant path on floats."""
+        fake-quant path on floats.  `consumer`: the QuantLinear that takes the context next (OPT's out_proj); when the context
+        quantiser is the core's last op the core hands it the quantiser's integers (`ctx_emit_index`) and the returned tensor is
+        the consumer's OUTPUT (`QuantLinear.linear_index`), marked by the third element of the result."""
         if not INT8_STORAGE or not hidden_states.is_cuda or head_dim != 64:
             return None
         spec = spec_of(self.softmax_fn)
@@ -776,15 +803,23 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
         qc = outs[0]
         kc, yk = outs[1] if want_values else (outs[1], None)
         vt, yv = outs[2] if want_values else (outs[2], None)
+        as_index = (INDEX_GEMM and consumer is not None and fq.ctx is not None and fq.ctx.qmax == 255.0 and (gate is None or not fq.ctx_before_gate)
+                    and isinstance(consumer, QuantLinear) and consumer.in_features == E and consumer.index_gemm_ok(hidden_states))
+        fq_call = dataclasses.replace(fq, ctx_emit_index=True) if as_index else fq
         try:
-            out = ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, out_dtype=hidden_states.dtype, softmax=spec, scale=scale, scale_div=scale_div, causal=causal,
-                                  clamp_min=causal or padvec is not None, mask_min=mask_min, gate=gate, key_pad_mask=padvec)
+            out = ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq_call, out_dtype=torch.float16 if as_index else hidden_states.dtype, softmax=spec, scale=scale,
+                                  scale_div=scale_div, causal=causal, clamp_min=causal or padvec is not None, mask_min=mask_min, gate=gate,
+                                  key_pad_mask=padvec)
         except _OehError as e:
             if e.code != -95:
                 raise
             return None
         self.__dict__["_i8_calls"] = self.__dict__.get("_i8_calls", 0) + 1  # (tests: which core ran)
-        return out.permute(0, 2, 1, 3).reshape(bsz, tgt_len, E), (yk, yv)
+        merged = out.permute(0, 2, 1, 3).reshape(bsz, tgt_len, E)
+        if as_index:
+            self.__dict__["_index_gemm_calls"] = self.__dict__.get("_index_gemm_calls", 0) + 1
+            return consumer.linear_index(merged, fq.ctx.scale, out_dtype=hidden_states.dtype), (yk, yv), True
+        return merged, (yk, yv), False
 
 
 class QuantizedBertSelfAttentionWithExtras(_QuantAttnBase):
@@ -828,7 +863,7 @@ class QuantizedBertSelfAttentionWithExtras(_QuantAttnBase):
                                                scale=1.0, scale_div=float(np.sqrt(self.attention_head_size)), causal=False, padvec=pad8,
                                                mask_min=float(torch.finfo(mdt).min), gate=gate8, fq=fq8, want_values=self.is_decoder)
                 if done is not None:
-                    context, (yk, yv) = done
+                    context, (yk, yv), _ = done
                     outputs = (context,)
                     if self.is_decoder:
                         outputs = outputs + ((self.transpose_for_scores(yk), self.transpose_for_scores(yv)),)
@@ -911,11 +946,11 @@ class QuantizedOPTAttentionWithExtras(_QuantAttnBase):
                     mdt = attention_mask.dtype if attention_mask is not None and attention_mask.is_floating_point() else hidden_states.dtype
                     done = self._int8_storage_core(hidden_states, (self.q_proj, self.k_proj, self.v_proj), self.num_heads, self.head_dim,
                                                    scale=self.scaling, scale_div=0.0, causal=causal8, padvec=pad8, mask_min=float(torch.finfo(mdt).min),
-                                                   gate=gate8, fq=fq8, want_values=self.is_decoder)
+                                                   gate=gate8, fq=fq8, want_values=self.is_decoder, consumer=self.out_proj)
                     if done is not None:
-                        merged, (yk, yv) = done
+                        merged, (yk, yv), projected = done
                         kv = (self._heads(yk, bsz), self._heads(yv, bsz)) if self.is_decoder else past_key_value
-                        return self.out_proj(merged), None, kv
+                        return (merged if projected else self.out_proj(merged)), None, kv
         q = self._heads(self.q_proj(hidden_states) * self.scaling, bsz)
         if key_value_states is not None and past_key_value is not None:
             k, v = past_key_value[0], past_key_value[1]
@@ -957,6 +992,9 @@ class QuantizedOPTAttentionWithExtras(_QuantAttnBase):
 # estimate_ranges state: the score and probability quantisers' percentile ranges from `ops.attn_calibrate` (the (B,H,Sq,Sk)
 # tensors are recomputed tile by tile inside the kernel, never stored); False: the observable path materialises them.
 FUSED_CALIBRATION = True
+# OPT's out_proj on the context quantiser's INTEGERS (ops ... ctx_emit_index + QuantLinear.linear_index): one 16-bit GEMM of
+# integers instead of the split pass + the operand-pair GEMM.  False: the core writes float values, out_proj runs as any QuantLinear.
+INDEX_GEMM = True
 # The INT8-storage attention core (integer matrix cores) is used by QuantizedOPTAttentionWithExtras whenever it applies;
 # False: always the fake-quant kernels on float values (tests compare the two).
 INT8_STORAGE = True

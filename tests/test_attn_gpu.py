@@ -1415,3 +1415,38 @@ def test_attn_calibrate_without_the_score_tensors(ops, order, dtype):
         err = np.abs(_np32(ctx) - want)
         # a score or probability within an ulp of a rounding boundary may land on the neighbouring grid point: rare, small
         assert (err > 2e-5).mean() <= 2e-3 and err.max() <= 2e-2, (order, batch, float(err.max()), float((err > 2e-5).mean()))
+
+
+@pytest.mark.gpu
+def test_context_quantiser_emits_its_integers(ops):
+    """include/oeh.h ctx_emit_index: the output is idx - zp of the context quantiser (what a QuantLinear consumer multiplies as
+    integers, quantized_opt.py:271) - on the int8-storage core and on the fake-quant kernels: scale * integers reproduces the
+    ordinary output bit for bit, in fp16 the integers are exact; refused (EINVAL) when a gate follows the quantiser."""
+    import dataclasses
+    from outeffhop_amd import _lib
+
+    torch.manual_seed(5)
+    B, H, S, D = 2, 3, 128, 64
+    dev = torch.device("cuda:0")
+    q = torch.randn(B, H, S, D, device=dev) * 0.5
+    k, v = torch.randn(B, H, S, D, device=dev), torch.randn(B, H, S, D, device=dev)
+    fq = ops.AttnFakeQuant(scores=ops.FakeQuantSpec(0.11, 130.0), probs=ops.FakeQuantSpec(1.0 / 255, 0.0), ctx=ops.FakeQuantSpec(0.021, 121.0))
+    fqi = dataclasses.replace(fq, ctx_emit_index=True)
+    kw = dict(softmax=ops.SoftmaxSpec(base=1), causal=True, clamp_min=True, mask_min=float(np.finfo(np.float32).min))
+    for dt in (torch.float32, torch.float16):
+        val = ops.attn_fwd(q.to(dt), k.to(dt), v.to(dt), fq=fq, **kw)
+        rel = ops.attn_fwd(q.to(dt), k.to(dt), v.to(dt), fq=fqi, **kw)
+        assert torch.equal(rel, rel.round()) and float(rel.min()) >= -121.0 and float(rel.max()) <= 134.0
+        assert torch.equal((rel.float() * np.float32(0.021)).to(dt), val)
+    grids = [ops.QuantGrid(0.02, 128.0), ops.QuantGrid(0.03, 125.0), ops.QuantGrid(0.025, 131.0)]
+    qc, kc = [torch.randint(-128, 128, (B, S, H * D), device=dev, dtype=torch.int8).view(B, S, H, D).permute(0, 2, 1, 3) for _ in range(2)]
+    vt = torch.randint(-128, 128, (B, H, D, S), device=dev, dtype=torch.int8)
+    val = ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, out_dtype=torch.float32, **kw)
+    rel = ops.attn_fwd_i8(qc, kc, vt, grids, fq=fqi, out_dtype=torch.float16, **kw)
+    assert torch.equal(rel, rel.round()) and torch.equal(rel.float() * np.float32(0.021), val)
+    gate = torch.rand(B, H, S, 1, device=dev)
+    with pytest.raises(_lib.OehError):
+        ops.attn_fwd(q, k, v, fq=fqi, gate=gate, **kw)
+    relg = ops.attn_fwd(q, k, v, fq=dataclasses.replace(fqi, ctx_before_gate=False), gate=gate, **kw)  # BERT order: the quantiser is last
+    valg = ops.attn_fwd(q, k, v, fq=dataclasses.replace(fq, ctx_before_gate=False), gate=gate, **kw)
+    assert torch.equal(relg * np.float32(0.021), valg)

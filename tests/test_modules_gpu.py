@@ -524,6 +524,18 @@ def test_quantised_opt_uses_the_int8_storage_core(oa, monkeypatch):
         out8, w8, past8 = qm(x, attention_mask=mask)
         out8n, _, _ = qm(x)
         assert len(calls) == 2 and w8 is None
+        # ... and out_proj ran on the context quantiser's integers (one 16-bit GEMM of integers, QuantLinear.linear_index); with
+        # the float hand-over instead (split pass + operand-pair GEMM) the outputs agree up to rare single steps of the output grid
+        assert qm.__dict__.get("_index_gemm_calls", 0) == 2
+        monkeypatch.setattr(Q, "INDEX_GEMM", False)
+        out8v, _, _ = qm(x, attention_mask=mask)
+        monkeypatch.setattr(Q, "INDEX_GEMM", True)
+        assert len(calls) == 3 and qm.__dict__["_index_gemm_calls"] == 2
+        calls.pop()
+        stepo = float(qm.out_proj.activation_quantizer.quantizer.delta)
+        erri = (out8 - out8v).abs()
+        print(f"quantised OPT: out_proj on integers vs on float values: max {float(erri.max()) / stepo:.2f} steps, {float((erri > 0.5 * stepo).float().mean()):.2e} of the outputs apart")
+        assert float(erri.max()) <= 1.05 * stepo and float((erri > 0.5 * stepo).float().mean()) < 1e-3
         monkeypatch.setattr(Q, "INT8_STORAGE", False)
         outf, _, pastf = qm(x, attention_mask=mask)
         outfn, _, _ = qm(x)

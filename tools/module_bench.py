@@ -116,11 +116,11 @@ def quantised():
         Q.FUSED_CALIBRATION = True
         qm.fix_ranges()
         x = torch.randn(B, S, E, device=dev)
-        for i8 in (False, True):
-            Q.INT8_STORAGE = i8
+        for i8, ig in ((False, False), (True, False), (True, True)):
+            Q.INT8_STORAGE, Q.INDEX_GEMM = i8, ig
             t_mod = timeit(lambda: qm(x, attention_mask=mask), n=50)
-            print(f"QuantizedOPT module fp32, INT8 storage core={i8}: {t_mod:8.1f} us  {B * S / t_mod:8.1f} M tokens/s")
-        Q.INT8_STORAGE = True
+            print(f"QuantizedOPT module fp32, INT8 storage core={i8}, out_proj on the context integers={ig}: {t_mod:8.1f} us  {B * S / t_mod:8.1f} M tokens/s")
+        Q.INT8_STORAGE, Q.INDEX_GEMM = True, True
         try:  # the frozen-range INT8 forward as a captured HIP graph
             qm(x, attention_mask=mask)
             torch.cuda.synchronize()
