@@ -151,6 +151,20 @@ def attn_fwd(
         raise ValueError(f"q/k/v dtypes must match and be fp16/bf16/fp32, got {q.dtype}, {k.dtype}, {v.dtype}")
     fix = lambda t: t if t.stride(3) == 1 else t.contiguous()  # noqa: E731
     q, k, v = fix(q), fix(k), fix(v)
+    Dp = _matrix_core_head_dim(D, Sq, Sk, plain=key_pad_mask is None and full_mask is None and not causal and fq is None)
+    if (Dp != D and gate_mlp is None and _prepared is None and (out is None or out.shape == (B, H, Sq, D))
+            and not (fq is not None and fq.ctx is not None and fq.ctx.dump is not None)):
+        # A head dim between the matrix-core kernels' (OPT-2.7b / ViT-H: 80; 96; 48; 16 with long rows ...): zero columns change
+        # neither the scores nor the other columns of the product - three pad copies and the next kernel size up instead of the
+        # any-shape kernel (one workgroup per query row, ~100x slower)
+        pad = lambda t: torch.nn.functional.pad(t, (0, Dp - D))  # noqa: E731
+        res = attn_fwd(pad(q), pad(k), pad(v), softmax=softmax, scale=scale, scale_div=scale_div, key_pad_mask=key_pad_mask, full_mask=full_mask,
+                       causal=causal, clamp_min=clamp_min, mask_min=float(torch.finfo(q.dtype).min if mask_min is None else mask_min), gate=gate,
+                       fq=fq)[..., :D]
+        if out is None:
+            return res
+        out.copy_(res)
+        return out
     if out is None:
         out = torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device).permute(0, 2, 1, 3)
     elif out.shape != (B, H, Sq, D) or out.dtype != q.dtype or out.stride(3) != 1:
@@ -229,6 +243,17 @@ def attn_fwd(
         rc = lib.oeh_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), None if fqd is None else C.byref(fqd), _stream())
     _lib.check(rc, "oeh_attn_fwd")
     return out
+
+
+def _matrix_core_head_dim(D: int, Sq: int, Sk: int, plain: bool) -> int:
+    """The head dim the problem is run at: D itself where a matrix-core kernel takes it (32, 64, 128; 16 for the small-shape
+    kernel: <= 64 rows, no mask, no fake-quant - `plain`), the next one up (zero-padded) below 128, D itself above (any-shape
+    kernel)."""
+    if D in (32, 64, 128) or D > 128:
+        return D
+    if D <= 16:
+        return 16 if (plain and Sq <= 64 and Sk <= 64) else 32
+    return 32 if D < 32 else (64 if D < 64 else 128)
 
 
 _warned_generic = set()

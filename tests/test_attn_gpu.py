@@ -186,9 +186,9 @@ def test_other_storage_dtypes(ops, dtype, tol):
 
 
 def test_generic_kernel_shapes(ops):
-    """Shapes outside the MFMA kernels (D = 48) run the any-shape HIP kernel; D = 16 with few rows has the small-shape kernel,
+    """Shapes outside the MFMA kernels (D = 160) run the any-shape HIP kernel; D = 16 with few rows has the small-shape kernel,
     clipped rows of more than 512 keys the two-pass kernel (16-bit and fp32 storage)."""
-    for (B, H, Sq, Sk, D, dt, name) in [(3, 4, 7, 5, 16, torch.float16, "small/ST2/D16/f16"), (1, 2, 33, 33, 48, torch.float16, "generic"),
+    for (B, H, Sq, Sk, D, dt, name) in [(3, 4, 7, 5, 16, torch.float16, "small/ST2/D16/f16"), (1, 2, 33, 33, 160, torch.float16, "generic"),
                                         (1, 1, 20, 700, 64, torch.float16, "flash16/MQ1/D64/f16/clip2p"), (1, 1, 20, 700, 64, torch.float32, "flash16/MQ1/D64/f32/clip2p")]:
         assert ops.attn_variant(B, H, Sq, Sk, D, dt, clip=True) == name
         q, k, v = _rand((B, H, Sq, D), 71, dtype=dt), _rand((B, H, Sk, D), 72, dtype=dt), _rand((B, H, Sk, D), 73, dtype=dt)
@@ -1450,3 +1450,33 @@ def test_context_quantiser_emits_its_integers(ops):
     relg = ops.attn_fwd(q, k, v, fq=dataclasses.replace(fqi, ctx_before_gate=False), gate=gate, **kw)  # BERT order: the quantiser is last
     valg = ops.attn_fwd(q, k, v, fq=dataclasses.replace(fq, ctx_before_gate=False), gate=gate, **kw)
     assert torch.equal(relg * np.float32(0.021), valg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,S,dt", [(80, 200, torch.float16), (96, 640, torch.float16), (48, 33, torch.float32), (16, 100, torch.float16), (8, 40, torch.float32),
+                                    (72, 130, torch.bfloat16)])
+def test_head_dims_between_the_kernels_are_zero_padded(ops, D, S, dt):
+    """OPT-2.7b / ViT-H have head dim 80, others 96 or 48: `ops.attn_fwd` runs them zero-padded at the next matrix-core head dim
+    (the library alone would pick the any-shape kernel: one workgroup per query row) - same result, no any-shape warning; with a
+    key-padding mask, a gate, an `out` tensor and the fused INT8 chain."""
+    import warnings
+
+    B, H = 2, 3
+    assert ops.attn_variant(B, H, S, S, D, dt, causal=True) == "generic"
+    q, k, v = _rand((B, H, S, D), 171, dtype=dt), _rand((B, H, S, D), 172, dtype=dt), _rand((B, H, S, D), 173, dtype=dt)
+    fmin = float(np.finfo(np.float32).min)
+    pad = _pad_mask(B, S, [S, S - 9], fmin)
+    gate = np.random.default_rng(3).random((B, H, S, 1), dtype=np.float32)
+    tol = None if dt == torch.float16 else (dict(atol=5e-4, rtol=5e-4) if dt == torch.float32 else BF16_TOL)  # (fp32: the probability operand is fp16)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=1 / math.sqrt(D), base=1, causal=True, clamp_min=True, mask_min=fmin)
+        got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), scale=1 / math.sqrt(D), causal=True, clamp_min=True, mask_min=fmin)
+        assert got.shape == (B, H, S, D)
+        _check(got, want, tol=tol, msg=f"causal D={D}")
+        want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=math.sqrt(D), scale_is_divisor=True, base=1, pad_mask=pad, mask_min=fmin, gate=gate)
+        out = torch.empty((B, S, H, D), dtype=dt, device="cuda").permute(0, 2, 1, 3)
+        got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), scale_div=math.sqrt(D), key_pad_mask=torch.from_numpy(pad).cuda(), mask_min=fmin,
+                           gate=torch.from_numpy(gate).cuda(), out=out)
+        assert got is out
+        _check(got, want, tol=tol, msg=f"padded + gated D={D}")
