@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the kernel variants (GPU box): random problems - shapes, dtypes, layouts, masks, softmax family, gate,
+fused INT8 chain - through `ops.attn_fwd` as the library picks the kernel, against the any-shape kernel (one workgroup per query
+row, fp32 FMAs; forced through include/oeh_debug.h) on the same inputs.  Prints every disagreement with the parameters that
+reproduce it and a summary per variant.   usage: python tools/fuzz_variants.py [seconds=120] [seed=0]"""
+import collections
+import ctypes as C
+import os
+import sys
+import time
+
+os.environ.setdefault("OEH_DEBUG_HOOKS", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from outeffhop_amd import _lib, ops
+
+GENERIC_ONLY = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 5) | (1 << 6) | (1 << 7)
+
+
+def ulp16(x):
+    ax = np.maximum(np.abs(x), 2.0 ** -14)
+    return 2.0 ** (np.floor(np.log2(ax)) - 10)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    fmin = float(np.finfo(np.float32).min)
+    stats = collections.Counter()
+    bad = 0
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < budget:
+        n += 1
+        B, H = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+        D = int(rng.choice([32, 64, 64, 64, 128, 16, 80, 48]))
+        Sq = int(rng.choice([rng.integers(1, 40), rng.integers(1, 200), rng.integers(1, 700)]))
+        Sk = Sq if rng.random() < 0.7 else int(rng.integers(1, 700))
+        dt = [torch.float16, torch.float16, torch.bfloat16, torch.float32][int(rng.integers(0, 4))]
+        causal = bool(rng.random() < 0.4) and Sq <= Sk
+        use_pad = bool(rng.random() < 0.35)
+        use_full = bool(rng.random() < 0.12)
+        base = int(rng.integers(0, 2))
+        clip = bool(rng.random() < 0.3)
+        gam, eta = ((-0.025, 1.1) if rng.random() < 0.5 else (-0.003, 1.003)) if clip else (0.0, 1.0)
+        use_gate = bool(rng.random() < 0.25)
+        use_fq = bool(rng.random() < 0.3) and dt != torch.bfloat16
+        div = bool(rng.random() < 0.4)
+        permuted = bool(rng.random() < 0.6)
+        g = torch.Generator(device="cuda").manual_seed(int(rng.integers(0, 2 ** 31)))
+
+        def mk(S, s):
+            if permuted:
+                return (torch.randn(B, S, H * D, device=dev, generator=g) * s).to(dt).view(B, S, H, D).permute(0, 2, 1, 3)
+            return (torch.randn(B, H, S, D, device=dev, generator=g) * s).to(dt)
+
+        q, k, v = mk(Sq, 1.0 if div else D ** -0.5), mk(Sk, 1.0), mk(Sk, 1.0)
+        kw = dict(softmax=ops.SoftmaxSpec(base, clip, gam, eta), causal=causal, clamp_min=bool(causal or use_full or rng.random() < 0.2), mask_min=fmin)
+        if div:
+            kw["scale_div"] = float(np.sqrt(D))
+        else:
+            kw["scale"] = float(rng.choice([1.0, 1.0, 0.5, 1.3]))
+        if use_pad:
+            pad = torch.zeros(B, Sk, device=dev)
+            for b in range(B):
+                L = int(rng.choice([Sk, rng.integers(0, Sk + 1), rng.integers(max(Sk - 20, 0), Sk + 1)]))
+                if rng.random() < 0.2 and L < Sk:   # left padding
+                    pad[b, : Sk - L] = fmin
+                else:
+                    pad[b, L:] = fmin
+            kw["key_pad_mask"] = pad
+        if use_full:
+            fm = torch.zeros(B, 1, Sq, Sk, device=dev)
+            fm[torch.rand(B, 1, Sq, Sk, device=dev, generator=g) < 0.3] = fmin
+            kw["full_mask"] = fm
+        if use_gate:
+            kw["gate"] = torch.rand(B, H, Sq, 1, device=dev, generator=g)
+        step = None
+        if use_fq:
+            FQ = ops.FakeQuantSpec
+            step = float(rng.choice([0.01, 0.02, 0.05]))
+            kw["fq"] = ops.AttnFakeQuant(FQ(float(rng.choice([0.05, 0.1, 0.2])), float(rng.integers(100, 160))), FQ(1.0 / 255.0, 0.0),
+                                         FQ(step, float(rng.integers(110, 146))), ctx_before_gate=bool(rng.random() < 0.5))
+        desc = (f"B={B} H={H} Sq={Sq} Sk={Sk} D={D} {str(dt)[6:]} causal={int(causal)} pad={int(use_pad)} full={int(use_full)} base={base} clip={int(clip)}"
+                f" gate={int(use_gate)} fq={int(use_fq)} div={int(div)} perm={int(permuted)} clamp={int(kw['clamp_min'])} scale={kw.get('scale')}")
+        try:
+            lib.oeh_debug_set_variant(0, 0)
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                var = ops.attn_variant(B, H, Sq, Sk, D, dt, fq=use_fq, clip=clip, base=base, gamma=gam, key_pad=use_pad, full_mask=use_full, causal=causal,
+                                       scale=kw.get("scale", 1.0), scale_div=kw.get("scale_div", 0.0), mask_min=fmin) if D in (16, 32, 64, 128) else f"padded-D{D}"
+                got = ops.attn_fwd(q, k, v, **kw).float().cpu().numpy()
+                lib.oeh_debug_set_variant(GENERIC_ONLY, 0)
+                ref = ops.attn_fwd(q, k, v, **kw).float().cpu().numpy()
+        finally:
+            lib.oeh_debug_set_variant(0, 0)
+        key = (var or "none").split("/")[0] + ("/" + "/".join((var or "").split("/")[4:]) if var and len(var.split("/")) > 4 else "")
+        stats[key] += 1
+        err = np.abs(got - ref)
+        if not np.isfinite(got).all():
+            print("NON-FINITE", var, desc, flush=True)
+            bad += 1
+            continue
+        if use_fq:
+            # Both paths end on the context grid.  The two kernels sum a score's products in different orders, so a score that sits
+            # on a rounding boundary of its grid can take the neighbouring index in one of them (rate ~1e-5 per score) and that
+            # row's probabilities - hence its context values - then differ by several steps: such rows are counted as ties, not as
+            # disagreements, while they stay a small share of the outputs.
+            off = float((err > 0.5 * step + 2e-3).mean())
+            worst = float(err.max() / step)
+            if off > 1e-2:
+                print(f"FQ MISMATCH {var}: max {worst:.2f} steps, {off:.2e} apart | {desc}", flush=True)
+                bad += 1
+            elif worst > 2.05:
+                stats["(fq problems with a boundary tie)"] += 1
+        else:
+            if dt == torch.float16:
+                lim = 2e-3 + ulp16(ref)
+            elif dt == torch.bfloat16:
+                lim = 2e-2 + 2e-2 * np.abs(ref)
+            else:
+                lim = 1.5e-3 + 5e-4 * np.abs(ref)  # fp32 storage: fp32-accurate scores (operand pairs), the probability operand of the second product is fp16
+            if (err > lim).any():
+                i = np.unravel_index((err - lim).argmax(), err.shape)
+                print(f"MISMATCH {var}: max err {err.max():.3e} at {i} got {got[i]:.5f} ref {ref[i]:.5f} | {desc}", flush=True)
+                bad += 1
+    print(f"{n} problems in {time.time() - t0:.0f} s, {bad} disagreements; kernels exercised:", dict(stats))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
