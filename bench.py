@@ -465,6 +465,7 @@ def main():
         else:
             dsc.scale, dsc.scale_div = 1.0, 8.0
             dsc.key_pad_mask, dsc.key_pad_dtype, dsc.key_pad_stride = pad.data_ptr(), _lib.OEH_F32, pad.stride(0)
+            dsc.key_pad_boolean = 1  # HF's extended mask: 0 / finfo.min entries (what the modules verify once per mask tensor)
         dsc.softmax_base, dsc.clip, dsc.gamma, dsc.eta, dsc.mask_min = base, int(clip), gamma, eta, fmin
         if hd is not None:  # per-layer predictor input: the gate is evaluated in the kernel
             dsc.gate_hidden = hd.data_ptr()

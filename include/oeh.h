@@ -154,6 +154,15 @@ typedef struct oeh_attn_desc {
    * quantises before the mask is added), probabilities, context - same layouts as everywhere. */
   struct { float scale; float zero_point; } q_grid, k_grid, v_grid;
   int32_t o_dtype;
+
+  /* (appended in ABI 4: fields are only ever added at the end of a descriptor) */
+  int32_t key_pad_boolean;       /* key_pad_mask: the caller's promise that every entry is 0 or <= -1e4 (HF's extended masks: 0 / finfo.min):
+                                    a padded key is then simply invisible and the INT8 chain can stay on the quantiser grid with
+                                    key padding too (full-row kernel's grid form, two-pass form for rows of more than 512 keys)
+                                    instead of the reference's op order on dequantised values.  With moderate negative entries
+                                    (an additive bias rather than a mask) leave it 0.  Same result as the literal order except
+                                    for a row WITHOUT any visible key whose mask entries are not absorbing (> -1e30): such a
+                                    row comes out as with finfo.min entries.  dtype OEH_I8 always reads the mask this way. */
 } oeh_attn_desc;
 
 /* QK^T -> scale -> [fq] -> mask -> softmax / softmax_1 -> [clip] -> [fq] -> PV -> [fq] -> gate -> [fq]

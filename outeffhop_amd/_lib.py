@@ -55,6 +55,7 @@ class oeh_attn_desc(C.Structure):
         ("gate_w1", C.c_void_p), ("gate_b1", C.c_void_p), ("gate_w2", C.c_void_p), ("gate_b2", C.c_void_p),
         ("gate_units", C.c_int32), ("gate_scaling", C.c_float), ("gate_out", C.c_void_p),
         ("q_grid", oeh_grid), ("k_grid", oeh_grid), ("v_grid", oeh_grid), ("o_dtype", C.c_int32),
+        ("key_pad_boolean", C.c_int32),
     ]
 
 

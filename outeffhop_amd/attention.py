@@ -345,7 +345,10 @@ def attention_core(
     if mask_min is None:
         mdt = attention_mask.dtype if attention_mask is not None and attention_mask.is_floating_point() else q.dtype
         mask_min = float(torch.finfo(mdt).min)
-    kw = dict(softmax=spec, scale=scale, scale_div=scale_div, key_pad_mask=pad, full_mask=full, causal=causal,
+    # the fused INT8 chain stays on the quantiser grid with padded keys when the mask is a mask (0 / finfo.min entries - what
+    # classify_causal has verified for a decoder mask; else one look per mask tensor object): include/oeh.h key_pad_boolean
+    pad_bool = pad is not None and fq is not None and (causal or pad_is_boolean(attention_mask))
+    kw = dict(softmax=spec, scale=scale, scale_div=scale_div, key_pad_mask=pad, full_mask=full, key_pad_boolean=pad_bool, causal=causal,
               clamp_min=clamp_min, mask_min=mask_min, fq=fq)
     out = None
     if gate_mlp is not None:

@@ -290,6 +290,7 @@ void fill_params(AttnParams& P, const oeh_attn_desc* d, const void* q, const voi
   P.clip_w = (float)((double)d->eta - (double)d->gamma);
   P.clip_g = d->gamma;
   P.pad = d->key_pad_mask; P.pad_f16 = d->key_pad_dtype == OEH_F16; P.pad_sb = d->key_pad_stride;
+  P.pad_bool = (d->key_pad_mask != nullptr && d->key_pad_boolean && d->mask_min < -1.0e4f) ? 1 : 0;
   P.full = d->full_mask; P.full_f16 = d->full_mask_dtype == OEH_F16;
   P.full_sb = d->full_mask_stride[0]; P.full_sq = d->full_mask_stride[1];
   P.causal = d->causal ? 1 : 0; P.clamp_min = d->clamp_min ? 1 : 0; P.mask_min = d->mask_min;

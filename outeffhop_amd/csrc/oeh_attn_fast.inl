@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
   static_assert(!SRC32 || (!GATE && IN == IN_F16), "fp32 storage: fp16 operand pairs, fp32 output, no in-kernel gate predictor");
   constexpr bool OUT32 = SRC32;
   static_assert(!FQ || !GATE, "the fake-quant variant has no in-kernel gate predictor");
-  static_assert(FQ != 1 || !CLIP, "FQ == 1 (the chain on the quantiser grid) is the unclipped form");
+  static_assert(!(FQ == 1 || FQ == 3) || !CLIP, "FQ == 1 / 3 (the chain on the quantiser grid) is the unclipped form");
+  constexpr bool GRID = (FQ == 1 || FQ == 3), GRIDPAD = (FQ == 3);  // FQ == 3: the grid chain with a key-padding vector of 0 / <= -1e4 entries
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
   constexpr int KT = NT / 4;
   constexpr int ROWB = 2 * D;
@@ -286,7 +287,14 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
   }
   const bool has_pad = P.pad != nullptr;
   if (has_pad) {  // (compiler-visible loads: its wait for them also covers the transfers above, which the next wait needs anyway)
-    for (int i = tid; i < NT * 16; i += 256) lds_pad[i] = (i < P.Sk) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + i) : 0.0f;
+    for (int i = tid; i < NT * 16; i += 256) {
+      float f = (i < P.Sk) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + i) : 0.0f;
+      if constexpr (GRIDPAD) {  // the grid chain (key_pad_boolean): per key +big (visible), the sentinel (padded) or -inf (past Sk: not even
+        // a masked key - a row without a visible key is uniform over the Sk keys under the vanilla softmax, as in the reference)
+        f = (i < P.Sk) ? (f < -1.0e4f ? -1.0e30f : 3.0e38f) : -__builtin_inff();
+      }
+      lds_pad[i] = f;
+    }
   }
   if constexpr (!SRC32) wait_tiles_in_flight<G>(min(2, T));  // Q landed; the one or two tiles behind it may still be in flight
   barrier_mem();
@@ -393,8 +401,9 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
     const int klimc = qrow + off;                                          // last key a causal row may see
     const int kt_causal = causal ? (max(0, q0 + off + 1) >> 6) : KT;       // first 64-key tile with a key the wave's first row must not see
     const int kt_tail = Sk >> 6;                                           // first 64-key tile with a key >= Sk
-    if constexpr (FQ == 1) {
-      // ---- the chain on the quantiser GRID (no key padding, no clipping: OPT's configuration).  Once a score is on its
+    if constexpr (GRID) {
+      // ---- the chain on the quantiser GRID (no clipping; key padding only as a vector of 0 / <= -1e4 entries - include/oeh.h
+      // key_pad_boolean: a flag per key in LDS, rel = min(rel, flag), one instruction per element - OPT's and BERT's configuration).  Once a score is on its
       // grid only the integer rel = idx - zp matters: the row maximum is scale * max(rel), x - m is scale * (rel - rel_max)
       // - formed here without the reference's two roundings of scale * rel - and exp(x - m) = exp2((rel - rel_max) * c2)
       // needs no range reduction: the argument's rounding error is 2^-24 |t|, i.e. below one ulp of the result wherever the
@@ -416,17 +425,22 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         if (kt < n_kt) {
-          const bool open_tile = kt < kt_causal && kt < kt_tail;               // no mask touches this 64-key tile (wave-uniform)
+          const bool open_tile = !GRIDPAD && kt < kt_causal && kt < kt_tail;   // no mask touches this 64-key tile (wave-uniform)
           const int lim = klim_g - 64 * kt;                                    // element (sub, r) is masked when 16 sub + r > lim
 #pragma unroll
-          for (int sub = 0; sub < 4; ++sub) {
+          for (int sub = 0; sub < 4; ++sub) {  // (as ONE body: an open and a masked copy of it cost 37 spilled registers at NT = 32)
             const int t = kt * 4 + sub;
             f4 rel;
 #pragma unroll
             for (int r = 0; r < 4; ++r) rel[r] = grid_rel_m(s[t][r], k1, slo, shi);
-            if (!open_tile) {
+            if (!open_tile && (!GRIDPAD || kt >= kt_causal || kt >= kt_tail)) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) rel[r] = (16 * sub + r > lim) ? RELMASK : rel[r];
+            }
+            if constexpr (GRIDPAD) {
+              const f4 flag = *reinterpret_cast<const f4*>(&lds_pad[16 * t + 4 * g]);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) rel[r] = __builtin_fminf(rel[r], flag[r]);
             }
             s[t] = rel;
           }
@@ -825,10 +839,12 @@ template <int NT, int D, int IN>
 static void launch_fast_nt_d_in(const AttnParams& P, unsigned grid, hipStream_t st) {
   const bool gate = P.gh != nullptr;
   const bool fqon = P.fq_s.en && P.fq_p.en;
-  const bool grid_chain = fqon && !P.clip && P.pad == nullptr;  // FQ == 1
+  const bool grid_chain = fqon && !P.clip && (P.pad == nullptr || P.pad_bool);  // FQ == 1, or 3 with a key-padding vector (include/oeh.h: key_pad_boolean)
+  const bool grid_pad = grid_chain && P.pad != nullptr;
   if (P.src32) {  // fp32 storage read directly, fp32 output
     if constexpr (IN == IN_F16) {
-      if (grid_chain) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 1, true>), dim3(grid), dim3(256), 0, st, P);
+      if (grid_pad) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 3, true>), dim3(grid), dim3(256), 0, st, P);
+      else if (grid_chain) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 1, true>), dim3(grid), dim3(256), 0, st, P);
       else if (fqon && P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 2, true>), dim3(grid), dim3(256), 0, st, P);
       else if (fqon) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 2, true>), dim3(grid), dim3(256), 0, st, P);
       else if (P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 0, true>), dim3(grid), dim3(256), 0, st, P);
@@ -837,7 +853,8 @@ static void launch_fast_nt_d_in(const AttnParams& P, unsigned grid, hipStream_t 
     return;
   }
   if (fqon) {
-    if (grid_chain) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 1>), dim3(grid), dim3(256), 0, st, P);
+    if (grid_pad) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 3>), dim3(grid), dim3(256), 0, st, P);
+    else if (grid_chain) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 1>), dim3(grid), dim3(256), 0, st, P);
     else if (P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 2>), dim3(grid), dim3(256), 0, st, P);
     else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 2>), dim3(grid), dim3(256), 0, st, P);
     return;

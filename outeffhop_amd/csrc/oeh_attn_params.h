@@ -46,6 +46,7 @@ struct AttnParams {
   int nBH, nBHpad;            // B*H and B*H rounded up to a multiple of 8 (XCD affinity of a head's q tiles)
   unsigned magic_nbh, magic_h;  // floor(2^32 / nBHpad), floor(2^32 / H): block id -> (q tile, batch, head) without integer divisions (oeh_common.h: div_magic)
   int skip_ok;                // causal tiles above the diagonal may be skipped (see oeh_api.hip)
+  int pad_bool;   // key_pad_boolean (include/oeh.h): mask entries are 0 or <= -1e4
   int head_major;             // fp32-storage kernels: block order in groups of this many heads (0 = all heads' heaviest q tiles first;
                               // oeh_common.h: block_to_tile)
   int snake;                  // one-pass kernel: every second row of 256 block ids walked backwards (snake_block_id, oeh_common.h)

@@ -125,6 +125,7 @@ def attn_fwd(
     scale_div: float = 0.0,
     key_pad_mask: Optional[torch.Tensor] = None,
     full_mask: Optional[torch.Tensor] = None,
+    key_pad_boolean: bool = False,
     causal: bool = False,
     clamp_min: bool = False,
     mask_min: Optional[float] = None,
@@ -138,7 +139,8 @@ def attn_fwd(
     stride).  Returns the logical (B,H,Sq,D) result, stored (B,Sq,H,D)-contiguous unless `out` is given, so the
     reference's head merge (bert_attention.py:335-337) is a free `.permute(0,2,1,3).reshape(B,Sq,H*D)`.
 
-    key_pad_mask: additive (B,Sk) [or anything reshapeable to it, e.g. HF's (B,1,1,Sk)];
+    key_pad_mask: additive (B,Sk) [or anything reshapeable to it, e.g. HF's (B,1,1,Sk)]; key_pad_boolean: the caller's promise that
+    its entries are 0 or <= -1e4 only (include/oeh.h - lets the fused INT8 chain stay on the quantiser grid with padded keys);
     full_mask: additive (B,1,Sq,Sk); gate: fp32, broadcastable to (B,H,Sq,1), already times the scaling factor."""
     dev = _need_gpu(q, k, v, key_pad_mask, full_mask, gate, out)
     if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
@@ -159,7 +161,7 @@ def attn_fwd(
         # any-shape kernel (one workgroup per query row, ~100x slower)
         pad = lambda t: torch.nn.functional.pad(t, (0, Dp - D))  # noqa: E731
         res = attn_fwd(pad(q), pad(k), pad(v), softmax=softmax, scale=scale, scale_div=scale_div, key_pad_mask=key_pad_mask, full_mask=full_mask,
-                       causal=causal, clamp_min=clamp_min, mask_min=float(torch.finfo(q.dtype).min if mask_min is None else mask_min), gate=gate,
+                       key_pad_boolean=key_pad_boolean, causal=causal, clamp_min=clamp_min, mask_min=float(torch.finfo(q.dtype).min if mask_min is None else mask_min), gate=gate,
                        fq=fq)[..., :D]
         if out is None:
             return res
@@ -185,6 +187,7 @@ def attn_fwd(
         m = m.contiguous()
         keep.append(m)
         d.key_pad_mask, d.key_pad_dtype, d.key_pad_stride = m.data_ptr(), _DT[m.dtype], m.stride(0)
+        d.key_pad_boolean = int(bool(key_pad_boolean))
     if full_mask is not None:
         if full_mask.shape != (B, 1, Sq, Sk):
             raise ValueError(f"Attention mask should be of size {(B, 1, Sq, Sk)}, but is {tuple(full_mask.shape)}")
@@ -405,6 +408,7 @@ def attn_fwd_i8(q: torch.Tensor, k: torch.Tensor, v_t: torch.Tensor, grids, *, f
             pm = pm.contiguous()
         keep.append(pm)
         d.key_pad_mask, d.key_pad_dtype, d.key_pad_stride = pm.data_ptr(), _DT[pm.dtype], pm.stride(0)
+        d.key_pad_boolean = 1  # (this path always reads the mask that way: include/oeh.h)
     if gate is not None:
         g = gate.to(torch.float32)
         while g.dim() < 4:
@@ -472,7 +476,7 @@ class PreparedAttn:
 
 def attn_variant(B, H, Sq, Sk, D, dtype=torch.float16, fq: bool = False, clip: bool = False, *, base: int = 1, gamma: float = -0.025,
                  key_pad: bool = False, full_mask: bool = False, causal: bool = False, scale: float = 1.0, scale_div: float = 0.0,
-                 mask_min: Optional[float] = None) -> Optional[str]:
+                 mask_min: Optional[float] = None, key_pad_boolean: bool = False) -> Optional[str]:
     """Name of the kernel variant the library would pick for this problem (host only; no GPU needed)."""
     d = oeh_attn_desc()
     d.B, d.H, d.Sq, d.Sk, d.D, d.dtype = B, H, Sq, Sk, D, _DT[dtype]
@@ -480,7 +484,7 @@ def attn_variant(B, H, Sq, Sk, D, dtype=torch.float16, fq: bool = False, clip: b
     d.mask_min = float(torch.finfo(torch.float32).min if mask_min is None else mask_min)
     d.softmax_base, d.causal = int(base), int(bool(causal))
     # only nullness of the mask pointers matters to the selection (host only: nothing is dereferenced)
-    d.key_pad_mask, d.key_pad_dtype = (1 if key_pad else None), OEH_F32
+    d.key_pad_mask, d.key_pad_dtype, d.key_pad_boolean = (1 if key_pad else None), OEH_F32, int(bool(key_pad_boolean))
     d.full_mask, d.full_mask_dtype = (1 if full_mask else None), OEH_F32
     if clip:
         d.clip, d.gamma, d.eta = 1, float(gamma), 1.0

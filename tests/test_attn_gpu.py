@@ -1480,3 +1480,47 @@ def test_head_dims_between_the_kernels_are_zero_padded(ops, D, S, dt):
                            gate=torch.from_numpy(gate).cuda(), out=out)
         assert got is out
         _check(got, want, tol=tol, msg=f"padded + gated D={D}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["bert", "opt"])
+@pytest.mark.parametrize("base", [1, 0])
+@pytest.mark.parametrize("S,dt", [(96, torch.float16), (512, torch.float16), (176, torch.float32)])
+def test_int8_grid_chain_with_key_padding(ops, order, base, S, dt):
+    """include/oeh.h key_pad_boolean: with a key-padding vector of 0 / finfo.min entries the fused INT8 chain stays on the quantiser
+    grid (full-row kernel's grid form: a flag per key, one instruction per element) instead of the reference's op order on
+    dequantised values - BERT order and OPT order with padded keys on top of the causal mask, right- and left-padded samples and one
+    without a visible key (softmax_1: zeros; vanilla: uniform over all keys): against the oracle, and against the literal form
+    (the same call without the promise) up to rare single steps."""
+    B, H, D = 4, 2, 64
+    fmin = float(np.finfo(np.float32).min)
+    q, k, v = _rand((B, H, S, D), 181, dtype=dt), _rand((B, H, S, D), 182, dtype=dt), _rand((B, H, S, D), 183, dtype=dt)
+    if order == "opt":
+        q = (q.float() * D ** -0.5).to(dt)
+    padm = _pad_mask(B, S, [S, S - 37, S, 0], fmin)
+    padm[2, :21] = fmin   # a left-padded sample
+    common = dict(base=base, causal=(order == "opt"), clamp_min=True, pad_mask=padm, mask_min=fmin)
+    if order == "bert":
+        common.update(scale=8.0, scale_is_divisor=True)
+    vis = dict(common, pad_mask=None)
+    _, fp = O.attn_core(_np32(q), _np32(k), _np32(v), want=("scores", "probs"), **vis)
+    d_s = O.quant_range_to_params(*np.percentile(fp["scores"], (0.001, 99.999)))
+    d_p = O.quant_range_to_params(*np.percentile(fp["probs"], (0.001, 99.999)))
+    d_c = O.quant_range_to_params(*np.percentile(O.attn_core(_np32(q), _np32(k), _np32(v), **vis), (0.001, 99.999)))
+    want = O.attn_core(_np32(q), _np32(k), _np32(v), fq_scores=d_s, fq_probs=d_p, fq_ctx=d_c, **common)
+    FQ = ops.FakeQuantSpec.from_delta
+    fq = ops.AttnFakeQuant(FQ(*d_s), FQ(*d_p), FQ(*d_c))
+    args = dict(softmax=ops.SoftmaxSpec(base), causal=(order == "opt"), clamp_min=True, mask_min=fmin, key_pad_mask=torch.from_numpy(padm).cuda(), fq=fq)
+    if order == "bert":
+        args["scale_div"] = 8.0
+    grid = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), key_pad_boolean=True, **args)
+    literal = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), **args)
+    step = float(np.float32(d_c[0]))
+    for name, got in (("grid", grid), ("literal", literal)):
+        err = np.abs(_np32(got) - want)
+        off = float((err > 0.5 * step).mean())
+        assert np.isfinite(_np32(got)).all() and off < 4e-3 and err.max() <= 2.05 * step + 2e-3, f"{name}: {off:.2e} off, max {err.max() / step:.2f} steps"
+    d = (grid.float() - literal.float()).abs()
+    assert float((d > 0.5 * step).float().mean()) < 2e-3 and float(d.max()) <= 2.05 * step + 2e-3
+    if base == 1:
+        assert float(grid[3].abs().max()) <= abs(float(np.float32(d_c[0])) * 0.51) + abs(want[3]).max()  # the sample without a visible key

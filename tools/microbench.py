@@ -21,7 +21,7 @@ from outeffhop_amd import _lib, ops
 
 
 def run(spec):
-    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, reps=1, graph=0, gmlp=-1, ab="", i8=0, hg=0)
+    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, reps=1, graph=0, gmlp=-1, ab="", i8=0, hg=0, padbool=1)
     for item in spec.split(","):
         k, v = item.split("=")
         kv[k] = v if k in ("dtype", "ab") else int(v)
@@ -64,7 +64,7 @@ def run(spec):
         fq = ops.AttnFakeQuant(FQ(0.08, 128.0), FQ(1.0 / 255.0, 0.0), FQ(0.02, 128.0))
     spec_sm = ops.SoftmaxSpec(kv["base"], bool(kv["clip"]), -0.025 if kv["clip"] else 0.0, 1.1 if kv["clip"] else 1.0)
     out = torch.empty(B, S, H, D, dtype=dt, device="cuda").permute(0, 2, 1, 3)
-    kw = dict(softmax=spec_sm, causal=bool(kv["causal"]), clamp_min=bool(kv["causal"] or kv["full"]), key_pad_mask=pad, full_mask=full,
+    kw = dict(softmax=spec_sm, causal=bool(kv["causal"]), clamp_min=bool(kv["causal"] or kv["full"]), key_pad_mask=pad, key_pad_boolean=pad is not None and bool(kv.get("padbool", 1)), full_mask=full,
               gate=gate, fq=fq, mask_min=fmin, out=out, gate_mlp=gmlp)
     if kv["i8"]:  # INT8 storage on the integer matrix cores (dtype = the output's): random indices, v transposed
         FQ = ops.FakeQuantSpec
