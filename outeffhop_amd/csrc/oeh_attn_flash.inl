@@ -64,7 +64,7 @@ template <int D, int IN, int MQ, bool PAD, bool GATE, bool SRC32 = false, int TP
 __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_attn_flash_kernel(const AttnParams P) {
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit matrix-core operands");
   constexpr bool CLIP = (TP == 1), FQ2 = (TP == 2);
-  static_assert(TP == 0 || (!PAD && !GATE), "two-pass forms: no key padding, no in-kernel gate predictor");
+  static_assert(TP == 0 || !GATE, "two-pass forms: no in-kernel gate predictor");
   static_assert(!SRC32 || (!GATE && IN == IN_F16), "fp32 storage: fp16 operands, fp32 output, no in-kernel gate predictor");
   constexpr bool OUT32 = SRC32;
   static_assert(MQ == 1 || MQ == 2, "one or two query blocks per wave");
@@ -467,6 +467,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     }
     __builtin_amdgcn_s_setprio(0);
     // exponent arguments t = (s - reference) * log2e  [key padding: BERT order scale*s + pad first]
+    f4 padflag[(has_pad && MODE >= 3) ? 4 : 1];  // the grid chain with key padding (key_pad_boolean): +big for a visible key, the sentinel for a padded one
     if constexpr (has_pad) {
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
@@ -478,10 +479,15 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
 #pragma unroll
           for (int r = 0; r < 4; ++r) padv[r] = (kb + r < Sk) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + kb + r) : 0.0f;
         }
+        if constexpr (MODE >= 3) {
 #pragma unroll
-        for (int j = J0; j < MQ; ++j)
+          for (int r = 0; r < 4; ++r) padflag[sub][r] = padv[r] < -1.0e4f ? NEGT : 3.0e38f;
+        } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[j][sub][r] = __builtin_fmaxf(__builtin_fmaf(s[j][sub][r], sc, padv[r]), NEG);
+          for (int j = J0; j < MQ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[j][sub][r] = __builtin_fmaxf(__builtin_fmaf(s[j][sub][r], sc, padv[r]), NEG);
+        }
       }
     }
     if constexpr (MODE >= 3) {  // the score quantiser's integer rel = idx - zp (masked keys get the -1e30 sentinel below)
@@ -490,7 +496,10 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[j][sub][r] = grid_rel_m(s[j][sub][r], fq_k1, fq_slo, fq_shi);
+          for (int r = 0; r < 4; ++r) {
+            s[j][sub][r] = grid_rel_m(s[j][sub][r], fq_k1, fq_slo, fq_shi);
+            if constexpr (has_pad) s[j][sub][r] = __builtin_fminf(s[j][sub][r], padflag[sub][r]);
+          }
     } else {
 #pragma unroll
     for (int j = J0; j < MQ; ++j)
@@ -869,19 +878,23 @@ static void launch_flash_d_mq_in(const AttnParams& P, unsigned grid, hipStream_t
   const bool pad = P.pad != nullptr, gate = P.gh != nullptr;
   if (P.src32) {  // fp32 storage read directly, fp32 output; no in-kernel gate predictor on this path
     if constexpr (IN == IN_F16 && !(D == 128 && MQ == 2)) {  // (d = 128 with two blocks per wave: never selected, oeh_api.hip: flash_mq)
-      if (P.fq_s.en) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true, 2>), dim3(grid), dim3(256), 0, st, P);
+      if (P.fq_s.en && pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, true, 2>), dim3(grid), dim3(256), 0, st, P);
+      else if (P.fq_s.en) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true, 2>), dim3(grid), dim3(256), 0, st, P);
+      else if (P.clip && pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, true, 1>), dim3(grid), dim3(256), 0, st, P);
       else if (P.clip) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true, 1>), dim3(grid), dim3(256), 0, st, P);
       else if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, true>), dim3(grid), dim3(256), 0, st, P);
       else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, true>), dim3(grid), dim3(256), 0, st, P);
     }
     return;
   }
-  if (P.fq_s.en) {  // (oeh_api.hip: flash_fq_eligible - the grid chain: no key padding, no clip, no in-kernel predictor)
-    hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, false, 2>), dim3(grid), dim3(256), 0, st, P);
+  if (P.fq_s.en) {  // (oeh_api.hip: flash_fq_eligible - the grid chain: no clip, no in-kernel predictor; key padding as a 0 / <= -1e4 vector)
+    if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, false, 2>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, false, 2>), dim3(grid), dim3(256), 0, st, P);
     return;
   }
-  if (P.clip) {  // (oeh_api.hip: flash_clip_eligible - no key padding, no in-kernel predictor)
-    hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, false, 1>), dim3(grid), dim3(256), 0, st, P);
+  if (P.clip) {  // (oeh_api.hip: flash_clip_eligible - no in-kernel predictor)
+    if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, false, 1>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, false, 1>), dim3(grid), dim3(256), 0, st, P);
     return;
   }
   if (pad) {

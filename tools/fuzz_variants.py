@@ -74,6 +74,7 @@ def main():
                 else:
                     pad[b, L:] = fmin
             kw["key_pad_mask"] = pad
+            kw["key_pad_boolean"] = bool(rng.random() < 0.5)   # (the entries are 0 / finfo.min: the promise holds)
         if use_full:
             fm = torch.zeros(B, 1, Sq, Sk, device=dev)
             fm[torch.rand(B, 1, Sq, Sk, device=dev, generator=g) < 0.3] = fmin
@@ -87,13 +88,13 @@ def main():
             kw["fq"] = ops.AttnFakeQuant(FQ(float(rng.choice([0.05, 0.1, 0.2])), float(rng.integers(100, 160))), FQ(1.0 / 255.0, 0.0),
                                          FQ(step, float(rng.integers(110, 146))), ctx_before_gate=bool(rng.random() < 0.5))
         desc = (f"B={B} H={H} Sq={Sq} Sk={Sk} D={D} {str(dt)[6:]} causal={int(causal)} pad={int(use_pad)} full={int(use_full)} base={base} clip={int(clip)}"
-                f" gate={int(use_gate)} fq={int(use_fq)} div={int(div)} perm={int(permuted)} clamp={int(kw['clamp_min'])} scale={kw.get('scale')}")
+                f" gate={int(use_gate)} fq={int(use_fq)} padbool={int(kw.get('key_pad_boolean', False))} div={int(div)} perm={int(permuted)} clamp={int(kw['clamp_min'])} scale={kw.get('scale')}")
         try:
             lib.oeh_debug_set_variant(0, 0)
             import warnings
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
-                var = ops.attn_variant(B, H, Sq, Sk, D, dt, fq=use_fq, clip=clip, base=base, gamma=gam, key_pad=use_pad, full_mask=use_full, causal=causal,
+                var = ops.attn_variant(B, H, Sq, Sk, D, dt, fq=use_fq, clip=clip, base=base, gamma=gam, key_pad=use_pad, key_pad_boolean=kw.get('key_pad_boolean', False), full_mask=use_full, causal=causal,
                                        scale=kw.get("scale", 1.0), scale_div=kw.get("scale_div", 0.0), mask_min=fmin) if D in (16, 32, 64, 128) else f"padded-D{D}"
                 got = ops.attn_fwd(q, k, v, **kw).float().cpu().numpy()
                 lib.oeh_debug_set_variant(GENERIC_ONLY, 0)
