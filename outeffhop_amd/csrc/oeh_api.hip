@@ -147,12 +147,11 @@ bool fast_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
 
 int g_force_flash = 0;                   // tools/microbench.py only
 
-// The one-pass kernel (oeh_attn_flash.inl) additionally needs the plain softmax_n (no clip) and, with key padding,
-// softmax_1 (a fully padded row is 0 there; under vanilla softmax it is uniform over all keys, which a one-pass
-// kernel that may skip tiles cannot reproduce).  No Sk limit.
+// The one-pass kernel (oeh_attn_flash.inl) additionally needs the plain softmax_n (no clip).  No Sk limit.
 bool flash_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq, bool short_rows_too = false) {
   if (!fast_eligible(d, fq) || d->clip || any_fq(fq)) return false;
-  if (d->key_pad_mask != nullptr && d->softmax_base != OEH_SOFTMAX_ONE) return false;
+  // (key padding under the vanilla softmax: a row without a visible key is uniform over ALL keys in the reference - the PAD variant's
+  // epilogue gives such rows the mean of V, oeh_attn_flash.inl)
   if (short_rows_too) return true;
   // short rows (<= 128 keys) fit the full-row kernel's registers in one pass, which measures faster there
   // (BERT-base S=128: 10.0 vs 11.7 us per launch)

@@ -806,6 +806,43 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     if (P.base != 0) den = den + __builtin_amdgcn_exp2f(mcneg[j]);  // softmax_1: + 1*exp(-reference)  (vutils/softmax_1.py:18-20)
     float rowscale = 1.0f / den;
     if constexpr (TP != 0) rowscale = 1.0f;  // the clipped probabilities / the probability indices went into the product as they are
+    if constexpr (PAD && TP == 0) {
+      // Vanilla softmax and a row WITHOUT a visible key (a fully padded sample; a left-padded one under the causal mask): every score
+      // of the reference is the same finfo.min, its probabilities are uniform over ALL Sk keys - which a kernel that skips masked
+      // tiles has not accumulated (l == 0 here).  Such rows - rare - take the mean of V straight from memory.
+      if (P.base == 0) {
+        const bool dead = den == 0.0f;
+        if (__builtin_amdgcn_ballot_w64(dead) != 0) {
+          if (dead) {
+            f4 acc[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[dt] = f4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (SRC32) {
+              const float* vp = reinterpret_cast<const float*>(P.v) + bh_offset(b, P.vs_b, h, P.vs_h) + 4 * ge;
+              for (int kk = 0; kk < Sk; ++kk)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) acc[dt] = acc[dt] + *reinterpret_cast<const f4*>(vp + (long)kk * P.vs_s + 16 * dt);
+            } else {
+              const unsigned short* vp = reinterpret_cast<const unsigned short*>(P.v) + bh_offset(b, P.vs_b, h, P.vs_h) + 4 * ge;
+              for (int kk = 0; kk < Sk; ++kk)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                  const u2 w = *reinterpret_cast<const u2*>(vp + (long)kk * P.vs_s + 16 * dt);
+                  acc[dt] = acc[dt] + f4{In<IN>::to_f32((unsigned short)(w.x & 0xffffu)), In<IN>::to_f32((unsigned short)(w.x >> 16)),
+                                         In<IN>::to_f32((unsigned short)(w.y & 0xffffu)), In<IN>::to_f32((unsigned short)(w.y >> 16))};
+                }
+            }
+            const float rs = 1.0f / (float)Sk;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              o[j][dt] = acc[dt] * rs;
+              if constexpr (SRC32) ox[j][dt] = f4{0.f, 0.f, 0.f, 0.f};
+            }
+            rowscale = 1.0f;
+          }
+        }
+      }
+    }
     if (P.gate != nullptr && qrow < Sq) rowscale = rowscale * P.gate[(long)b * P.gs_b + (long)h * P.gs_h + (long)qrow * P.gs_s];
     if constexpr (GATE) rowscale = rowscale * gate_row[j];
     // TP = 2: [scale of the quantised P] [context quantiser] gate [context quantiser] - the full-row kernel's epilogue chain,

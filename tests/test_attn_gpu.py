@@ -1571,3 +1571,30 @@ def test_long_rows_with_key_padding_two_pass(ops, order, kind, dt):
     err = np.abs(_np32(got) - want)
     off = float((err > 0.5 * step).mean())
     assert np.isfinite(_np32(got)).all() and off < 4e-3 and err.max() <= 2.05 * step + 2e-3, f"{off:.2e} off, max {err.max() / step:.2f} steps"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S", [320, 704])
+@pytest.mark.parametrize("dt", [torch.float16, torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("causal", [False, True])
+def test_vanilla_softmax_with_key_padding_on_the_one_pass_kernel(ops, S, dt, causal):
+    """Key padding under the VANILLA softmax on the one-pass kernel (round 3; before: full-row kernel up to 512 keys, any-shape kernel
+    beyond): a row without a visible key - a fully padded sample, the first rows of a left-padded one under the causal mask - is
+    uniform over ALL keys in the reference (models/softmax.py: every score is the same finfo.min), i.e. the mean of V: the PAD
+    variant's epilogue forms it for such rows."""
+    B, H, D = 4, 2, 64
+    fmin = float(np.finfo(np.float32).min)
+    q, k, v = _rand((B, H, S, D), 6101, dtype=dt), _rand((B, H, S, D), 6102, dtype=dt), _rand((B, H, S, D), 6103, dtype=dt)
+    padm = _pad_mask(B, S, [S - 90, S, 0, S], fmin)
+    padm[1, :70] = fmin    # left-padded
+    padm[3, 5:] = fmin     # five visible keys
+    gate = np.random.default_rng(4).random((B, H, S, 1), dtype=np.float32)
+    name = ops.attn_variant(B, H, S, S, D, dt, base=0, key_pad=True, causal=causal, scale=0.125, mask_min=fmin)
+    assert name.startswith("flash16/"), name
+    want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=0.125, base=0, causal=causal, clamp_min=True, pad_mask=padm, mask_min=fmin, gate=gate)
+    got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=ops.SoftmaxSpec(0), scale=0.125, causal=causal, clamp_min=True, mask_min=fmin,
+                       key_pad_mask=torch.from_numpy(padm).cuda(), gate=torch.from_numpy(gate).cuda())
+    tol = F16_TOL if dt == torch.float16 else (dict(atol=5e-4, rtol=5e-4) if dt == torch.float32 else BF16_TOL)
+    _check(got, want, tol=tol, msg=f"vanilla + pad S={S} causal={causal}")
+    mean_v = _np32(v)[2].mean(axis=1, keepdims=True) * gate[2]
+    assert np.abs(_np32(got)[2] - mean_v).max() < (2e-2 if dt == torch.bfloat16 else 2e-3)   # the sample without a visible key: the mean of V

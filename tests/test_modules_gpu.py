@@ -476,7 +476,7 @@ def test_opt_consecutive_batches_with_different_padding(oa, quantised):
 
 def test_fused_gate_falls_back_when_the_library_refuses(oa, monkeypatch):
     """`except _lib.OehError` named a module attention.py never imported - the OEH_ENOTSUP fallback to
-    oeh_gate_fwd raised NameError.  Force the refusal (vanilla softmax + key padding + 640 keys runs the any-shape kernel,
+    oeh_gate_fwd raised NameError.  Force the refusal (clipped vanilla softmax + key padding + 640 keys runs the any-shape kernel,
     which has no in-kernel predictor) with the probe patched to say yes."""
     from outeffhop_amd import attention as A, ops
 
@@ -488,7 +488,7 @@ def test_fused_gate_falls_back_when_the_library_refuses(oa, monkeypatch):
     w1, b1 = torch.randn(H, D, device=dev) * 0.05, torch.randn(H, device=dev)
     pad = torch.zeros(B, 1, 1, S, device=dev)
     pad[1, ..., 500:] = torch.finfo(torch.float32).min
-    sm = oa.SOFTMAX_MAPPING["vanilla"]
+    sm = oa.SOFTMAX_MAPPING["clipped(-.003:1.003)"]
     gp = ops.GatePredictor(hidden, w1, b1, scaling=2.0, out=torch.empty(B, H, S, device=dev))
     with pytest.raises(oa._lib.OehError) as ei:  # the library does refuse this combination ...
         ops.attn_fwd(q, k, v, softmax=sm.spec, scale_div=8.0, key_pad_mask=pad, gate_mlp=gp)
