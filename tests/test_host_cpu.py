@@ -240,8 +240,10 @@ def test_attn_variant_describes_the_real_problem():
     assert ops.attn_variant(16, 12, 512, 512, 64, f16, causal=True) == "flash16/MQ2/D64/f16"
     assert ops.attn_variant(2, 12, 512, 512, 64, f16, causal=True) == "flash16/MQ1/D64/f16"
     assert ops.attn_variant(8, 16, 512, 512, 128, torch.float32, causal=True) == "flash16/MQ1/D128/f32"
-    # vanilla softmax + key padding + long rows: neither 16-bit fast kernel takes it
-    assert not ops.fused_gate_ok(2, 4, 640, 640, 64, f16, base=0, key_pad=True)
+    # vanilla softmax + key padding + long rows: the one-pass kernel takes it since round 3; clipped on top of that, neither fast kernel
+    assert ops.fused_gate_ok(2, 4, 640, 640, 64, f16, base=0, key_pad=True)
+    assert ops.attn_variant(2, 4, 640, 640, 64, f16, base=0, key_pad=True) == "flash16/MQ1/D64/f16"
+    assert not ops.fused_gate_ok(2, 4, 640, 640, 64, f16, base=0, clip=True, key_pad=True)
     assert ops.fused_gate_ok(2, 4, 640, 640, 64, f16, base=1, key_pad=True)
     assert not ops.fused_gate_ok(2, 4, 64, 64, 64, f16, clip=True, gamma=0.01)   # gamma > 0: general kernel
     assert not ops.fused_gate_ok(2, 4, 96, 64, 64, f16, causal=True)            # Sq > Sk causal: general kernel
