@@ -573,10 +573,8 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
         for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float pv = __builtin_amdgcn_exp2f(s[j][sub][r]) * pinv[j];
-            pv = pv * P.clip_w;
-            pv = pv + P.clip_g;
-            s[j][sub][r] = __builtin_amdgcn_fmed3f(pv, 0.0f, 1.0f);
+            // (one fused multiply-add with the instruction's clamp bit, as in the full-row kernel: e * (w / den) + gamma)
+            s[j][sub][r] = __builtin_amdgcn_fmed3f(__builtin_fmaf(__builtin_amdgcn_exp2f(s[j][sub][r]), pinv[j] * P.clip_w, P.clip_g), 0.0f, 1.0f);
           }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
