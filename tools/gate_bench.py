@@ -5,7 +5,8 @@ from outeffhop_amd import _lib
 lib = _lib.load()
 H, d, S = 12, 64, 128
 for B in (8, 32, 128, 512):
-    hid = [torch.randn(B, S, H*d, device="cuda").half() for _ in range(8)]
+    DT = int(os.environ.get("GATE_DT", "0"))
+    hid = [torch.randn(B, S, H*d, device="cuda").half() if DT == 0 else torch.randn(B, S, H*d, device="cuda") for _ in range(8)]
     for m in (16, 0, 64):
         mm = max(m, 1)
         w1 = torch.randn(H, mm, d, device="cuda") * 0.02; b1 = torch.zeros(H, mm, device="cuda")
@@ -15,7 +16,7 @@ for B in (8, 32, 128, 512):
         vp = C.c_void_p
         def call(i):
             hd = hid[i % 8]
-            rc = lib.oeh_gate_fwd(vp(hd.data_ptr()), 0, B, S, H, d, hd.stride(0), hd.stride(1), vp(w1.data_ptr()), vp(b1.data_ptr()), vp(w2.data_ptr()) if m else None, vp(b2.data_ptr()) if m else None, m, 0, 1.0, vp(out.data_ptr()), st)
+            rc = lib.oeh_gate_fwd(vp(hd.data_ptr()), 2 if DT else 0, B, S, H, d, hd.stride(0), hd.stride(1), vp(w1.data_ptr()), vp(b1.data_ptr()), vp(w2.data_ptr()) if m else None, vp(b2.data_ptr()) if m else None, m, 0, 1.0, vp(out.data_ptr()), st)
             assert rc == 0, rc
         for i in range(20): call(i)
         torch.cuda.synchronize()
