@@ -52,7 +52,8 @@ constexpr int fast_occupancy() {  // what the LDS rings allow (6 tiles of 64 x 2
 // epilogue.  A separate variant: the others carry none of it.
 // FQ: the fused fake-quantisers (scores / probabilities / context); two forms, separate variants because a kernel that holds
 // both allocates registers for the union (143 spilled).  FQ == 1: no key padding, no clipping (OPT) - the chain runs on the
-// quantiser grid (see phase 2).  FQ == 2: the per-element chain is the reference's op
+// quantiser grid (see phase 2); FQ == 3: the same with a key-padding vector whose entries are 0 or <= -1e4 (include/oeh.h
+// key_pad_boolean: BERT's and HF's masks) - a flag per key in LDS, one v_min per element.  FQ == 2: the per-element chain is the reference's op
 // order literally - scale, quantise, masks added (not substituted), x - m, 1-ulp exp, normalise, [clip], quantise - as in
 // the general kernel (oeh_attn_mfma.inl), on this kernel's data path.  The variant is compiled for the reference's
 // configuration, scores AND probabilities quantised (context optional): a run-time test per quantiser and per four elements
