@@ -149,6 +149,11 @@ int g_force_flash = 0;                   // tools/microbench.py only
 
 // The one-pass kernel (oeh_attn_flash.inl) additionally needs the plain softmax_n (no clip).  No Sk limit.
 bool flash_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq, bool short_rows_too = false) {
+  if (d->full_mask != nullptr) {  // a (B,1,Sq,Sk) mask: only where the general kernel does not reach (rows of more than 512 keys); PAD variant
+    oeh_attn_desc t = *d;
+    t.full_mask = nullptr;
+    return d->Sk > 512 && !d->clip && !any_fq(fq) && fast_eligible(&t, fq) && (d->mask_min < -1.0e4f);
+  }
   if (!fast_eligible(d, fq) || d->clip || any_fq(fq)) return false;
   // (key padding under the vanilla softmax: a row without a visible key is uniform over ALL keys in the reference - the PAD variant's
   // epilogue gives such rows the mean of V, oeh_attn_flash.inl)

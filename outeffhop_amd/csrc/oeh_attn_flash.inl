@@ -328,8 +328,8 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   const bool pad_in_lds = PAD && Sk <= PADROW;
   if constexpr (PAD) {
     int last = -1;  // last key that is not masked
-    for (int key = tid; key < ((Sk + 63) & ~63); key += 256) {
-      const float pv = key < Sk ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + key) : 0.0f;
+    for (int key = tid; key < ((Sk + 63) & ~63); key += 256) {  // (no padding vector: the variant serves a (B,1,Sq,Sk) mask alone - zeros)
+      const float pv = (key < Sk && P.pad != nullptr) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + key) : 0.0f;
       if (key < PADROW) lds_padrow[key] = pv;
       if (key < Sk && pv > -1.0e30f) last = key;
     }
@@ -477,16 +477,30 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
           padv = *reinterpret_cast<const f4*>(&lds_padrow[kb]);
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) padv[r] = (kb + r < Sk) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + kb + r) : 0.0f;
+          for (int r = 0; r < 4; ++r) padv[r] = (kb + r < Sk && P.pad != nullptr) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + kb + r) : 0.0f;
         }
         if constexpr (MODE >= 3) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) padflag[sub][r] = padv[r] < -1.0e4f ? NEGT : 3.0e38f;
         } else {
 #pragma unroll
-          for (int j = J0; j < MQ; ++j)
+          for (int j = J0; j < MQ; ++j) {
+            if (P.full != nullptr) {
+              // a (B,1,Sq,Sk) additive mask on rows of more than 512 keys (the general kernel takes the shorter ones): read per
+              // block from memory - compiler-visible loads inside the LDS-DMA stream, i.e. its waits drain the ring; slow next to
+              // the other variants, two orders of magnitude faster than the any-shape kernel this combination used to reach
+              const long mrow = (long)b * P.full_sb + (long)min(rb[j] + c, Sq - 1) * P.full_sq;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[j][sub][r] = __builtin_fmaxf(__builtin_fmaf(s[j][sub][r], sc, padv[r]), NEG);
+              for (int r = 0; r < 4; ++r) {
+                float x = __builtin_fmaf(s[j][sub][r], sc, padv[r]);
+                if (kb + r < Sk) x = x + load_mask(P.full, P.full_f16, mrow + kb + r);
+                s[j][sub][r] = __builtin_fmaxf(x, NEG);
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) s[j][sub][r] = __builtin_fmaxf(__builtin_fmaf(s[j][sub][r], sc, padv[r]), NEG);
+            }
+          }
         }
       }
     }
@@ -910,7 +924,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
 
 template <int D, int MQ, int IN>
 static void launch_flash_d_mq_in(const AttnParams& P, unsigned grid, hipStream_t st) {
-  const bool pad = P.pad != nullptr, gate = P.gh != nullptr;
+  const bool pad = P.pad != nullptr || P.full != nullptr, gate = P.gh != nullptr;  // (the PAD variants also serve a (B,1,Sq,Sk) mask)
   if (P.src32) {  // fp32 storage read directly, fp32 output; no in-kernel gate predictor on this path
     if constexpr (IN == IN_F16 && !(D == 128 && MQ == 2)) {  // (d = 128 with two blocks per wave: never selected, oeh_api.hip: flash_mq)
       if (P.fq_s.en && pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, true, 2>), dim3(grid), dim3(256), 0, st, P);
