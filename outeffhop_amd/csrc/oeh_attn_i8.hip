@@ -35,6 +35,9 @@
 //     clamp on the same side) - differences of such values are the exact integer differences the exponent needs;
 //   * row maximum as v_max3 chains; the causal / tail test of a diagonal tile is one compare + select per element against a
 //     per-lane key limit, and only there.
+// Measured and dropped (round 3): q tiles in PAIRS per workgroup (nQT-1-j, then j: every workgroup the same nQT + 1 key tiles, half as
+// many workgroups, one dispatch round, the second tile's K / V^T L2 hits) - 17.8 against 17.1-17.4 us at S = 256, 14.3-14.6 against
+// 13.8-14.0 at S = 128: the dynamic two-round dispatch, heaviest first, already balances, and the pair serialises two prologues.
 // DUMP variant (tests): the three index tensors are written out as uint8 (include/oeh.h: oeh_fq.dump_idx), scores for every
 // key (the reference quantises before the mask is added).
 #include "oeh_attn_fast.inl"
@@ -150,8 +153,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   int asum = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) asum = __builtin_amdgcn_sdot4(qf[j], ones, asum, false);
-  asum += __shfl_xor(asum, 16);
-  asum += __shfl_xor(asum, 32);
+  asum = row4_sum(asum);
   if constexpr (PAD) {  // (compiler-visible loads: its wait for them also covers the first transfers, which the first tile wait needs anyway)
     for (int i = threadIdx.x; i < NT * 16; i += 256) {
       float f = -__builtin_inff();
@@ -259,8 +261,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
       }
     }
   }
-  mr = __builtin_fmaxf(mr, __shfl_xor(mr, 16));
-  mr = __builtin_fmaxf(mr, __shfl_xor(mr, 32));
+  mr = row4_max(mr);
   const float m = (mr - MAGIC) * P.fq_s.scale;               // the reference's row maximum, fl(scale * rel_max)
   const float c2 = P.fq_s.c2;
   f4 sum4 = f4{0.f, 0.f, 0.f, 0.f};
@@ -278,8 +279,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
     }
   }
   float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
-  sum += __shfl_xor(sum, 16);
-  sum += __shfl_xor(sum, 32);
+  sum = row4_sum(sum);
   float den = sum;
   if (P.base != 0) den = sum + exp_acc(m * -1.0f);
   const float cinv = (1.0f / den) * P.fq_p.rscale, pzp = P.fq_p.zp;
@@ -304,8 +304,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
       }
     }
   }
-  psum += __shfl_xor(psum, 16);
-  psum += __shfl_xor(psum, 32);
+  psum = row4_sum(psum);
 
   // =========================== phase 3: O^T = V^T P^T (i32) and the key sums of V^T ===========================
   // sum_k (v + cv)(p + cp) = o + cp vsum + cv psum + n cv cp: the query's constant cv psum + n cv cp is what the accumulators start at

@@ -350,6 +350,27 @@ __device__ __forceinline__ unsigned lds_offset(const void* p) {
   return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p;
 }
 
+// all-reduce over the 4 lanes (c, c+16, c+32, c+48) that hold one query row: v_permlane16_swap + v_permlane32_swap (VALU, no LDS
+// crossbar round trip, no lane-index registers as ds_bpermute needs)
+__device__ __forceinline__ float row4_sum(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(f32_bits(x), f32_bits(x), false, false);
+  x = bits_f32(a[0]) + bits_f32(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(f32_bits(x), f32_bits(x), false, false);
+  return bits_f32(b[0]) + bits_f32(b[1]);
+}
+__device__ __forceinline__ int row4_sum(int x) {
+  auto a = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+  x = (int)a[0] + (int)a[1];
+  auto b = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+  return (int)b[0] + (int)b[1];
+}
+__device__ __forceinline__ float row4_max(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(f32_bits(x), f32_bits(x), false, false);
+  x = __builtin_fmaxf(bits_f32(a[0]), bits_f32(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(f32_bits(x), f32_bits(x), false, false);
+  return __builtin_fmaxf(bits_f32(b[0]), bits_f32(b[1]));
+}
+
 __device__ __forceinline__ float load_mask(const void* base, int is_f16, long off) {
   return is_f16 ? (float)reinterpret_cast<const _Float16*>(base)[off] : reinterpret_cast<const float*>(base)[off];
 }
