@@ -479,8 +479,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
           }
         }
       }
-      mr = __builtin_fmaxf(mr, __shfl_xor(mr, 16));
-      mr = __builtin_fmaxf(mr, __shfl_xor(mr, 32));
+      mr = row4_max(mr);
       m = (mr - MAGIC) * P.fq_s.scale;                                        // the reference's row maximum, fl(scale * rel_max)
       const float c2 = P.fq_s.c2;
       f4 sum4 = f4{0.f, 0.f, 0.f, 0.f};
@@ -502,8 +501,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
         }
       }
       float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
-      sum += __shfl_xor(sum, 16);
-      sum += __shfl_xor(sum, 32);
+      sum = row4_sum(sum);
       float den = sum;
       if (P.base != 0) den = sum + exp_acc(m * -1.0f);                       // softmax_1: + 1*exp(-max)  (softmax_1.py:18-20)
       inv_fq = 1.0f / den;
@@ -573,8 +571,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
         }
       }
     }
-    m = __builtin_fmaxf(m, __shfl_xor(m, 16));
-    m = __builtin_fmaxf(m, __shfl_xor(m, 32));
+    m = row4_max(m);
     float sum = 0.0f;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
@@ -592,8 +589,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
         }
       }
     }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
+    sum = row4_sum(sum);
     float den = sum;
     if (P.base != 0) den = sum + exp_acc(m * -1.0f);  // softmax_1: + 1*exp(-max)  (softmax_1.py:18-20)
     inv_fq = 1.0f / den;
@@ -662,8 +658,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
       }
     }
   }
-  m = __builtin_fmaxf(m, __shfl_xor(m, 16));
-  m = __builtin_fmaxf(m, __shfl_xor(m, 32));
+  m = row4_max(m);
 
   OEH_STAMP(11);
   // in pad mode the registers hold scaled+masked scores, otherwise raw dot products
@@ -707,8 +702,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
       }
     }
   }
-  sum += __shfl_xor(sum, 16);
-  sum += __shfl_xor(sum, 32);
+  sum = row4_sum(sum);
   float den = sum;
   if (P.base != 0) den = sum + exp_acc(m_true * -1.0f);
   inv = 1.0f / den;

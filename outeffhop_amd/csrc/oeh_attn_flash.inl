@@ -698,19 +698,16 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     for (int j = 0; j < MQ; ++j) {
       if constexpr (FQ2) {
         float mr = mrl[j];
-        mr = __builtin_fmaxf(mr, __shfl_xor(mr, 16));
-        mr = __builtin_fmaxf(mr, __shfl_xor(mr, 32));
+        mr = row4_max(mr);
         float l = lsum[j] * __builtin_amdgcn_exp2f((mrl[j] - mr) * fq_c2);
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        l = row4_sum(l);
         const float m = (mr - kGridMagic) * P.fq_s.scale;            // the reference's row maximum, fl(scale * rel_max)
         if (P.base != 0) l = l + exp_acc(m * -1.0f);                  // softmax_1: + 1*exp(-max)  (softmax_1.py:18-20)
         mrl[j] = mr;
         pinv[j] = (1.0f / l) * P.fq_p.rscale;                        // e * this -> the probability's index (before rint)
       } else {
         float l = lsum[j];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        l = row4_sum(l);
         if (P.base != 0) l = l + __builtin_amdgcn_exp2f(mcneg[j]);    // softmax_1: + 1*exp(-reference)
         pinv[j] = 1.0f / l;
       }

@@ -255,8 +255,7 @@ __global__ __launch_bounds__(256, (occupancy_hint<NT, D, IN>())) void oeh_attn_m
         mr = __builtin_fmaxf(__builtin_fmaxf(mr, __builtin_fmaxf(rel[0], rel[1])), __builtin_fmaxf(rel[2], rel[3]));
       }
     }
-    mr = __builtin_fmaxf(mr, __shfl_xor(mr, 16));
-    mr = __builtin_fmaxf(mr, __shfl_xor(mr, 32));
+    mr = row4_max(mr);
     m = mr * P.fq_s.scale;
     const float c2 = P.fq_s.c2;
     f4 sum4 = f4{0.f, 0.f, 0.f, 0.f};
@@ -274,8 +273,7 @@ __global__ __launch_bounds__(256, (occupancy_hint<NT, D, IN>())) void oeh_attn_m
       }
     }
     float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
+    sum = row4_sum(sum);
     float den = sum;
     if (P.base != 0) den = sum + exp_acc(m * -1.0f);
     const float cinv = (1.0f / den) * P.fq_p.rscale, plo = P.fq_p.lo, phi = P.fq_p.hi;
@@ -346,8 +344,7 @@ __global__ __launch_bounds__(256, (occupancy_hint<NT, D, IN>())) void oeh_attn_m
       m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(x[0], x[1])), __builtin_fmaxf(x[2], x[3]));
     }
   }
-  m = __builtin_fmaxf(m, __shfl_xor(m, 16));
-  m = __builtin_fmaxf(m, __shfl_xor(m, 32));
+  m = row4_max(m);
 
   float sum = 0.0f;
 #pragma unroll
@@ -371,8 +368,7 @@ __global__ __launch_bounds__(256, (occupancy_hint<NT, D, IN>())) void oeh_attn_m
       }
     }
   }
-  sum += __shfl_xor(sum, 16);
-  sum += __shfl_xor(sum, 32);
+  sum = row4_sum(sum);
   float den = sum;
   if (P.base != 0) den = sum + exp_acc(m * -1.0f);  // softmax_1: + 1*exp(-max)  (softmax_1.py:18-20)
   const float inv = 1.0f / den;
