@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   // The K and the V^T phases have eight MFMAs per wave and tile between two barriers: they run at the pace the tiles ARRIVE.
   // Tiles are 4 KB here, so the rings are deep - R slots, PF tiles requested ahead (PF <= R - 1: a slot is refilled only
   // after the barrier that follows its last readers).
-  constexpr int R = 6, PF = 4;
+  constexpr int R = 6, PF = (NT == 8) ? 2 : 4;
   constexpr float RELMASK = -1.0e30f;
   constexpr bool OUT32 = (OUT == IN_F32);
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * R * TILEB];
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
-  static_assert(PF == 4 && PF <= R - 1, "wait_tile's immediates");
+  static_assert(PF <= 4 && PF <= R - 1, "wait_tile's immediates");
 
   // ---- Q: global -> registers in the B-operand layout (query q0 + c, head dims 16 g ..), and its row sum
   i4 qf;
