@@ -52,9 +52,11 @@ template <int NT, int OUT, bool DUMP, bool CQ2, bool PAD>
 __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P) {
   constexpr int D = 64, KT = NT / 4, TILEB = 64 * 64, DT = 4;
   // The K and the V^T phases have eight MFMAs per wave and tile between two barriers: they run at the pace the tiles ARRIVE.
-  // Tiles are 4 KB here, so the rings are deep - R slots, PF tiles requested ahead (PF <= R - 1: a slot is refilled only
-  // after the barrier that follows its last readers).
-  constexpr int R = 6, PF = (NT == 8) ? 2 : 4;
+  // R slots per ring, PF tiles requested ahead (PF <= R - 1: a slot is refilled only after the barrier that follows its last
+  // readers).  PF = 2 (round 3; 4 before): a launch is one burst of every workgroup's requests against HBM, and tiles requested
+  // far ahead only delay the tiles every workgroup needs first - same-process: S = 128 0.94, S = 256 0.97, S = 512 0.99 against
+  // PF = 4; PF = 3 in between; PF = 1 exposes the latency (S = 512 +8 %).
+  constexpr int R = 6, PF = 2;
   constexpr float RELMASK = -1.0e30f;
   constexpr bool OUT32 = (OUT == IN_F32);
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * R * TILEB];
