@@ -103,8 +103,7 @@ __global__ __launch_bounds__(256, 2) void oeh_attn_small_kernel(const AttnParams
       s[t] = acc;
       m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(acc[0], acc[1])), __builtin_fmaxf(acc[2], acc[3]));
     }
-    m = __builtin_fmaxf(m, __shfl_xor(m, 16));
-    m = __builtin_fmaxf(m, __shfl_xor(m, 32));
+    m = row4_max(m);
     float sum = 0.0f;
 #pragma unroll
     for (int t = 0; t < ST; ++t)
@@ -114,8 +113,7 @@ __global__ __launch_bounds__(256, 2) void oeh_attn_small_kernel(const AttnParams
         s[t][r] = e;
         sum += e;
       }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
+    sum = row4_sum(sum);
     float den = sum;
     if (P.base != 0) den = sum + exp_acc(m * -1.0f);  // softmax_1: + 1*exp(-max)  (softmax_1.py:18-20)
 #pragma unroll
