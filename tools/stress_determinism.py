@@ -48,4 +48,12 @@ case("two-pass clip S=640 fp32", 8,12,640,64, lambda pad: dict(causal=True, clam
 case("two-pass INT8 causal S=1024", 8,12,1024,64, lambda pad: dict(causal=True, clamp_min=True, fq=int8))
 case("two-pass INT8 S=640 fp32", 8,12,640,64, lambda pad: dict(causal=True, clamp_min=True, fq=int8), torch.float32)
 case("small-shape 28x28", 224,4,28,64, lambda pad: dict(scale=0.125), torch.float32)
+# round 3: the grid chain with a key-padding vector (full-row FQ == 3), the PAD forms of the two-pass kernels, vanilla + padding on the
+# one-pass kernel, a (B,1,S,S) mask on long rows
+case("INT8 grid + pad S=128 (BERT)", 32,12,128,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad, key_pad_boolean=True, fq=int8))
+case("INT8 grid causal + pad S=512", 16,12,512,64, lambda pad: dict(causal=True, clamp_min=True, key_pad_mask=pad, key_pad_boolean=True, fq=int8))
+case("two-pass INT8 + pad S=704", 8,12,704,64, lambda pad: dict(causal=True, clamp_min=True, key_pad_mask=pad, key_pad_boolean=True, fq=int8))
+case("two-pass clip + pad S=704", 8,12,704,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad, softmax=clipsm))
+case("one-pass vanilla + pad S=640", 8,12,640,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad, softmax=ops.SoftmaxSpec(0)))
+case("one-pass full mask S=640", 4,12,640,64, lambda pad: dict(scale_div=8.0, clamp_min=True, full_mask=(pad[:, None, None, :] + torch.zeros(pad.shape[0], 1, 640, 640, device="cuda")).contiguous()))
 sys.exit(1 if tot else 0)
