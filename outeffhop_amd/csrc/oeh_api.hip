@@ -180,7 +180,7 @@ bool flash_clip_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
 bool flash_fq_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
   oeh_attn_desc t = *d;
   if (t.dtype == OEH_F32) t.dtype = OEH_F16;  // fp32 storage: the SRC32 form
-  if (!any_fq(fq) || d->clip || !fast_eligible(&t, fq)) return false;  // (fast_eligible: both quantisers, no dumps, scale, masks)
+  if (!any_fq(fq) || !fast_eligible(&t, fq)) return false;  // (fast_eligible: both quantisers, no dumps, scale, masks, gamma <= 0 when clipped)
   if (d->gate == nullptr && d->gate_hidden != nullptr) return false;
   // key padding: on the grid only as a vector of 0 / <= -1e4 entries (key_pad_boolean), and with softmax_1 (trailing padded tiles are not streamed)
   if (d->key_pad_mask != nullptr && !(d->key_pad_boolean && d->softmax_base == OEH_SOFTMAX_ONE)) return false;

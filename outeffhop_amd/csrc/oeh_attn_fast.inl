@@ -71,7 +71,6 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
   static_assert(!SRC32 || IN == IN_F16, "fp32 storage: fp16 operand pairs, fp32 output");
   constexpr bool OUT32 = SRC32;
   static_assert(!FQ || !GATE, "the fake-quant variant has no in-kernel gate predictor");
-  static_assert(!(FQ == 1 || FQ == 3) || !CLIP, "FQ == 1 / 3 (the chain on the quantiser grid) is the unclipped form");
   constexpr bool GRID = (FQ == 1 || FQ == 3), GRIDPAD = (FQ == 3);  // FQ == 3: the grid chain with a key-padding vector of 0 / <= -1e4 entries
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
   constexpr int KT = NT / 4;
@@ -509,6 +508,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
       if (P.base != 0) den = sum + exp_acc(m * -1.0f);                       // softmax_1: + 1*exp(-max)  (softmax_1.py:18-20)
       inv_fq = 1.0f / den;
       const float cinv = inv_fq * P.fq_p.rscale, plo = P.fq_p.lo, phi = P.fq_p.hi;
+      const float clip_iw = inv_fq * P.clip_w, clip_g = P.clip_g;  // (CLIP)
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         if (kt < n_kt) {
@@ -517,7 +517,14 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
             const int t = kt * 4 + sub;
             float pv[4];  // integer valued (idx - zp): exact in f16/bf16; the scale is applied after the product
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_fmed3f(__builtin_rintf(s[t][r] * cinv), plo, phi);
+            for (int r = 0; r < 4; ++r) {
+              if constexpr (CLIP) {  // clip(p (eta - gamma) + gamma, 0, 1) as one clamped fma (a masked key: e = 0, gamma <= 0 -> 0), then the index
+                const float pc = __builtin_amdgcn_fmed3f(__builtin_fmaf(s[t][r], clip_iw, clip_g), 0.0f, 1.0f);
+                pv[r] = __builtin_amdgcn_fmed3f(__builtin_rintf(pc * P.fq_p.rscale), plo, phi);
+              } else {
+                pv[r] = __builtin_amdgcn_fmed3f(__builtin_rintf(s[t][r] * cinv), plo, phi);
+              }
+            }
             const unsigned lo = (IN == IN_BF16) ? pack2_bf16(pv[0], pv[1]) : pack2_f16(pv[0], pv[1]);
             const unsigned hi = (IN == IN_BF16) ? pack2_bf16(pv[2], pv[3]) : pack2_f16(pv[2], pv[3]);
             s[t][0] = bits_f32(lo);
@@ -862,11 +869,13 @@ template <int NT, int D, int IN>
 static void launch_fast_nt_d_in(const AttnParams& P, unsigned grid, hipStream_t st) {
   const bool gate = P.gh != nullptr;
   const bool fqon = P.fq_s.en && P.fq_p.en;
-  const bool grid_chain = fqon && !P.clip && (P.pad == nullptr || P.pad_bool);  // FQ == 1, or 3 with a key-padding vector (include/oeh.h: key_pad_boolean)
+  const bool grid_chain = fqon && (P.pad == nullptr || P.pad_bool);  // FQ == 1, or 3 with a key-padding vector (include/oeh.h: key_pad_boolean)
   const bool grid_pad = grid_chain && P.pad != nullptr;
   if (P.src32) {  // fp32 storage read directly, fp32 output
     if constexpr (IN == IN_F16) {
-      if (grid_pad) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 3, true>), dim3(grid), dim3(256), 0, st, P);
+      if (grid_pad && P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 3, true>), dim3(grid), dim3(256), 0, st, P);
+      else if (grid_pad) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 3, true>), dim3(grid), dim3(256), 0, st, P);
+      else if (grid_chain && P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 1, true>), dim3(grid), dim3(256), 0, st, P);
       else if (grid_chain) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 1, true>), dim3(grid), dim3(256), 0, st, P);
       else if (fqon && P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 2, true>), dim3(grid), dim3(256), 0, st, P);
       else if (fqon) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 2, true>), dim3(grid), dim3(256), 0, st, P);
@@ -878,7 +887,9 @@ static void launch_fast_nt_d_in(const AttnParams& P, unsigned grid, hipStream_t 
     return;
   }
   if (fqon) {
-    if (grid_pad) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 3>), dim3(grid), dim3(256), 0, st, P);
+    if (grid_pad && P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 3>), dim3(grid), dim3(256), 0, st, P);
+    else if (grid_pad) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 3>), dim3(grid), dim3(256), 0, st, P);
+    else if (grid_chain && P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 1>), dim3(grid), dim3(256), 0, st, P);
     else if (grid_chain) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 1>), dim3(grid), dim3(256), 0, st, P);
     else if (P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 2>), dim3(grid), dim3(256), 0, st, P);
     else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 2>), dim3(grid), dim3(256), 0, st, P);

@@ -567,6 +567,16 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       }
       if constexpr (MODE == 4) {  // final pass of the grid chain: exponential against the row maximum, index of the probability
         const float plo = P.fq_p.lo, phi = P.fq_p.hi;
+        if (P.clip) {  // the clipped grid form of the full-row kernel: clip(p (eta - gamma) + gamma, 0, 1) as one clamped fma, then the index
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float e = __builtin_amdgcn_exp2f((s[j][sub][r] - mrl[j]) * fq_c2);
+              const float pc = __builtin_amdgcn_fmed3f(__builtin_fmaf(e, pinv[j], P.clip_g), 0.0f, 1.0f);
+              s[j][sub][r] = __builtin_amdgcn_fmed3f(__builtin_rintf(pc * P.fq_p.rscale), plo, phi);
+            }
+        } else {
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
@@ -574,6 +584,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
             const float e = __builtin_amdgcn_exp2f((s[j][sub][r] - mrl[j]) * fq_c2);
             s[j][sub][r] = __builtin_amdgcn_fmed3f(__builtin_rintf(e * pinv[j]), plo, phi);
           }
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const f4 a = s[j][2 * u], bb = s[j][2 * u + 1];
@@ -704,7 +715,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
         const float m = (mr - kGridMagic) * P.fq_s.scale;            // the reference's row maximum, fl(scale * rel_max)
         if (P.base != 0) l = l + exp_acc(m * -1.0f);                  // softmax_1: + 1*exp(-max)  (softmax_1.py:18-20)
         mrl[j] = mr;
-        pinv[j] = (1.0f / l) * P.fq_p.rscale;                        // e * this -> the probability's index (before rint)
+        pinv[j] = (1.0f / l) * (P.clip ? P.clip_w : P.fq_p.rscale);  // e * this -> the probability's index (before rint); clipped: -> p (eta - gamma)
       } else {
         float l = lsum[j];
         l = row4_sum(l);

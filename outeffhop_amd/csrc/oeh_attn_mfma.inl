@@ -276,7 +276,9 @@ __global__ __launch_bounds__(256, (occupancy_hint<NT, D, IN>())) void oeh_attn_m
     sum = row4_sum(sum);
     float den = sum;
     if (P.base != 0) den = sum + exp_acc(m * -1.0f);
-    const float cinv = (1.0f / den) * P.fq_p.rscale, plo = P.fq_p.lo, phi = P.fq_p.hi;
+    const float inv_g = 1.0f / den;
+    const float cinv = inv_g * P.fq_p.rscale, plo = P.fq_p.lo, phi = P.fq_p.hi;
+    const float clip_iw = inv_g * P.clip_w, clip_g = P.clip_g;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       ph[t] = u2{0u, 0u};
@@ -284,7 +286,14 @@ __global__ __launch_bounds__(256, (occupancy_hint<NT, D, IN>())) void oeh_attn_m
         const int key0 = 16 * t + 4 * g;
         f4 pv;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_fmed3f(__builtin_rintf(s[t][r] * cinv), plo, phi);
+        for (int r = 0; r < 4; ++r) {
+          if (P.clip) {  // (the full-row kernel's clipped grid form, same operations)
+            const float pc = __builtin_amdgcn_fmed3f(__builtin_fmaf(s[t][r], clip_iw, clip_g), 0.0f, 1.0f);
+            pv[r] = __builtin_amdgcn_fmed3f(__builtin_rintf(pc * P.fq_p.rscale), plo, phi);
+          } else {
+            pv[r] = __builtin_amdgcn_fmed3f(__builtin_rintf(s[t][r] * cinv), plo, phi);
+          }
+        }
         if (dump_p && qvalid) dump4(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * P.Sk + key0, fq_dump_word(pv, P.fq_p), P.Sk - key0);
         if constexpr (MI == IN_BF16) {
           ph[t].x = pack2_bf16(pv[0], pv[1]);
@@ -523,7 +532,7 @@ static int launch_one(const AttnParams& P, hipStream_t st) {
 template <int NT, int D>
 static int launch_nt_d(const AttnParams& P, int in, bool fq, hipStream_t st) {
   if (fq) {
-    const bool grid_chain = P.fq_s.en && P.fq_p.en && !P.clip && P.pad == nullptr && P.full == nullptr && P.scale_div == 0.0f;
+    const bool grid_chain = P.fq_s.en && P.fq_p.en && P.pad == nullptr && P.full == nullptr && P.scale_div == 0.0f;
     if (grid_chain) {
       switch (in) {
         case IN_F16: return launch_one<NT, D, IN_F16, 1>(P, st);

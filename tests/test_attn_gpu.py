@@ -1670,3 +1670,36 @@ def test_full_masks_on_long_rows_run_the_one_pass_kernel(ops, dt, base):
                            key_pad_mask=None if pad is None else torch.from_numpy(pad).cuda(), clamp_min=True, mask_min=fmin)
         _check(got, want, tol=tol, msg=f"full mask, pad={pad is not None}, base={base}")
     assert ops.attn_variant(B, H, Sq, 512, D, dt, base=base, full_mask=True, scale=0.125, mask_min=fmin).startswith("mfma16/")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,dt", [(512, torch.float16), (704, torch.float16), (640, torch.float32), (128, torch.float16)])
+@pytest.mark.parametrize("pad", [False, True])
+def test_clipped_int8_chain_on_the_quantiser_grid(ops, S, dt, pad):
+    """Clipped softmax together with the three fake-quantisers (the reference's `--attn_softmax clipped...` with `--quantize`,
+    quantized_opt.py:151-210 around models/softmax.py:16-19): since round 3 on the quantiser grid too - the clip as one clamped fma
+    between the exponential and the probability's index - in the full-row kernel and, for rows of more than 512 keys, in the two-pass
+    form (before: the literal chain, 38 against 27 us on the OPT shape; the any-shape kernel on long rows).  Against the oracle."""
+    B, H, D = 2, 2, 64
+    fmin = float(np.finfo(np.float32).min)
+    sm = "clippedsoftmax1(-.025:1)"
+    q = (_rand((B, H, S, D), 9101, dtype=dt).float() * D ** -0.5).to(dt)
+    k, v = _rand((B, H, S, D), 9102, dtype=dt), _rand((B, H, S, D), 9103, dtype=dt)
+    padm = _pad_mask(B, S, [S, S - 41], fmin) if pad else None
+    common = dict(causal=True, clamp_min=True, pad_mask=padm, mask_min=fmin, **SPECS[sm])
+    vis = dict(common, pad_mask=None)
+    _, fp = O.attn_core(_np32(q), _np32(k), _np32(v), want=("scores", "probs"), **vis)
+    d_s = O.quant_range_to_params(*np.percentile(fp["scores"], (0.001, 99.999)))
+    d_p = O.quant_range_to_params(*np.percentile(fp["probs"], (0.001, 99.999)))
+    d_c = O.quant_range_to_params(*np.percentile(O.attn_core(_np32(q), _np32(k), _np32(v), **vis), (0.001, 99.999)))
+    want = O.attn_core(_np32(q), _np32(k), _np32(v), fq_scores=d_s, fq_probs=d_p, fq_ctx=d_c, **common)
+    name = ops.attn_variant(B, H, S, S, D, dt, fq=True, clip=True, base=1, gamma=-0.025, causal=True, key_pad=pad, key_pad_boolean=pad, mask_min=fmin)
+    assert name.startswith("flash16/" if S > 512 else "fast16/") and name.endswith("/fq2p" if S > 512 else "/fq"), name
+    FQ = ops.FakeQuantSpec.from_delta
+    got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=_spec(ops, sm), causal=True, clamp_min=True, mask_min=fmin,
+                       key_pad_mask=None if padm is None else torch.from_numpy(padm).cuda(), key_pad_boolean=pad,
+                       fq=ops.AttnFakeQuant(FQ(*d_s), FQ(*d_p), FQ(*d_c)))
+    step = float(np.float32(d_c[0]))
+    err = np.abs(_np32(got) - want)
+    off = float((err > 0.5 * step).mean())
+    assert np.isfinite(_np32(got)).all() and off < 4e-3 and err.max() <= 2.05 * step + 2e-3, f"{off:.2e} off, max {err.max() / step:.2f} steps"
