@@ -149,7 +149,7 @@ typedef struct oeh_attn_desc {
    *   o has dtype o_dtype (OEH_F16 | OEH_BF16 | OEH_F32).
    * Requires D == 64, Sk <= 512 and a multiple of 16, 16-byte aligned rows, masks none | causal | key_pad_mask (with or
    * without causal) whose entries are 0 (visible) or <= -1e4 (padded: HF's extended masks hold 0 / finfo.min) - a padded key is
-   * dropped exactly like a causally hidden one, other mask values are NOT added to the scores on this path -, no clipping, and `fq`
+   * dropped exactly like a causally hidden one, other mask values are NOT added to the scores on this path -, clipping only with gamma <= 0 (the reference's registry), and `fq`
    * with scores and probabilities enabled (probabilities on a full 8-bit grid, qmax == 255; whole-number zero points, as
    * uniform_quantizers.py:79 makes them): OEH_ENOTSUP otherwise (run the fake-quant variants on dequantised values).
    * The test-only index dumps (oeh_fq.dump_idx) are honoured with o_dtype == OEH_F32: scores for every key (the reference

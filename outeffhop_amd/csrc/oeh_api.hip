@@ -248,7 +248,7 @@ bool i8_eligible(const oeh_attn_desc* d, const void* q, const void* k, const voi
   if (fq->probs.zero_point != std::nearbyint(fq->probs.zero_point) || fq->scores.zero_point != std::nearbyint(fq->scores.zero_point)) return false;
   const bool dumps = fq->scores.dump_idx != nullptr || fq->probs.dump_idx != nullptr || fq->ctx.dump_idx != nullptr;
   if (dumps && d->o_dtype != OEH_F32) return false;  // the index dumps (tests) exist in the fp32-output form
-  if (d->clip || d->full_mask != nullptr || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
+  if ((d->clip && d->gamma > 0.0f) || d->full_mask != nullptr || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
   if (d->key_pad_mask != nullptr && !(d->mask_min < -1.0e4f)) return false;  // (a key-padding vector of 0 / <= -1e4 entries: include/oeh.h)
   if (d->scale_div != 0.0f ? !(d->scale_div > 0.0f && std::isfinite(d->scale_div)) : !(d->scale > 0.0f && std::isfinite(d->scale))) return false;
   if (d->causal && (d->Sq > d->Sk || !(d->mask_min < -1.0e4f))) return false;

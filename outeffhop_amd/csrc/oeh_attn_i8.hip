@@ -22,7 +22,7 @@
 // Masks: none | analytic causal | a key-padding vector (PAD variants: BERT's (B,1,1,S) mask, OPT's padded batches) whose
 // entries are 0 or <= -1e4 (HF's extended masks: 0 / finfo.min - the host checks it once per mask tensor): a padded key
 // carries the sentinel like a causally hidden one, its exponential is exactly 0 as in the reference.  Everything else of the
-// INT8 configuration (clipping, other head dims, arbitrary additive masks) runs the fake-quant variants of the 16-bit / fp32
+// INT8 configuration (clipping with gamma > 0, other head dims, arbitrary additive masks) runs the fake-quant variants of the 16-bit / fp32
 // kernels on dequantised values.
 //
 // The vector arithmetic per score element is the cost of this kernel (round 2: 21.7 wave-instructions per element, the
@@ -284,7 +284,10 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   sum = row4_sum(sum);
   float den = sum;
   if (P.base != 0) den = sum + exp_acc(m * -1.0f);
-  const float cinv = (1.0f / den) * P.fq_p.rscale, pzp = P.fq_p.zp;
+  const float inv_den = 1.0f / den;
+  const float cinv = inv_den * P.fq_p.rscale, pzp = P.fq_p.zp;
+  const float clip_iw = inv_den * P.clip_w, clip_g = P.clip_g, prs = P.fq_p.rscale;  // clipped softmax (round 3): one clamped fma in front of the index
+  const bool clipped = P.clip != 0;
   // probabilities: index = sat_u8(rne(e * cinv + zp)) by v_cvt_pk_u8_f32, four keys to a register, centred by the XOR;
   // a masked key has e == 0, index zp, value 0.  The centred indices' row sum goes with them.
   int psum = 0;
@@ -294,8 +297,16 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         unsigned w = 0u;
+        if (clipped) {  // clip(p (eta - gamma) + gamma, 0, 1) (models/softmax.py:16-19; gamma <= 0: a masked key, e = 0, stays 0), then the index
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(s[kt * 4 + t][r], cinv, pzp), r, w);
+          for (int r = 0; r < 4; ++r) {
+            const float pc = __builtin_amdgcn_fmed3f(__builtin_fmaf(s[kt * 4 + t][r], clip_iw, clip_g), 0.0f, 1.0f);
+            w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(pc, prs, pzp), r, w);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(s[kt * 4 + t][r], cinv, pzp), r, w);
+        }
         if constexpr (DUMP) {
           const int key0 = 64 * kt + 16 * g + 4 * t;
           if (P.fq_p.dump != nullptr && qvalid && key0 < Sk) *reinterpret_cast<unsigned*>(P.fq_p.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0) = w;

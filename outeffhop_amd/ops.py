@@ -374,7 +374,7 @@ def attn_fwd_i8(q: torch.Tensor, k: torch.Tensor, v_t: torch.Tensor, grids, *, f
     (q, k, v) QuantGrid; `fq` with scores and probabilities (8-bit) [and context].  Returns the logical (B,H,Sq,64) result in
     `out_dtype`, stored (B,Sq,H,64)-contiguous.  `key_pad_mask`: (B,Sk) additive, entries 0 or <= -1e4 ONLY (HF's extended
     masks; the caller vouches for it - `attention.pad_is_boolean`).  Raises OehError(-95) for what this path does not take
-    (clipping, other head dims, full additive masks ...): the caller then runs `attn_fwd(..., fq=...)` on the dequantised values."""
+    (clipping with gamma > 0, other head dims, full additive masks ...): the caller then runs `attn_fwd(..., fq=...)` on the dequantised values."""
     dev = _need_gpu(q, k, v_t, gate, out, key_pad_mask)
     if q.dtype != torch.int8 or k.dtype != torch.int8 or v_t.dtype != torch.int8:
         raise ValueError("q, k, v_t must be int8 (centred indices)")

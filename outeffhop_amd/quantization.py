@@ -761,7 +761,7 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
         """the q/k/v projections are QuantLinear - their outputs ARE 8-bit indices on calibrated grids
         (hijacker.py:78-127; quantized_opt.py:67-75, quantized_bert.py:236-238) - so the attention core takes the indices
         themselves and runs both products on the integer matrix cores (`ops.attn_fwd_i8`, include/oeh.h dtype OEH_I8).  Applies
-        when the three output quantisers are 8-bit with frozen ranges, head_dim = 64, the softmax is not clipped and the mask is
+        when the three output quantisers are 8-bit with frozen ranges, head_dim = 64, the softmax is unclipped or clipped with gamma <= 0 and the mask is
         none / causal / a key-padding vector of 0 / finfo.min entries (`padvec`, vouched for by the caller); returns the
         merged context (B, T, E) and the (k, v) float values (`want_values`: a decoder's cache), or None -> the caller runs the
         fake-quant path on floats.  `consumer`: the QuantLinear that takes the context next (OPT's out_proj); when the context
@@ -771,7 +771,7 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
             return None
         spec = spec_of(self.softmax_fn)
         bsz, tgt_len, _ = hidden_states.shape
-        if spec is None or spec.clip or tgt_len % 16 != 0 or tgt_len > 512 or fq.probs is None or fq.probs.qmax != 255.0 or fq.scores is None:
+        if spec is None or (spec.clip and spec.gamma > 0.0) or tgt_len % 16 != 0 or tgt_len > 512 or fq.probs is None or fq.probs.qmax != 255.0 or fq.scores is None:
             return None
         if not all(isinstance(m, QuantLinear) and m._qa and m.activation_quantizer.is_fixed and m.activation_quantizer.quantizer.n_bits == 8
                    and m.activation_function is None for m in lins):

@@ -1189,9 +1189,22 @@ def test_int8_storage_on_the_integer_matrix_cores(ops, S, causal, base, out_dtyp
                        mask_min=fmin, gate=gate.cuda(), fq=fq)
     d2 = (got.float() - ref).abs()
     assert float(d2.max()) <= 1.01 * step + tol and float((d2 > tol + 1e-3 * ref.abs()).float().mean()) <= 3e-4
-    # not this path: key padding, clipping, a 7-bit probability grid, another head dim -> refused, never silently something else
+    # clipped softmax (gamma <= 0: the reference's registry) on the integer cores since round 3: against the oracle, same bounds
+    csm = SPECS["clippedsoftmax1(-.025:1)"]
+    ccommon = dict(causal=causal, clamp_min=causal, **csm)
+    cctx, cfp = O.attn_core(qdh, kdh, vdh, want=("scores", "probs"), **ccommon)
+    c_p = O.quant_range_to_params(*np.percentile(cfp["probs"], (0.001, 99.999)))
+    c_c = O.quant_range_to_params(*np.percentile(cctx, (0.001, 99.999)))
+    cwant = O.attn_core(qdh, kdh, vdh, fq_scores=d_s, fq_probs=c_p, fq_ctx=c_c, ctx_quant_before_gate=True, gate=gate.numpy(), **ccommon)
+    cgot = ops.attn_fwd_i8(qc, kc, vt, grids, fq=ops.AttnFakeQuant(FQ(*d_s), FQ(*c_p), FQ(*c_c)), out_dtype=out_dtype,
+                           softmax=ops.SoftmaxSpec(1, True, csm["gamma"], csm["eta"]), scale=scaling, causal=causal, clamp_min=causal, mask_min=fmin, gate=gate.cuda())
+    cstep = float(np.float32(c_c[0]))
+    cerr = np.abs(_np32(cgot) - cwant)
+    coff = float((cerr > tol + (0 if out_dtype == torch.float32 else 1e-3) * np.abs(cwant)).mean())
+    assert cerr.max() <= 1.01 * cstep + tol and coff <= 1e-3, f"clipped: max err {cerr.max():.3e} (step {cstep:.3e}), {coff:.2e} off their grid point"
+    # not this path: gamma > 0, a 7-bit probability grid, another head dim -> refused, never silently something else
     with pytest.raises(OehError) as ei:
-        ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, softmax=ops.SoftmaxSpec(1, True, -0.025, 1.1), scale=scaling)
+        ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, softmax=ops.SoftmaxSpec(1, True, 0.01, 1.1), scale=scaling)
     assert ei.value.code == -95
     with pytest.raises(OehError):
         ops.attn_fwd_i8(qc, kc, vt, grids, fq=ops.AttnFakeQuant(FQ(*d_s), ops.FakeQuantSpec(1 / 127.0, 0.0, 127.0), None), scale=scaling)
@@ -1251,7 +1264,7 @@ def test_int8_storage_key_padding_and_bert_order(ops, order, causal, base):
     # a mask value that is neither 0 nor <= -1e4 is the caller's to keep away (attention.pad_is_boolean); a full additive mask is refused
     from outeffhop_amd._lib import OehError
     with pytest.raises((OehError, TypeError)):
-        ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, softmax=ops.SoftmaxSpec(1, True, -0.025, 1.1), key_pad_mask=dev(padm), **kkw)
+        ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, softmax=ops.SoftmaxSpec(1, True, 0.01, 1.1), key_pad_mask=dev(padm), **kkw)   # (gamma > 0)
 
 
 def test_int8_storage_indices_match_the_reference_capture(ops):
