@@ -47,7 +47,8 @@ def main():
         sc = float(rng.uniform(0.05, 0.3))
         step = float(rng.choice([0.01, 0.02, 0.04]))
         fq = ops.AttnFakeQuant(FQ(sc, float(rng.integers(100, 160))), FQ(1.0 / 255.0, 0.0), FQ(step, float(rng.integers(110, 146))), ctx_before_gate=not bert)
-        kw = dict(softmax=ops.SoftmaxSpec(base), causal=causal, clamp_min=bool(causal or use_pad), mask_min=fmin)
+        clip = bool(rng.random() < 0.3)
+        kw = dict(softmax=ops.SoftmaxSpec(base, clip, -0.025 if clip else 0.0, 1.1 if clip else 1.0), causal=causal, clamp_min=bool(causal or use_pad), mask_min=fmin)
         if bert:
             kw["scale_div"] = 8.0
         else:
@@ -62,7 +63,7 @@ def main():
                 else:
                     pad[b, L:] = fmin
         gate = torch.rand(B, H, S, 1, device=dev, generator=g) if use_gate else None
-        desc = f"B={B} H={H} S={S} causal={int(causal)} pad={int(use_pad)} base={base} bert={int(bert)} gate={int(use_gate)} out={str(out_dt)[6:]} zq={zq}"
+        desc = f"B={B} H={H} S={S} clip={int(clip)} causal={int(causal)} pad={int(use_pad)} base={base} bert={int(bert)} gate={int(use_gate)} out={str(out_dt)[6:]} zq={zq}"
         try:
             got = ops.attn_fwd_i8(q8, k8, v8t, grids, fq=fq, out_dtype=out_dt, key_pad_mask=pad, gate=gate, **kw).float()
         except Exception as e:  # noqa: BLE001
