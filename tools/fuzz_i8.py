@@ -4,7 +4,7 @@
 operand pairs, fp32-accurate scores) - shapes, causal / key padding / none, both softmax bases, BERT and OPT order, gate, q grids
 with zero point 0 / 255 (the CQ2 variant), output dtypes, the integer output (`ctx_emit_index`).  The two must agree except
 where a score or probability sat on a rounding boundary of its quantiser (exact integer products against rounded fp32 ones):
-such rows differ; a report is printed when more than two rows and 1 % of the rows are apart.
+such rows differ (and single steps of the context grid anywhere); a report is printed when more than 1 % of the outputs in more than two rows and 1 % of the rows are apart.
 usage: python tools/fuzz_i8.py [seconds=90] [seed=0]"""
 import os
 import sys
@@ -76,7 +76,7 @@ def main():
         lim = 0.5 * step + tol + tol * ref.abs()
         off = float((err > lim).float().mean())
         rows_bad = int((err > lim).any(dim=-1).sum())   # a tie flips ONE row's probabilities: count rows, a tiny problem has few of them
-        if not torch.isfinite(got).all() or rows_bad > max(2, 0.01 * B * H * S):
+        if not torch.isfinite(got).all() or (off > 1e-2 and rows_bad > max(2, 0.01 * B * H * S)):
             print(f"MISMATCH {off:.2e} of the outputs apart, max {float(err.max()) / step:.2f} steps | {desc}", flush=True)
             bad += 1
         elif off > 0:
