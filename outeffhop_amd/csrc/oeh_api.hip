@@ -146,6 +146,7 @@ bool fast_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
 }
 
 int g_force_flash = 0;                   // tools/microbench.py only
+int g_force_small = 0;                   // tests: the small-shape kernel wherever it can run (no size heuristic)
 
 // The one-pass kernel (oeh_attn_flash.inl) additionally needs the plain softmax_n (no clip).  No Sk limit.
 bool flash_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq, bool short_rows_too = false) {
@@ -211,8 +212,12 @@ bool small_eligible(const oeh_attn_desc* d, const void* q, const void* k, const 
   if (any_fq(fq) || d->key_pad_mask != nullptr || d->full_mask != nullptr || d->causal) return false;
   if (d->gate == nullptr && d->gate_hidden != nullptr) return false;
   if (!(d->D == 16 || d->D == 32 || d->D == 64) || d->Sk > 64 || d->Sq > 64) return false;
-  // a wave per problem only pays when there are enough problems to fill the chip (or no matrix-core kernel takes the shape)
-  if (!(d->D == 16 || (long)d->B * d->H >= 256)) return false;
+  // A wave per problem only pays when there are enough problems to fill the chip and on fp32 data, where it also is the EXACT path
+  // (fp32 matrix-core products: 3e-6 of the reference; the operand-pair kernels round the probability operand to fp16) - measured,
+  // round 3 (B*H = 768..896, d = 64): fp32 S = 28 9.3 us against 10.3 in the one-pass kernel (S = 64: 20.3 against 13.5, kept here for
+  // the accuracy); 16-bit data: S = 28 8.3 against 8.05 in the full-row kernel, S = 48 18.6 against 6.6, S = 64 19.9 against 7.1 - so
+  // 16-bit problems take the matrix-core kernels - or when no matrix-core kernel takes the shape (d = 16)
+  if (!g_force_small && d->D != 16 && (d->dtype != OEH_F32 || (long)d->B * d->H < 256)) return false;
   const int ab = 4 * elem_bytes(d->dtype);
   const int64_t* sts[4] = {d->q_stride, d->k_stride, d->v_stride, d->o_stride};
   const void* ps[4] = {q, k, v, o};
@@ -536,7 +541,7 @@ static bool debug_hooks_on() {
 }
 int oeh_debug_set_variant(int off_mask, int flash_mq_force) {
   if (!debug_hooks_on()) return OEH_ENOTSUP;
-  g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force; g_place = (off_mask >> 9) & 1;
+  g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force; g_place = (off_mask >> 9) & 1; g_force_small = (off_mask >> 10) & 1;
   { const char* e = std::getenv("OEH_HEAD_GROUP"); g_head_group = e != nullptr ? (std::atoi(e) & ~7) : 0; }
   return OEH_OK;
 }
