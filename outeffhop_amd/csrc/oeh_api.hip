@@ -159,9 +159,14 @@ bool flash_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq, bool short_ro
   // (key padding under the vanilla softmax: a row without a visible key is uniform over ALL keys in the reference - the PAD variant's
   // epilogue gives such rows the mean of V, oeh_attn_flash.inl)
   if (short_rows_too) return true;
-  // short rows (<= 128 keys) fit the full-row kernel's registers in one pass, which measures faster there
-  // (BERT-base S=128: 10.0 vs 11.7 us per launch)
-  if (d->Sk <= 128 && !g_force_flash) return false;
+  // short rows (<= 128 keys) fit the full-row kernel's registers in one pass, which measures faster there (BERT-base B=32 S=128:
+  // 7.7 vs 9.7 us per launch) - until the batch is large enough for the one-pass kernel's 128-row workgroups to fill the chip by
+  // themselves (>= 768 of them): then its halved K / V streaming wins (H=12 S=128, round 3: B=48 12.3 vs 13.0 us, B=64 15.5 vs 14.5,
+  // B=96 23.0 vs 20.3, B=128 31.5 vs 24.2)
+  if (d->Sk <= 128 && !g_force_flash) {
+    const long wgs = (long)d->B * d->H * ((d->Sq + 127) / 128);
+    if (!(d->Sk > 64 && d->Sq >= 112 && wgs >= 768)) return false;
+  }
   return true;
 }
 
