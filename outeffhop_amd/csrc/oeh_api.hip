@@ -165,7 +165,7 @@ bool flash_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq, bool short_ro
   // B=96 23.0 vs 20.3, B=128 31.5 vs 24.2)
   if (d->Sk <= 128 && !g_force_flash) {
     const long wgs = (long)d->B * d->H * ((d->Sq + 127) / 128);
-    if (!(d->Sk > 64 && d->Sq >= 112 && wgs >= 768)) return false;
+    if (!(d->Sk > 64 && d->Sq >= 112 && wgs >= (d->D <= 32 ? 1536 : 768))) return false;  // (d = 32: 768 workgroups 12.6 vs 11.5 us, 1536 21.3 vs 22.7)
   }
   return true;
 }
