@@ -200,7 +200,11 @@ bool flash32_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
   if (d->dtype != OEH_F32 || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
   oeh_attn_desc t = *d;
   t.dtype = OEH_F16;
-  return flash_eligible(&t, fq, true);  // short rows as well: BERT-base S=128 15.4 us against 16.7 us in the general kernel
+  if (!flash_eligible(&t, fq, true)) return false;
+  // rows of <= 128 keys: the full-row kernel's fp32 form where it applies, at every batch size measured (round 3, H=12 S=128: B=32 16.5
+  // vs 20.0 us, B=64 29.8 vs 30.6, B=128 54.6 vs 57.7); what it does not take stays here (16.7 us in the general kernel)
+  if (d->Sk <= 128 && !g_force_flash && d->full_mask == nullptr && fast_eligible(&t, fq)) return false;
+  return true;
 }
 // ... and on the full-row kernel (clipped softmax, the INT8 chain, vanilla softmax with key padding)
 bool fast32_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
