@@ -62,6 +62,12 @@ WORKLOADS = {
     "bert_int8_i8": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=True, gate=False, i8=True,
                          desc="BERT-base attention core B=32 H=12 S=128 d=64 key-padding mask softmax1, q/k/v as int8 indices of 8-bit grids "
                               "(v transposed), both products on v_mfma_i32_16x16x64_i8, 3 fused INT8 quantisers, fp32 output"),
+    # ... and in fp32 storage, the precision the reference's validate_mlm_config.py runs (accelerate_configs/1gpu_no_mp.yaml)
+    "bert_softmax1_fp32": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=False, gate=False, fp32=True,
+                               desc="BERT-base attention core B=32 H=12 S=128 d=64 fp32 storage key-padding mask softmax1"),
+    "bert_gated_fp32": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=False, gate=True, fp32=True,
+                            desc="BERT-base gated attention core B=32 H=12 S=128 d=64 fp32 storage: per-token gate from per-head MLPs 64->16->1 "
+                                 "evaluated inside the attention kernel on fp16 operand pairs"),
     "bert_gated": dict(B=32, H=12, S=128, d=64, order="bert", sm=(1, False, 0.0, 1.0), int8=False, gate=True,
                        desc="BERT-base gated attention core B=32/GPU H=12 S=128 d=64 fp16: per-token gate from per-head MLPs "
                             "64->16->1 on the layer input, evaluated inside the attention kernel (gate_hidden ... of oeh_attn_desc)"),

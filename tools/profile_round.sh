@@ -6,7 +6,7 @@
 # goes under gpurun_out/prof_<round>/ (scratch); tools/profile_summary.py turns it into the tracked files under profiles/.
 set -u
 ROUND=$1; shift
-WLS=${@:-opt_softmax1 opt_clipped opt_int8 opt_int8_i8 opt_softmax1_fp32 opt_int8_fp32 bert_softmax1 bert_gated bert_int8 bert_int8_i8 stanhop}
+WLS=${@:-opt_softmax1 opt_clipped opt_int8 opt_int8_i8 opt_softmax1_fp32 opt_int8_fp32 bert_softmax1 bert_gated bert_int8 bert_int8_i8 bert_softmax1_fp32 bert_gated_fp32 stanhop}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$ROUND
 mkdir -p "$OUT"
