@@ -250,7 +250,7 @@ int flash_mq(const oeh_attn_desc* d) {
   if (g_flash_mq != 0 && !(d->D == 128 && d->dtype == OEH_F32)) return g_flash_mq;
   if (d->D == 128 && d->dtype == OEH_F32) return 1;  // two blocks of fp32 operand pairs at d = 128 do not fit the register file (130 spills)
   const long wg2 = (long)((d->Sq + 127) / 128) * d->B * d->H;
-  return (d->Sq > 64 && wg2 >= 512) ? 2 : 1;
+  return (d->Sq > 64 && wg2 >= 416) ? 2 : 1;  // (H=12 S=512 causal: B=8 - 384 workgroups - 10.8 vs 12.4 us with one block per wave, B=9 - 432 - 13.3 vs 12.8, B=10 14.5 vs 12.7, B=12 16.2 vs 13.5)
 }
 
 // INT8 storage (oeh_attn_i8.hip): see include/oeh.h, oeh_attn_desc.q_grid
