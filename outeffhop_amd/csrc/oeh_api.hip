@@ -163,6 +163,9 @@ bool flash_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq, bool short_ro
   // 7.7 vs 9.7 us per launch) - until the batch is large enough for the one-pass kernel's 128-row workgroups to fill the chip by
   // themselves (>= 768 of them): then its halved K / V streaming wins (H=12 S=128, round 3: B=48 12.3 vs 13.0 us, B=64 15.5 vs 14.5,
   // B=96 23.0 vs 20.3, B=128 31.5 vs 24.2)
+  // causal rows whose count leaves the last 128-row workgroup at most half full (S = 192, 320, 448): the full-row kernel's 64-row
+  // workgroups waste nothing there (16.9 vs 18.3, 15.7 vs 17.1, 18.7 vs 19.4 us); without the causal mask the one-pass kernel keeps its lead
+  if (d->causal && d->Sk <= 512 && ((d->Sq - 1) % 128) < 64 && d->Sq > 128 && !g_force_flash && !short_rows_too) return false;
   if (d->Sk <= 128 && !g_force_flash) {
     const long wgs = (long)d->B * d->H * ((d->Sq + 127) / 128);
     if (!(d->Sk > 64 && d->Sq >= 112 && wgs >= (d->D <= 32 ? 1536 : 768))) return false;  // (d = 32: 768 workgroups 12.6 vs 11.5 us, 1536 21.3 vs 22.7)

@@ -460,7 +460,7 @@ def test_snake_block_order_changes_nothing_but_the_placement(ops):
     from outeffhop_amd import _lib
 
     lib = _lib.load()
-    for n, (B, H, S) in enumerate([(16, 12, 512), (5, 12, 512), (3, 7, 1024), (9, 12, 320)]):
+    for n, (B, H, S) in enumerate([(16, 12, 512), (5, 12, 512), (3, 7, 1024), (9, 12, 384)]):
         q, k, v = (_rand((B, H, S, 64), 3100 + 3 * n + i).cuda() for i in range(3))
         assert ops.attn_variant(B, H, S, S, 64, torch.float16, causal=True).startswith("flash16/")
         a = ops.attn_fwd(q, k, v, causal=True, clamp_min=True)
@@ -600,7 +600,7 @@ def test_gate_predictor_fused_one_pass(ops, mq, units):
     from outeffhop_amd import _lib
 
     lib = _lib.load()
-    B, H, S, D = 2, 3, 300, 64
+    B, H, S, D = 2, 3, 330, 64
     fmin = float(np.finfo(np.float32).min)
     q = (_rand((B, S, H * D), 6001).float() * 0.125).half()
     k, v, hidden = _rand((B, S, H * D), 6002), _rand((B, S, H * D), 6003), _rand((B, S, H * D), 6004).cuda()
@@ -617,14 +617,14 @@ def test_gate_predictor_fused_one_pass(ops, mq, units):
         gate_o = O.gate_values(_np32(hidden), H, "linear", dict(w=w1.cpu().numpy(), b=b1.cpu().numpy()))
     lib.oeh_debug_set_variant(0, mq)
     try:
-        for pad in (None, torch.from_numpy(_pad_mask(B, S, [300, 170], fmin)).cuda()):
+        for pad in (None, torch.from_numpy(_pad_mask(B, S, [330, 170], fmin)).cuda()):
             assert ops.attn_variant(B, H, S, S, D).startswith(f"flash16/MQ{mq}/")
             gp = ops.GatePredictor(hidden, w1, b1, w2, b2, scaling=1.0, out=torch.empty((B, H, S), dtype=torch.float32, device="cuda"))
             kw = dict(causal=True, clamp_min=True, key_pad_mask=pad, mask_min=fmin)
             got = ops.attn_fwd(view(q), view(k), view(v), gate_mlp=gp, **kw)
             gerr = float(np.abs(gp.out.cpu().numpy() - gate_o[..., 0]).max())
             assert gerr < 2e-3, f"in-kernel gate vs the oracle's predictor: {gerr:.3e}"
-            okw = dict(causal=True, clamp_min=True, pad_mask=None if pad is None else _pad_mask(B, S, [300, 170], fmin))
+            okw = dict(causal=True, clamp_min=True, pad_mask=None if pad is None else _pad_mask(B, S, [330, 170], fmin))
             want_o = O.attn_core(_np32(view(q)), _np32(view(k)), _np32(view(v)), gate=gate_o, **okw, **SPECS["softmax1"])
             ctx = np.abs(O.attn_core(_np32(view(q)), _np32(view(k)), _np32(view(v)), **okw, **SPECS["softmax1"]))
             err = np.abs(_np32(got) - want_o)
@@ -1600,7 +1600,7 @@ def test_long_rows_with_key_padding_two_pass(ops, order, kind, dt):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("S", [320, 704])
+@pytest.mark.parametrize("S", [384, 704])
 @pytest.mark.parametrize("dt", [torch.float16, torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("causal", [False, True])
 def test_vanilla_softmax_with_key_padding_on_the_one_pass_kernel(ops, S, dt, causal):
