@@ -146,6 +146,7 @@ bool fast_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
 }
 
 int g_force_flash = 0;                   // tools/microbench.py only
+int g_no_d128_rule = 0;                 // tests: the full-row kernel also for head dim 128 with clip / INT8 (the comparison against the general kernel)
 int g_force_small = 0;                   // tests: the small-shape kernel wherever it can run (no size heuristic)
 
 // The one-pass kernel (oeh_attn_flash.inl) additionally needs the plain softmax_n (no clip).  No Sk limit.
@@ -181,7 +182,7 @@ bool flash_clip_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
   if (!d->clip || any_fq(fq) || !fast_eligible(&t, fq)) return false;  // (fast_eligible: gamma <= 0, masks, scale)
   if (d->gate == nullptr && d->gate_hidden != nullptr) return false;
   if (d->key_pad_mask != nullptr && d->softmax_base != OEH_SOFTMAX_ONE) return false;  // (as in the one-pass form: trailing padded tiles are not streamed)
-  return d->Sk > 512 || g_force_flash;
+  return d->Sk > 512 || (d->D == 128 && d->Sk >= 384) || g_force_flash;  // (d = 128, S = 512: 47.4 vs 58.2 us in the full-row kernel, causal 38.1 vs 41.2)
 }
 
 // The fused INT8 chain on rows of MORE than 512 keys: the one-pass kernel's two-pass form of the grid chain (TP = 2).  What
@@ -295,7 +296,11 @@ Variant pick_variant(const oeh_attn_desc* d, const void* q, const void* k, const
   if (d_ok && al && flash32_eligible(d, fq) && !(g_variant_off & ((1 << V_FLASH) | (1 << 6)))) return V_FLASH;
   if (d_ok && al && flash_fq_eligible(d, fq) && !(g_variant_off & ((1 << V_FLASH) | (d->dtype == OEH_F32 ? (1 << 6) : 0)))) return V_FLASH;
   if (d_ok && al && flash_clip_eligible(d, fq) && !(g_variant_off & ((1 << V_FLASH) | (d->dtype == OEH_F32 ? (1 << 6) : 0)))) return V_FLASH;
-  if (shape_ok && p_exact && al && fast_eligible(d, fq) && !(g_variant_off & (1 << V_FAST))) return V_FAST;
+  // head dim 128: the full-row kernel fits ONE workgroup per CU (16-KB tiles), and with the clip or the INT8 chain on top the general
+  // kernel - smaller workgroups of its own - measures faster (round 3, B=16 H=8 S=512 causal: INT8 44.6 vs 39.8 us, clipped 41.2 vs 39.7;
+  // S=256 clipped 30.3 vs 25.0); the plain softmax stays on the one-pass / full-row kernels
+  const bool d128_general = !g_no_d128_rule && d->D == 128 && d->dtype != OEH_F32 && (any_fq(fq) || d->clip) && d->key_pad_mask == nullptr && !(d->gate == nullptr && d->gate_hidden != nullptr);
+  if (shape_ok && p_exact && al && fast_eligible(d, fq) && !d128_general && !(g_variant_off & (1 << V_FAST))) return V_FAST;
   if (shape_ok && p_exact && al && fast32_eligible(d, fq) && !(g_variant_off & ((1 << V_FAST) | (1 << 7)))) return V_FAST;
   if (shape_ok && p_exact && al) return V_MFMA;
   if ((size_t)(d->D + d->Sk) * 4 <= 64 * 1024) return V_GENERIC;
@@ -556,7 +561,7 @@ static bool debug_hooks_on() {
 }
 int oeh_debug_set_variant(int off_mask, int flash_mq_force) {
   if (!debug_hooks_on()) return OEH_ENOTSUP;
-  g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force; g_place = (off_mask >> 9) & 1; g_force_small = (off_mask >> 10) & 1;
+  g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force; g_place = (off_mask >> 9) & 1; g_force_small = (off_mask >> 10) & 1; g_no_d128_rule = (off_mask >> 11) & 1;
   { const char* e = std::getenv("OEH_HEAD_GROUP"); g_head_group = e != nullptr ? (std::atoi(e) & ~7) : 0; }
   return OEH_OK;
 }

@@ -692,7 +692,7 @@ def test_fq_kernels_agree_bitwise_on_ragged_shapes(ops):
                  (0.004 + 0.02 * float(rng.random()), float(rng.integers(60, 190)))]
         want_dump = bool(rng.integers(0, 2))
         res = []
-        for off_mask in (0, 4):  # as picked (full-row FQ variant); full-row kernel disabled (general kernel)
+        for off_mask in (1 << 11, 4):  # the full-row FQ variant (also at d = 128, where the library would pick the general kernel); full-row kernel disabled (general kernel)
             dumps = [torch.zeros((B, H, Sq, Sk), dtype=torch.uint8, device="cuda"), torch.zeros((B, H, Sq, Sk), dtype=torch.uint8, device="cuda"),
                      torch.zeros((B, H, Sq, D), dtype=torch.uint8, device="cuda")] if want_dump else [None] * 3
             specs = [FQ(g_[0], g_[1], dump=d_) if o_ else None for g_, d_, o_ in zip(grids, dumps, on)]

@@ -3,12 +3,13 @@
 disabled): where is the pick not the fastest?  usage: python tools/probe/variant_sweep.py"""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+D = int(os.environ.get("SWEEP_D", "64")); H = int(os.environ.get("SWEEP_H", "12")); DT = os.environ.get("SWEEP_DT", "f16")
 specs = []
 for S, B in ((64, 128), (128, 64), (192, 48), (256, 32), (320, 24), (384, 24), (512, 16), (768, 12), (1024, 8)):
     for causal in (0, 1):
         for extra in ("", ",clip=1", ",int8=1"):
-            base = f"B={B},S={S},causal={causal}{extra},iters=150"
-            specs += [base, base + ",off=2", base + ",off=4", base + ",off=256"]
+            base = f"B={B},H={H},S={S},D={D},dtype={DT},causal={causal}{extra},iters=150"
+            specs += [base, base + (",off=66" if DT == "f32" else ",off=2"), base + (",off=132" if DT == "f32" else ",off=4"), base + ",off=256"]
 out = subprocess.run([sys.executable, os.path.join(root, "tools", "microbench.py")] + specs, capture_output=True, text=True, cwd=root).stdout
 rows = [l for l in out.splitlines() if " us " in l]
 for i in range(0, len(rows), 4):
