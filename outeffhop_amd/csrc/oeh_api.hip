@@ -228,12 +228,12 @@ bool small_eligible(const oeh_attn_desc* d, const void* q, const void* k, const 
   if (any_fq(fq) || d->key_pad_mask != nullptr || d->full_mask != nullptr || d->causal) return false;
   if (d->gate == nullptr && d->gate_hidden != nullptr) return false;
   if (!(d->D == 16 || d->D == 32 || d->D == 64) || d->Sk > 64 || d->Sq > 64) return false;
-  // A wave per problem only pays when there are enough problems to fill the chip and on fp32 data, where it also is the EXACT path
-  // (fp32 matrix-core products: 3e-6 of the reference; the operand-pair kernels round the probability operand to fp16) - measured,
-  // round 3 (B*H = 768..896, d = 64): fp32 S = 28 9.3 us against 10.3 in the one-pass kernel (S = 64: 20.3 against 13.5, kept here for
-  // the accuracy); 16-bit data: S = 28 8.3 against 8.05 in the full-row kernel, S = 48 18.6 against 6.6, S = 64 19.9 against 7.1 - so
-  // 16-bit problems take the matrix-core kernels - or when no matrix-core kernel takes the shape (d = 16)
-  if (!g_force_small && d->D != 16 && (d->dtype != OEH_F32 || (long)d->B * d->H < 256)) return false;
+  // A wave per problem only pays when there are enough problems to fill the chip, on fp32 data - where it also is the EXACT path (fp32
+  // matrix-core products: 3e-6 of the reference; the operand-pair kernels round the probability operand to fp16) - and on rows of at
+  // most 32 keys: measured, round 3 (d = 64, against the full-row kernel's fp32 form): B*H = 896 S = 28 9.4 vs 8.9 us (kept here: STanHop's
+  // shape, the exact path), B*H = 1536 S = 32 13.3 vs 13.7, but S = 48 29.8 vs 20.2 and S = 64 37.0 vs 22.7; 16-bit data: S = 28 8.3 vs 8.05
+  // in the full-row kernel, S = 48 18.6 vs 6.6, S = 64 19.9 vs 7.1 - or when no matrix-core kernel takes the shape (d = 16)
+  if (!g_force_small && d->D != 16 && (d->dtype != OEH_F32 || d->Sk > 32 || d->Sq > 32 || (long)d->B * d->H < 256)) return false;
   const int ab = 4 * elem_bytes(d->dtype);
   const int64_t* sts[4] = {d->q_stride, d->k_stride, d->v_stride, d->o_stride};
   const void* ps[4] = {q, k, v, o};

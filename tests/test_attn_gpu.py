@@ -942,7 +942,7 @@ def test_small_shape_kernel_stanhop(ops, dtype):
     # what the library picks by itself (round 3, measured): the small-shape kernel for fp32 problems (exact fp32 products) when there
     # are enough of them to fill the chip, and for d = 16; 16-bit problems take the full-row kernel (S = 64: 7.1 us against 19.9)
     assert ops.attn_variant(224, 4, 28, 28, 64, torch.float32).startswith("small/") and ops.attn_variant(64, 4, 10, 28, 16, torch.float16).startswith("small/")
-    assert ops.attn_variant(224, 4, 28, 28, 64, torch.float16).startswith("fast16/") and ops.attn_variant(80, 4, 64, 64, 64, torch.float32).startswith("small/")
+    assert ops.attn_variant(224, 4, 28, 28, 64, torch.float16).startswith("fast16/") and ops.attn_variant(80, 4, 64, 64, 64, torch.float32).startswith("fast16/")
     from outeffhop_amd import _lib
     forced = _lib.load().oeh_debug_set_variant(1 << 10, 0) == 0  # the kernel under test wherever it can run (hooks off: the library's own picks)
     try:
@@ -963,7 +963,8 @@ def _small_shape_cases(ops, dtype, tol, modes, n, forced):
             want = O.attn_core(_np32(qv), _np32(kv), _np32(vv), scale=scale, gate=None if gate is None else gate.numpy(), **SPECS[sm])
             got = ops.attn_fwd(qv.cuda(), kv.cuda(), vv.cuda(), softmax=_spec(ops, sm), scale=scale, gate=None if gate is None else gate.cuda())
             assert got.dtype == dtype and got.permute(0, 2, 1, 3).is_contiguous()
-            _check(got, want, tol, msg=f"{(B, L, S, H, E)} {sm} {dtype}")
+            exact = forced or dtype != torch.float32 or ops.attn_variant(B, H, L, S, E, dtype, clip="clipped" in sm).startswith("small/")
+            _check(got, want, tol if exact else dict(atol=5e-4, rtol=5e-4), msg=f"{(B, L, S, H, E)} {sm} {dtype}")  # (not this kernel: fp16 probability operand)
     # BERT-order division and a single problem with D = 16 (no other matrix-core kernel takes D = 16)
     q, k, v = _rand((2, 3, 20, 16), 1, dtype=dtype), _rand((2, 3, 40, 16), 2, dtype=dtype), _rand((2, 3, 40, 16), 3, dtype=dtype)
     want = O.attn_core(_np32(q), _np32(k), _np32(v), scale=4.0, scale_is_divisor=True, **SPECS["softmax1"])
