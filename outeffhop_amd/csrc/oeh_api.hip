@@ -207,7 +207,9 @@ bool flash32_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
   if (!flash_eligible(&t, fq, true)) return false;
   // rows of <= 128 keys: the full-row kernel's fp32 form where it applies, at every batch size measured (round 3, H=12 S=128: B=32 16.5
   // vs 20.0 us, B=64 29.8 vs 30.6, B=128 54.6 vs 57.7); what it does not take stays here (16.7 us in the general kernel)
-  if (d->Sk <= 128 && !g_force_flash && d->full_mask == nullptr && fast_eligible(&t, fq)) return false;
+  // (without a padding vector and with >= 768 of its 128-row workgroups the one-pass form is ahead again: B=64 25.5 vs 28.6 us; with padding a tie)
+  const bool many_unpadded = d->key_pad_mask == nullptr && d->Sq >= 112 && d->Sk > 64 && (long)d->B * d->H * ((d->Sq + 127) / 128) >= 768;
+  if (d->Sk <= 128 && !g_force_flash && d->full_mask == nullptr && !many_unpadded && fast_eligible(&t, fq)) return false;
   // ... and causal rows that leave the last 128-row workgroup at most half full, up to 320 rows (S = 192: 33.1 vs 40.3 us, S = 320: 38.4 vs
   // 39.0; S = 448: 42.9 vs 42.2 - the one-pass kernel again)
   if (d->causal && d->Sk <= 384 && d->Sq > 128 && ((d->Sq - 1) % 128) < 64 && !g_force_flash && d->full_mask == nullptr && fast_eligible(&t, fq)) return false;
