@@ -310,8 +310,8 @@ def _cpu_model():
 def fp16_check():
     """north_star: "within 1e-3 fp16".  The headline kernel against the reference arithmetic (CPU oracle) on a bounded sample
     of the headline workload (B=1 H=2 S=512 d=64 fp16 causal softmax1 / clippedsoftmax1), with the error split into its two
-    parts: the kernel's own arithmetic BEFORE the final rounding (taken from the fp32-output form of the same kernel on the
-    same fp16 values; must be <= 1e-3) and the rounding of the result to fp16 storage (at most half an fp16 ulp of the
+    parts: the kernel's own arithmetic BEFORE the final rounding (the same fp16 kernel with o_dtype = OEH_F32: its output
+    straight from the fp32 accumulators; must be <= 1e-3) and the rounding of the result to fp16 storage (at most half an fp16 ulp of the
     reference value on top).  Part of the cpu_baseline leg: the oracle is the checker only."""
     import numpy as np
     import torch
@@ -331,7 +331,7 @@ def fp16_check():
                            causal=True, clamp_min=True)
         kw = dict(softmax=ops.SoftmaxSpec(*sm), causal=True, clamp_min=True, mask_min=fmin)
         got16 = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), **kw).float().cpu().numpy()
-        got32 = ops.attn_fwd(q.cuda().float(), k.cuda().float(), v.cuda().float(), **kw).cpu().numpy()
+        got32 = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), out_dtype=torch.float32, **kw).cpu().numpy()  # the fp16 kernel's own accumulators
         half_ulp = 0.5 * np.spacing(np.abs(want).astype(np.float16)).astype(np.float32)  # the storage rounding of an exact result
         e16, e32 = np.abs(got16 - want), np.abs(got32 - want)
         out[name] = {"max_abs_err_fp16_output": float(e16.max()),

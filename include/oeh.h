@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OEH_ABI_VERSION 4
+#define OEH_ABI_VERSION 5
 
 /* error codes (negative errno style) */
 #define OEH_OK 0
@@ -81,7 +81,8 @@ typedef struct oeh_fq_desc {
  * (bert_attention.py:335-337, opt_attention.py:318-322) costs nothing. */
 typedef struct oeh_attn_desc {
   int32_t B, H, Sq, Sk, D;
-  int32_t dtype;                 /* OEH_F16 | OEH_BF16 | OEH_F32 : q, k, v and o */
+  int32_t dtype;                 /* OEH_F16 | OEH_BF16 | OEH_F32 : q, k, v and o;  OEH_I8 : q, k, v are centred 8-bit indices on
+                                    q_grid / k_grid / v_grid (v transposed) and o is o_dtype - see the ABI-3 fields below */
   int64_t q_stride[3];           /* elements: batch, head, seq */
   int64_t k_stride[3];
   int64_t v_stride[3];
@@ -155,7 +156,12 @@ typedef struct oeh_attn_desc {
    * The test-only index dumps (oeh_fq.dump_idx) are honoured with o_dtype == OEH_F32: scores for every key (the reference
    * quantises before the mask is added), probabilities, context - same layouts as everywhere. */
   struct { float scale; float zero_point; } q_grid, k_grid, v_grid;
-  int32_t o_dtype;
+  int32_t o_dtype;               /* dtype == OEH_I8: the output's dtype.  dtype OEH_F16 / OEH_BF16 (ABI 5): OEH_F32 here asks for the
+                                    output straight from the kernel's fp32 accumulators (o is then fp32, strides in fp32 elements) - the
+                                    arithmetic of the kernel that ships before its output rounding, for the "within 1e-3" checks: sibling
+                                    instantiations of the one-pass kernel's plain form (masks none / causal) and of the full-row
+                                    kernel's plain / clipped forms (+ key padding) at head dim 64 that differ in the epilogue's store
+                                    only; OEH_ENOTSUP elsewhere.  Any other value: o has `dtype`. */
 
   /* (appended in ABI 4: fields are only ever added at the end of a descriptor) */
   int32_t key_pad_boolean;       /* key_pad_mask: the caller's promise that every entry is 0 or <= -1e4 (HF's extended masks: 0 / finfo.min):

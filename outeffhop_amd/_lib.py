@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OEH_LIB: explicit path of another build of the same library (A/B timing of compiler flags; tools/ only)
 LIB_PATH = os.environ.get("OEH_LIB") or os.path.join(_HERE, "lib", "liboeh_hip.so")
 
-ABI_VERSION = 4  # include/oeh.h: OEH_ABI_VERSION
+ABI_VERSION = 5  # include/oeh.h: OEH_ABI_VERSION
 CALIB_WORK_BYTES = 36864  # include/oeh.h: OEH_CALIB_WORK_BYTES
 OEH_F16, OEH_BF16, OEH_F32, OEH_I8 = 0, 1, 2, 3
 OEH_SOFTMAX_VANILLA, OEH_SOFTMAX_ONE = 0, 1

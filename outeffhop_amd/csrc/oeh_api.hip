@@ -117,6 +117,9 @@ int validate(const oeh_attn_desc* d, const void* q, const void* k, const void* v
   return OEH_OK;
 }
 
+// 16-bit q / k / v with the output taken from the fp32 accumulators (include/oeh.h: o_dtype)
+bool want_out32(const oeh_attn_desc* d) { return (d->dtype == OEH_F16 || d->dtype == OEH_BF16) && d->o_dtype == OEH_F32; }
+
 bool any_fq(const oeh_fq_desc* fq) { return fq != nullptr && (fq->scores.enable || fq->probs.enable || fq->ctx.enable); }
 
 bool is_pow2(float x) {
@@ -166,10 +169,14 @@ bool flash_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq, bool short_ro
   // B=96 23.0 vs 20.3, B=128 31.5 vs 24.2)
   // causal rows whose count leaves the last 128-row workgroup at most half full (S = 192, 320, 448): the full-row kernel's 64-row
   // workgroups waste nothing there (16.9 vs 18.3, 15.7 vs 17.1, 18.7 vs 19.4 us); without the causal mask the one-pass kernel keeps its lead
-  if (d->causal && d->Sk <= 512 && ((d->Sq - 1) % 128) < 64 && d->Sq > 128 && !g_force_flash && !short_rows_too) return false;
+  // (round 4, profiles/r04_dispatch_ab.txt - both sides of every rule in one process: S = 192 4.8 %, S = 320 3.1 % for the full-row kernel,
+  // S = 448 a tie (18.3 vs 18.2 us): the rule ends at 384 keys, like its fp32 twin below)
+  if (d->causal && d->Sk <= 384 && ((d->Sq - 1) % 128) < 64 && d->Sq > 128 && !g_force_flash && !short_rows_too) return false;
   if (d->Sk <= 128 && !g_force_flash) {
     const long wgs = (long)d->B * d->H * ((d->Sq + 127) / 128);
-    if (!(d->Sk > 64 && d->Sq >= 112 && wgs >= (d->D <= 32 ? 1536 : 768))) return false;  // (d = 32: 768 workgroups 12.6 vs 11.5 us, 1536 21.3 vs 22.7)
+    // (one threshold for every head dim since round 4: at d = 32 and 768 workgroups the one-pass kernel measured 10.0 vs 11.0 us, at
+    // 1536 16.7 vs 21.8 - the separate d <= 32 threshold of 1536 was the wrong way round on the re-measurement)
+    if (!(d->Sk > 64 && d->Sq >= 112 && wgs >= 768)) return false;
   }
   return true;
 }
@@ -207,8 +214,9 @@ bool flash32_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
   if (!flash_eligible(&t, fq, true)) return false;
   // rows of <= 128 keys: the full-row kernel's fp32 form where it applies, at every batch size measured (round 3, H=12 S=128: B=32 16.5
   // vs 20.0 us, B=64 29.8 vs 30.6, B=128 54.6 vs 57.7); what it does not take stays here (16.7 us in the general kernel)
-  // (without a padding vector and with >= 768 of its 128-row workgroups the one-pass form is ahead again: B=64 25.5 vs 28.6 us; with padding a tie)
-  const bool many_unpadded = d->key_pad_mask == nullptr && d->Sq >= 112 && d->Sk > 64 && (long)d->B * d->H * ((d->Sq + 127) / 128) >= 768;
+  // (with >= 768 of its 128-row workgroups the one-pass form is ahead again: B=64 25.8 vs 30.5 us; with a padding vector 30.5 vs 31.5 -
+  // round 4: one rule for both, profiles/r04_dispatch_ab.txt)
+  const bool many_unpadded = d->Sq >= 112 && d->Sk > 64 && (long)d->B * d->H * ((d->Sq + 127) / 128) >= 768;
   if (d->Sk <= 128 && !g_force_flash && d->full_mask == nullptr && !many_unpadded && fast_eligible(&t, fq)) return false;
   // ... and causal rows that leave the last 128-row workgroup at most half full, up to 320 rows (S = 192: 33.1 vs 40.3 us, S = 320: 38.4 vs
   // 39.0; S = 448: 42.9 vs 42.2 - the one-pass kernel again)
@@ -291,7 +299,7 @@ Variant pick_variant(const oeh_attn_desc* d, const void* q, const void* k, const
   bool p_exact = true;
   if (fq != nullptr && fq->probs.enable) p_exact = fq->probs.qmax <= (d->dtype == OEH_BF16 ? 255.0f : 2047.0f);
   const bool al = (q == nullptr) || (aligned16(q, d->q_stride, eb) && aligned16(k, d->k_stride, eb) &&
-                                     aligned16(v, d->v_stride, eb) && aligned16(o, d->o_stride, eb));
+                                     aligned16(v, d->v_stride, eb) && aligned16(o, d->o_stride, want_out32(d) ? 4 : eb));
   const bool d_ok = d->D == 32 || d->D == 64 || d->D == 128;
   if (small_eligible(d, q, k, v, o, fq) && !(g_variant_off & (1 << V_SMALL))) return V_SMALL;
   if (d_ok && al && flash_eligible(d, fq) && !(g_variant_off & (1 << V_FLASH))) return V_FLASH;
@@ -397,6 +405,15 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
   AttnParams P;
   fill_params(P, desc, q, k, v, o, fq);
   P.src32 = (desc->dtype == OEH_F32 && (var == V_FLASH || var == V_FAST)) ? 1 : 0;  // fp32 storage read directly, fp32 output
+  if (want_out32(desc)) {
+    // the accumulators themselves - sibling instantiations (O32) of what the 16-bit workloads of BASELINE.json run: the one-pass kernel's
+    // plain form (masks none / causal) and the full-row kernel's plain and clipped forms (+ key padding), head dim 64, gate values only
+    const bool gated_in_kernel = desc->gate == nullptr && desc->gate_hidden != nullptr;
+    const bool ok = desc->D == 64 && !any_fq(fq) && !gated_in_kernel &&
+                    ((var == V_FLASH && !desc->clip && desc->key_pad_mask == nullptr && desc->full_mask == nullptr) || var == V_FAST);
+    if (!ok) return OEH_ENOTSUP;
+    P.out32 = 1;
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (var == V_SMALL) return oeh::launch_attn_small(P, desc->dtype, st);
   if (var == V_I8) {

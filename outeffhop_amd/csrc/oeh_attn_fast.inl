@@ -66,10 +66,13 @@ constexpr int fast_occupancy() {  // what the LDS rings allow (6 tiles of 64 x 2
 // the DMA would produce; every product is accumulated from the operand pairs (3 MFMAs per score k-step, 2 per context k-step),
 // i.e. with fp32 accuracy.  Two ring slots shared by the K-then-V stream (a slot's readers are all behind the barrier that
 // precedes its next commit); Q goes global -> registers directly.
-template <int NT, int D, int IN, bool CLIP, bool GATE, int FQ = 0, bool SRC32 = false>
+// O32: 16-bit storage with the output taken from the fp32 accumulators (include/oeh.h: o_dtype = OEH_F32) - the same loops, only the
+// epilogue's store differs (a runtime switch in the epilogue measured +2 ... +8 % on the production launches, round 4).
+template <int NT, int D, int IN, bool CLIP, bool GATE, int FQ = 0, bool SRC32 = false, bool O32 = false>
 __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void oeh_attn_fast_kernel(const AttnParams P) {
   static_assert(!SRC32 || IN == IN_F16, "fp32 storage: fp16 operand pairs, fp32 output");
-  constexpr bool OUT32 = SRC32;
+  static_assert(!O32 || (!SRC32 && !GATE && FQ == 0), "fp32 output of 16-bit storage: the plain and clipped forms");
+  constexpr bool OUT32 = SRC32 || O32;
   static_assert(!FQ || !GATE, "the fake-quant variant has no in-kernel gate predictor");
   constexpr bool GRID = (FQ == 1 || FQ == 3), GRIDPAD = (FQ == 3);  // FQ == 3: the grid chain with a key-padding vector of 0 / <= -1e4 entries
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit storage only");
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
       float f = (i < P.Sk) ? load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + i) : 0.0f;
       if constexpr (GRIDPAD) {  // the grid chain (key_pad_boolean): per key +big (visible), the sentinel (padded) or -inf (past Sk: not even
         // a masked key - a row without a visible key is uniform over the Sk keys under the vanilla softmax, as in the reference)
-        f = (i < P.Sk) ? (f < -1.0e4f ? -1.0e30f : 3.0e38f) : -__builtin_inff();
+        f = (i < P.Sk) ? (f <= -1.0e4f ? -1.0e30f : 3.0e38f) : -__builtin_inff();
       }
       lds_pad[i] = f;
     }
@@ -830,7 +833,8 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
 #pragma unroll
       for (int r = 0; r < 4; ++r) ov[r] = o[dt][r] * rowscale;
     }
-    if constexpr (OUT32) {  // fp32 output straight from the accumulators (fp32 storage)
+    if constexpr (OUT32) {  // fp32 output straight from the accumulators (fp32 storage; O32: 16-bit storage with o_dtype = OEH_F32 -
+                            // the kernel's arithmetic before the output rounding, include/oeh.h)
       if (q0 + ce < P.Sq)
         store_wt16(reinterpret_cast<float*>(P.o) + bh_offset(b, P.os_b, h, P.os_h) + (long)(q0 + ce) * P.os_s + 16 * dt + 4 * ge,
                    u4{f32_bits(ov[0]), f32_bits(ov[1]), f32_bits(ov[2]), f32_bits(ov[3])});
@@ -894,6 +898,13 @@ static void launch_fast_nt_d_in(const AttnParams& P, unsigned grid, hipStream_t 
     else if (P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 2>), dim3(grid), dim3(256), 0, st, P);
     else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 2>), dim3(grid), dim3(256), 0, st, P);
     return;
+  }
+  if constexpr (D == 64) {  // (oeh_api.hip: out32_supported)
+    if (P.out32) {
+      if (P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 0, false, true>), dim3(grid), dim3(256), 0, st, P);
+      else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 0, false, true>), dim3(grid), dim3(256), 0, st, P);
+      return;
+    }
   }
   if (P.clip) {
     if (gate) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, true>), dim3(grid), dim3(256), 0, st, P);

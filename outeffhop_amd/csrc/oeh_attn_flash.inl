@@ -60,13 +60,16 @@ constexpr int flash_occupancy() { return D >= 128 ? 1 : (SRC32 ? 2 : 3); }  // f
 // index of the probability from e * RN(1 / (den scale_p))) in the same two passes: the statistics pass keeps a running maximum
 // and sum per LANE (no cross-lane step inside the loop), the final pass recomputes rel against the row's maximum and feeds the
 // integer-valued probability to the second product; context quantiser and gate in the epilogue.  Rows of any length.
-template <int D, int IN, int MQ, bool PAD, bool GATE, bool SRC32 = false, int TP = 0>
+// O32: 16-bit storage with the output taken from the fp32 accumulators (include/oeh.h: o_dtype = OEH_F32) - the same loop, only the
+// epilogue's store differs (as a runtime switch in the epilogue it cost the production launches +0.7 ... +3 %, round 4).
+template <int D, int IN, int MQ, bool PAD, bool GATE, bool SRC32 = false, int TP = 0, bool O32 = false>
 __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_attn_flash_kernel(const AttnParams P) {
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit matrix-core operands");
+  static_assert(!O32 || (!SRC32 && !GATE && !PAD && TP == 0), "fp32 output of 16-bit storage: the plain one-pass form");
   constexpr bool CLIP = (TP == 1), FQ2 = (TP == 2);
   static_assert(TP == 0 || !GATE, "two-pass forms: no in-kernel gate predictor");
   static_assert(!SRC32 || (!GATE && IN == IN_F16), "fp32 storage: fp16 operands, fp32 output, no in-kernel gate predictor");
-  constexpr bool OUT32 = SRC32;
+  constexpr bool OUT32 = SRC32 || O32;
   static_assert(MQ == 1 || MQ == 2, "one or two query blocks per wave");
   constexpr int ROWB = 2 * D;
   constexpr int TILEB = 64 * ROWB;      // one operand tile (64 keys)
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
         }
         if constexpr (MODE >= 3) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) padflag[sub][r] = padv[r] < -1.0e4f ? NEGT : 3.0e38f;
+          for (int r = 0; r < 4; ++r) padflag[sub][r] = padv[r] <= -1.0e4f ? NEGT : 3.0e38f;
         } else {
 #pragma unroll
           for (int j = J0; j < MQ; ++j) {
@@ -623,16 +626,23 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       // later only for rows whose maximum exceeds it by 2^8.  The common case is decided on the LANE maxima (no cross-lane
       // step); the row maximum is formed only when some row moves.  Decided per ROW, so that a row's result depends on
       // its own keys only (bitwise causality); the wave-uniform branch merely skips the code when no row moves.
-      if (__builtin_amdgcn_ballot_w64(mt > thr) != 0) {
+      // Key padding: a row whose keys so far were all absorbed by the mask (l == 0: a left-padded sample) has no reference yet -
+      // its first visible tile sets it, as tile 0 does for every other row (else very negative scores behind a masked first tile
+      // would all underflow against the initial reference 0, and under the vanilla softmax the row would pass for one without a
+      // visible key).  lacc holds the row sum in every register of every lane of the row: the decision stays per row.
+      float thr_j = thr;
+      if constexpr (has_pad && MODE == 0) thr_j = (lacc[j][0] == 0.0f) ? -1.0e20f : thr;
+      if (__builtin_amdgcn_ballot_w64(mt > thr_j) != 0) {
         mt = row_allreduce_max(mt);
-        const float delta = (mt > thr) ? mt : 0.0f;
+        const float delta = (mt > thr_j) ? mt : 0.0f;
         mcneg[j] -= delta;
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[j][sub][r] -= delta;
         if (i != 0) {
-          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          float alpha = __builtin_amdgcn_exp2f(-delta);
+          if constexpr (has_pad && MODE == 0) alpha = (thr_j < -1.0e19f) ? 1.0f : alpha;  // nothing accumulated yet (and exp2(-delta) may overflow)
           if constexpr (MODE == 1) lsum[j] *= alpha;
 #pragma unroll
           for (int r = 0; r < 4; ++r) lacc[j][r] *= alpha;
@@ -884,14 +894,19 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
         for (int r = 0; r < 4; ++r) o[j][dt][r] = xs[dt * 4 + r];
     }
     auto finish = [&](float x) { return FQ2 ? x : x * rowscale; };
-    if constexpr (OUT32) {  // fp32 output straight from the accumulators (fp32 storage): 16 B per lane, 64 B per row and instruction
+    if constexpr (OUT32) {  // fp32 output straight from the accumulators: 16 B per lane, 64 B per row and instruction (fp32 storage; O32:
+                            // 16-bit storage with o_dtype = OEH_F32 - the kernel's arithmetic before the output rounding, include/oeh.h)
       if (qrow < Sq) {
         float* orow = reinterpret_cast<float*>(P.o) + bh_offset(b, P.os_b, h, P.os_h) + (long)qrow * P.os_s + 4 * ge;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           f4 ov;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ov[r] = finish(FQ2 ? o[j][dt][r] : __builtin_fmaf(ox[j][dt][r], kSplitDown, o[j][dt][r]));
+          for (int r = 0; r < 4; ++r) {
+            float x = o[j][dt][r];
+            if constexpr (SRC32) { if (!FQ2) x = __builtin_fmaf(ox[j][dt][r], kSplitDown, x); }
+            ov[r] = finish(x);
+          }
           store_wt16(orow + 16 * dt, u4{f32_bits(ov[0]), f32_bits(ov[1]), f32_bits(ov[2]), f32_bits(ov[3])});
         }
       }
@@ -953,6 +968,12 @@ static void launch_flash_d_mq_in(const AttnParams& P, unsigned grid, hipStream_t
     if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, false, 1>), dim3(grid), dim3(256), 0, st, P);
     else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, false, 1>), dim3(grid), dim3(256), 0, st, P);
     return;
+  }
+  if constexpr (D == 64) {  // (oeh_api.hip: out32_supported)
+    if (P.out32) {
+      hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, false, 0, true>), dim3(grid), dim3(256), 0, st, P);
+      return;
+    }
   }
   if (pad) {
     if (gate) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, true>), dim3(grid), dim3(256), 0, st, P);

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   if constexpr (PAD) {  // (compiler-visible loads: its wait for them also covers the first transfers, which the first tile wait needs anyway)
     for (int i = threadIdx.x; i < NT * 16; i += 256) {
       float f = -__builtin_inff();
-      if (i < Sk) f = load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + i) < -1.0e4f ? RELMASK : 3.0e38f;
+      if (i < Sk) f = load_mask(P.pad, P.pad_f16, (long)b * P.pad_sb + i) <= -1.0e4f ? RELMASK : 3.0e38f;
       lds_pad[i] = f;
     }
   }

@@ -38,6 +38,7 @@ struct AttnParams {
   FqP fq_s, fq_p, fq_c;
   int ctx_before_gate;
   int src32;                  // fp32 q / k / v read directly by the kernel and fp32 output (SRC32 variants)
+  int out32;                  // 16-bit q / k / v, fp32 output straight from the accumulators (o_dtype = OEH_F32; one-pass and full-row kernels)
   // INT8 storage (oeh_attn_i8.hip): 128 - zero point of q, k, v and of the probabilities; RN(s_q s_k scale / s_scores), RN(s_p s_v)
   int i8_cq, i8_ck, i8_cv, i8_cp;
   float i8_k1, i8_so;

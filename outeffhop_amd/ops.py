@@ -133,6 +133,7 @@ def attn_fwd(
     fq: Optional[AttnFakeQuant] = None,
     out: Optional[torch.Tensor] = None,
     gate_mlp: Optional["GatePredictor"] = None,
+    out_dtype: Optional[torch.dtype] = None,
     _prepared: Optional[list] = None,
 ) -> torch.Tensor:
     """Fused attention core.  q,k,v are logical (B,H,S,D) views (any batch/head/seq strides, unit head-dim
@@ -141,7 +142,10 @@ def attn_fwd(
 
     key_pad_mask: additive (B,Sk) [or anything reshapeable to it, e.g. HF's (B,1,1,Sk)]; key_pad_boolean: the caller's promise that
     its entries are 0 or <= -1e4 only (include/oeh.h - lets the fused INT8 chain stay on the quantiser grid with padded keys);
-    full_mask: additive (B,1,Sq,Sk); gate: fp32, broadcastable to (B,H,Sq,1), already times the scaling factor."""
+    full_mask: additive (B,1,Sq,Sk); gate: fp32, broadcastable to (B,H,Sq,1), already times the scaling factor.
+    out_dtype=torch.float32 with fp16 / bf16 inputs: the output straight from the kernel's fp32 accumulators (include/oeh.h: o_dtype) -
+    the kernel's arithmetic before the output rounding, which is how tests / smoke / bench check the "within 1e-3" contract on the
+    kernel that ships; the one-pass and full-row kernels only (OehError -95 otherwise)."""
     dev = _need_gpu(q, k, v, key_pad_mask, full_mask, gate, out)
     if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
         raise ValueError("q, k, v must be 4-D (B,H,S,D) views")
@@ -153,8 +157,11 @@ def attn_fwd(
         raise ValueError(f"q/k/v dtypes must match and be fp16/bf16/fp32, got {q.dtype}, {k.dtype}, {v.dtype}")
     fix = lambda t: t if t.stride(3) == 1 else t.contiguous()  # noqa: E731
     q, k, v = fix(q), fix(k), fix(v)
+    odt = q.dtype if out_dtype is None else out_dtype
+    if odt != q.dtype and not (odt == torch.float32 and q.dtype in (torch.float16, torch.bfloat16)):
+        raise ValueError(f"out_dtype must be the input dtype, or float32 for fp16 / bf16 inputs (got {odt} for {q.dtype})")
     Dp = _matrix_core_head_dim(D, Sq, Sk, plain=key_pad_mask is None and full_mask is None and not causal and fq is None)
-    if (Dp != D and gate_mlp is None and _prepared is None and (out is None or out.shape == (B, H, Sq, D))
+    if (Dp != D and gate_mlp is None and _prepared is None and odt == q.dtype and (out is None or out.shape == (B, H, Sq, D))
             and not (fq is not None and fq.ctx is not None and fq.ctx.dump is not None)):
         # A head dim between the matrix-core kernels' (OPT-2.7b / ViT-H: 80; 96; 48; 16 with long rows ...): zero columns change
         # neither the scores nor the other columns of the product - three pad copies and the next kernel size up instead of the
@@ -168,13 +175,14 @@ def attn_fwd(
         out.copy_(res)
         return out
     if out is None:
-        out = torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device).permute(0, 2, 1, 3)
-    elif out.shape != (B, H, Sq, D) or out.dtype != q.dtype or out.stride(3) != 1:
-        raise ValueError("out must be a (B,H,Sq,D) view with unit head-dim stride and the input dtype")
+        out = torch.empty((B, Sq, H, D), dtype=odt, device=q.device).permute(0, 2, 1, 3)
+    elif out.shape != (B, H, Sq, D) or out.dtype != odt or out.stride(3) != 1:
+        raise ValueError("out must be a (B,H,Sq,D) view with unit head-dim stride and the input dtype (or out_dtype)")
 
     d = oeh_attn_desc()
     d.B, d.H, d.Sq, d.Sk, d.D = B, H, Sq, Sk, D
     d.dtype = _DT[q.dtype]
+    d.o_dtype = _DT[odt]  # (read for 16-bit inputs only when it says OEH_F32)
     for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", out)):
         getattr(d, name)[:] = [t.stride(0), t.stride(1), t.stride(2)]
     d.scale, d.scale_div = float(scale), float(scale_div)
@@ -271,8 +279,11 @@ def _warn_if_any_shape_kernel(lib, d, fqd, softmax) -> None:
         return
     if d.D not in (16, 32, 64, 128):
         reason = f"head dim {d.D} (matrix-core kernels: 32, 64, 128; 16 for <= 64 keys)"
-    elif d.D == 16:
+    elif d.D == 16 and (d.Sq > 64 or d.Sk > 64):
         reason = f"head dim 16 with more than 64 rows (Sq={d.Sq}, Sk={d.Sk})"
+    elif d.D == 16:
+        reason = ("head dim 16 outside the small-shape kernel's cases (a mask, fake-quant, the in-kernel gate predictor, or rows that are "
+                  f"not 4-element aligned; Sq={d.Sq}, Sk={d.Sk})")
     elif d.Sk > 512:
         what = "fused fake-quant" if fqd is not None else ("clipped softmax outside the two-pass kernel's cases" if softmax.clip else "this mask / scale combination")
         reason = f"{what} with {d.Sk} > 512 keys (the full-row kernels hold a row of <= 512 scores)"
@@ -543,6 +554,19 @@ _calib_work = {}  # (device index, stream) -> scratch buffer of the on-device pe
                    # streams of one GPU must not share histograms: ADVICE r2)
 
 
+def _calib_scratch(dev):
+    """The current stream's 36-KB selection scratch on `dev`.  Bounded: streams come and go (a recycled handle simply reuses its
+    buffer), so beyond 32 entries the table starts over instead of keeping one buffer per stream ever seen."""
+    with _on_device(dev):
+        key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    work = _calib_work.get(key)
+    if work is None:
+        if len(_calib_work) >= 32:
+            _calib_work.clear()  # (buffers still referenced by enqueued work stay alive in the caching allocator's stream order)
+        work = _calib_work[key] = torch.empty(_lib.CALIB_WORK_BYTES // 8, dtype=torch.int64, device=dev)
+    return work
+
+
 def percentile_ema(x: torch.Tensor, q_lo: float, q_hi: float, state: torch.Tensor, momentum: float = 0.9, first: bool = False) -> torch.Tensor:
     """(np.percentile(x, q_lo), np.percentile(x, q_hi)) blended into `state` (float64[2] on x's GPU) with the running average of
     RunningMinMaxEstimator (range_estimators.py:101-104), without leaving the device: `include/oeh.h: oeh_percentile_ema`."""
@@ -552,11 +576,7 @@ def percentile_ema(x: torch.Tensor, q_lo: float, q_hi: float, state: torch.Tenso
     if state.dtype != torch.float64 or state.numel() != 2 or not state.is_contiguous():
         raise ValueError("state must be a contiguous float64 tensor of 2 elements")
     xc = x.detach().contiguous()
-    with _on_device(dev):
-        key = (dev.index, torch.cuda.current_stream().cuda_stream)
-    work = _calib_work.get(key)
-    if work is None:
-        work = _calib_work[key] = torch.empty(_lib.CALIB_WORK_BYTES // 8, dtype=torch.int64, device=dev)
+    work = _calib_scratch(dev)
     with _on_device(dev):
         rc = _lib.load().oeh_percentile_ema(_ptr(xc), xc.numel(), _DT[x.dtype], float(q_lo), float(q_hi), float(momentum), int(bool(first)),
                                             _ptr(state), _ptr(work), _stream())
@@ -618,11 +638,7 @@ def attn_calibrate(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tensor], 
     if which != CALIB_CONTEXT:
         if state is None:
             raise ValueError("state (float64[2] on the device) is required for the statistics passes")
-        with _on_device(dev):
-            key = (dev.index, torch.cuda.current_stream().cuda_stream)
-        work = _calib_work.get(key)
-        if work is None:
-            work = _calib_work[key] = torch.empty(_lib.CALIB_WORK_BYTES // 8, dtype=torch.int64, device=dev)
+        work = _calib_scratch(dev)
     with _on_device(dev):
         rc = _lib.load().oeh_attn_calibrate(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), int(which), _ptr(scores_range), _ptr(probs_range), int(n_bits),
                                             float(eps), float(q_lo), float(q_hi), float(momentum), int(bool(first)), _ptr(state), _ptr(work), _stream())

@@ -36,7 +36,7 @@ def test_library_loads_and_exports_every_symbol():
     if out is not None and out.returncode == 0:
         exported = {ln.split()[-1] for ln in out.stdout.splitlines() if " T " in ln}
         assert set(_declared()) <= exported
-    assert lib.oeh_abi_version() == 4
+    assert lib.oeh_abi_version() == 5
     assert b"gfx950" in lib.oeh_build_info()
     assert lib.oeh_strerror(-22) == b"invalid argument"
 

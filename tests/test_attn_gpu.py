@@ -989,11 +989,15 @@ def _check_fp16_contract(got, want, msg):
 
 
 def _check_arithmetic_1e3(ops, q, k, v, want, msg, **kw):
-    """The same fp16 VALUES through the fp32-storage form of the kernel (fp32 output straight from the accumulators): what
-    the kernel computes before the output is rounded to fp16 must be within 1e-3 of the reference, everywhere."""
-    got = ops.attn_fwd(q.float(), k.float(), v.float(), **kw)
+    """The fp16 kernel that SHIPS, with its output taken from the fp32 accumulators (`out_dtype=torch.float32`, include/oeh.h:
+    o_dtype - the same instantiation, the same instruction stream up to the epilogue's store): what it computes before the output is
+    rounded to fp16 must be within 1e-3 of the reference, everywhere.  (Rounds 1-3 measured this through the fp32-STORAGE
+    instantiation on the same values - a proxy; VERDICT r3 weak #1.)  The stored fp16 output must be that value rounded once."""
+    got = ops.attn_fwd(q, k, v, out_dtype=torch.float32, **kw)
     err = float(np.abs(_np32(got) - want).max())
     assert err <= 1e-3, f"{msg}: arithmetic error {err:.3e} > 1e-3"
+    stored = ops.attn_fwd(q, k, v, **kw)
+    assert torch.equal(stored, got.to(q.dtype)), f"{msg}: the stored output is not the accumulator rounded once"
     return err
 
 
@@ -1730,3 +1734,236 @@ def test_clipped_int8_chain_on_the_quantiser_grid(ops, S, dt, pad):
     err = np.abs(_np32(got) - want)
     off = float((err > 0.5 * step).mean())
     assert np.isfinite(_np32(got)).all() and off < 4e-3 and err.max() <= 2.05 * step + 2e-3, f"{off:.2e} off, max {err.max() / step:.2f} steps"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 4
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["i8", "fast_fq3", "flash_fq2p"])
+def test_padding_masks_of_exactly_minus_1e4_hide_their_keys(ops, path):
+    """HF's classic extended mask `(1 - mask) * -10000.0` holds EXACTLY -1e4; include/oeh.h (key_pad_boolean) and
+    `attention.pad_is_boolean` call such an entry hidden (<= -1e4), and the three kernels that read the promise tested `< -1e4`:
+    the padded keys attended.  The integer core's PAD variant, the full-row kernel's grid form with padding (FQ == 3) and the one-pass
+    kernel's two-pass grid form with padding: a -1e4 mask must give bit for bit what a finfo.min mask gives (both mean "not there";
+    every row keeps a visible key), and both must agree with the oracle run with the -1e4 mask literally (the reference's op order)."""
+    B, H, D = 3, 2, 64
+    S = 640 if path == "flash_fq2p" else 208
+    fmin = float(np.finfo(np.float32).min)
+    lens = [S, S - 75, 19]
+    pad_hf = _pad_mask(B, S, lens, -10000.0)      # HF: (1 - mask) * -10000.0
+    pad_min = _pad_mask(B, S, lens, fmin)
+    assert (pad_hf[pad_hf != 0] == np.float32(-10000.0)).all()
+    FQ = ops.FakeQuantSpec.from_delta
+    dev = lambda t: torch.from_numpy(t).cuda()  # noqa: E731
+    if path == "i8":
+        g = torch.Generator().manual_seed(4101)
+        x = [torch.randn((B, S, H * D), generator=g).numpy() * s_ for s_ in (1.0, 1.2, 0.9)]
+        (qi, qd, qg), (ki, kd, kg), (vi, vd, vg) = (_quantise_to_grid(t) for t in x)
+        heads = lambda t: np.ascontiguousarray(t.reshape(B, S, H, D).transpose(0, 2, 1, 3))  # noqa: E731
+        qdh, kdh, vdh = heads(qd), heads(kd), heads(vd)
+        common = dict(base=1, scale=8.0, scale_is_divisor=True)
+    else:
+        q, k, v = _rand((B, H, S, D), 4102), _rand((B, H, S, D), 4103), _rand((B, H, S, D), 4104)
+        qdh, kdh, vdh = _np32(q), _np32(k), _np32(v)
+        common = dict(base=1, scale=8.0, scale_is_divisor=True)
+    ctx_fp, fp = O.attn_core(qdh, kdh, vdh, want=("scores", "probs"), **common)
+    d_s = O.quant_range_to_params(*np.percentile(fp["scores"], (0.001, 99.999)))
+    d_p = O.quant_range_to_params(*np.percentile(fp["probs"], (0.001, 99.999)))
+    d_c = O.quant_range_to_params(*np.percentile(ctx_fp, (0.001, 99.999)))
+    want = O.attn_core(qdh, kdh, vdh, fq_scores=d_s, fq_probs=d_p, fq_ctx=d_c, pad_mask=pad_hf, **common)
+    fq = ops.AttnFakeQuant(FQ(*d_s), FQ(*d_p), FQ(*d_c))
+    sm = ops.SoftmaxSpec(1, False, 0.0, 1.0)
+    if path == "i8":
+        qc = ops.centre_indices(dev(qi)).view(B, S, H, D).permute(0, 2, 1, 3)
+        kc = ops.centre_indices(dev(ki)).view(B, S, H, D).permute(0, 2, 1, 3)
+        vt = ops.centre_indices(dev(vi)).view(B, S, H, D).permute(0, 2, 3, 1).contiguous()
+        grids = (ops.QuantGrid(*qg), ops.QuantGrid(*kg), ops.QuantGrid(*vg))
+        run = lambda pm: ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, out_dtype=torch.float32, softmax=sm, scale_div=8.0, mask_min=fmin, key_pad_mask=dev(pm))  # noqa: E731
+    else:
+        name = ops.attn_variant(B, H, S, S, D, torch.float16, fq=True, key_pad=True, key_pad_boolean=True, scale_div=8.0, mask_min=fmin)
+        assert name.startswith("fast16/") if path == "fast_fq3" else (name.startswith("flash16/") and name.endswith("fq2p")), name
+        run = lambda pm: ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=sm, scale_div=8.0, mask_min=fmin, key_pad_mask=dev(pm), key_pad_boolean=True, fq=fq)  # noqa: E731
+    got_hf, got_min = run(pad_hf), run(pad_min)
+    assert torch.equal(got_hf, got_min), f"{path}: a -1e4 entry is read differently from a finfo.min entry ({float((got_hf.float() - got_min.float()).abs().max()):.3e})"
+    step = float(np.float32(d_c[0]))
+    err = np.abs(_np32(got_hf) - want)
+    off = float((err > 0.5 * step + 1e-3).mean())
+    assert err.max() <= 2.05 * step + 2e-3 and off < 4e-3, f"{path}: max {err.max() / step:.2f} steps, {off:.2e} off (padded keys attending?)"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S", [256, 640])
+def test_vanilla_softmax_with_non_absorbing_padding_and_very_negative_scores(ops, S):
+    """the one-pass kernel's PAD variant under the VANILLA softmax.  (a) A fully padded sample whose mask entries are
+    NOT absorbing (-1e4): every score is s - 1e4, the reference's probabilities are softmax(s), not uniform - the kernel must not
+    take the "no visible key: mean of V" shortcut.  (b) A left-padded sample (finfo.min: first tile absorbed) whose visible scores
+    are all below -100: against the initial reference 0 every exponential underflows; the first VISIBLE tile must set the row's
+    reference (the row used to pass for one without a visible key).  Against the oracle."""
+    B, H, D = 3, 2, 64
+    fmin = float(np.finfo(np.float32).min)
+    g = torch.Generator().manual_seed(4200 + S)
+    q = (1.5 + 0.05 * torch.randn((B, H, S, D), generator=g)).half()
+    k = (-1.5 + 0.05 * torch.randn((B, H, S, D), generator=g)).half()   # scores around -144
+    v = _rand((B, H, S, D), 4201)
+    padm = np.zeros((B, S), dtype=np.float32)
+    padm[0, :] = -10000.0          # (a) fully padded, non-absorbing
+    padm[1, :100] = fmin           # (b) left-padded: more than one 64-key tile absorbed
+    padm[2, S - 50:] = -10000.0    # right-padded, non-absorbing entries
+    assert ops.attn_variant(B, H, S, S, D, torch.float16, base=0, key_pad=True, mask_min=fmin).startswith("flash16/")
+    want = O.attn_core(_np32(q), _np32(k), _np32(v), base=0, pad_mask=padm, mask_min=fmin)
+    got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=ops.SoftmaxSpec(0), mask_min=fmin, key_pad_mask=torch.from_numpy(padm).cuda())
+    assert np.isfinite(_np32(got)).all()
+    _check(got, want, msg=f"vanilla + non-absorbing / left padding S={S}")
+    mean_v = _np32(v)[0].mean(axis=1, keepdims=True)
+    assert np.abs(want[0] - mean_v).max() > 1e-2   # (the case is not degenerate: the reference is NOT the mean of V there)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_fp32_output_of_the_16bit_kernels(ops, dt):
+    """VERDICT r3 next #4a: `out_dtype=torch.float32` (include/oeh.h: o_dtype = OEH_F32 with 16-bit q / k / v) stores the one-pass
+    and full-row kernels' fp32 accumulators - the arithmetic of the kernel that ships, before the output rounding.  The 16-bit
+    output of the same call must be exactly that value rounded once; kernels without the switch refuse (no silent fallback)."""
+    from outeffhop_amd._lib import OehError
+
+    B, H, D = 2, 3, 64
+    fmin = float(np.finfo(np.float32).min)
+    cases = [("flash16/", 512, dict(softmax=ops.SoftmaxSpec(1), causal=True, clamp_min=True, mask_min=fmin), dict(base=1, causal=True, clamp_min=True)),
+             ("fast16/", 256, dict(softmax=ops.SoftmaxSpec(1, True, -0.025, 1.1), causal=True, clamp_min=True, mask_min=fmin),
+              dict(base=1, clip=True, gamma=-0.025, eta=1.1, causal=True, clamp_min=True)),
+             ("fast16/", 128, dict(softmax=ops.SoftmaxSpec(1), scale_div=8.0, mask_min=fmin), dict(base=1, scale=8.0, scale_is_divisor=True))]
+    for prefix, S, kw, okw in cases:
+        q = (_rand((B, H, S, D), 4301 + S, dtype=torch.float32) * (D ** -0.5 if "scale_div" not in kw else 1.0)).to(dt)
+        k, v = _rand((B, H, S, D), 4302 + S, dtype=dt), _rand((B, H, S, D), 4303 + S, dtype=dt)
+        name = ops.attn_variant(B, H, S, S, D, dt, clip=kw["softmax"].clip, causal=kw.get("causal", False), scale_div=kw.get("scale_div", 0.0), mask_min=fmin)
+        assert name.startswith(prefix), name
+        acc = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), out_dtype=torch.float32, **kw)
+        out = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), **kw)
+        assert acc.dtype == torch.float32 and acc.permute(0, 2, 1, 3).is_contiguous()
+        assert torch.equal(out, acc.to(dt)), f"{name}: the stored output is not the accumulator rounded once"
+        want = O.attn_core(_np32(q), _np32(k), _np32(v), **okw)
+        err = float(np.abs(_np32(acc) - want).max())
+        assert err <= (1e-3 if dt == torch.float16 else 8e-3), f"{name}: arithmetic error {err:.3e}"
+    # a (B,1,Sq,Sk) mask on short rows runs the general kernel: no fp32-output form there
+    q, k, v = _rand((1, 2, 64, D), 1, dtype=dt).cuda(), _rand((1, 2, 64, D), 2, dtype=dt).cuda(), _rand((1, 2, 64, D), 3, dtype=dt).cuda()
+    with pytest.raises(OehError) as ei:
+        ops.attn_fwd(q, k, v, full_mask=torch.zeros(1, 1, 64, 64, device="cuda"), out_dtype=torch.float32)
+    assert ei.value.code == -95
+    with pytest.raises(ValueError):
+        ops.attn_fwd(q.float(), k.float(), v.float(), out_dtype=torch.float16)
+
+
+@pytest.mark.gpu
+def test_int8_storage_randomised_sweep_against_the_oracle(ops):
+    """VERDICT r3 weak #3 / next #4b: the ragged shapes of `test_int8_storage_randomised_sweep` (cross attention with a cache offset,
+    zero points at 0 and 255 - the CQ2 variant -, zero points on both sides of 128, context quantiser before / after the gate / off,
+    strided (B,S,H*64) storage, NT = 8 / 16 / 32) against `O.attn_core` on the DEQUANTISED values - the reference's op chain, not this
+    repository's own fake-quant kernels: an output may sit one context-grid step away where a quantiser input was within an ulp of a
+    rounding boundary (the integer products are exact where the reference rounds every product), in at most 1e-4 ... 5e-4 of the
+    outputs, never further; with the context quantiser off the outputs agree to 2e-5 + 2e-5 |ref|."""
+    rng = np.random.default_rng(2025)
+    fmin = float(np.finfo(np.float32).min)
+    cases = [  # (B, H, Sq, Sk, causal, base, zq, zk, zv, ctx quantiser: "before" | "after" | None, gate)
+        (2, 3, 144, 144, True, 1, 0.0, 131.0, 120.0, "before", True),      # zero point 0: 128 - zp = 128 (CQ2)
+        (1, 4, 77, 272, True, 0, 255.0, 97.0, 160.0, "after", True),       # zero point 255; cross attention with a cache offset
+        (3, 2, 200, 48, False, 1, 128.0, 0.0, 255.0, "before", False),     # k / v grids at the ends; cross attention, NT = 8
+        (2, 2, 33, 512, True, 1, 120.0, 160.0, 131.0, None, True),         # decoder step block against a 512-key cache, no context quantiser
+        (1, 3, 256, 256, False, 0, 97.0, 128.0, 100.0, "after", True),     # NT = 16, vanilla
+        (2, 1, 400, 400, True, 1, 131.0, 120.0, 97.0, "before", False),    # ragged NT = 32
+    ]
+    worst_off = 0.0
+    for n, (B, H, Sq, Sk, causal, base, zq, zk, zv, cq, gated) in enumerate(cases):
+        g = torch.Generator().manual_seed(7000 + n)
+        sq, sk_, sv = (0.031 * (0.2 if zq in (0.0, 255.0) else 1.0)), 0.027, 0.035
+        qi = torch.randint(0, 256, (B, Sq, H * 64), generator=g, dtype=torch.int64).to(torch.uint8)
+        ki = torch.randint(0, 256, (B, Sk, H * 64), generator=g, dtype=torch.int64).to(torch.uint8)
+        vi = torch.randint(0, 256, (B, Sk, H * 64), generator=g, dtype=torch.int64).to(torch.uint8)
+        deq = lambda idx, s_, z_: ((idx.float() - z_) * np.float32(s_))  # noqa: E731
+        hv = lambda t, S_: t.view(B, S_, H, 64).permute(0, 2, 1, 3)  # noqa: E731
+        scaling = 0.125
+        qd, kd, vd = hv(deq(qi, sq, zq), Sq) * scaling, hv(deq(ki, sk_, zk), Sk), hv(deq(vi, sv, zv), Sk)
+        s_grid, p_grid, c_grid = (0.09, float(rng.choice([128.0, 100.0, 140.0]))), (1.0 / 255.0, 0.0), (0.03, 126.0)
+        gate = torch.rand((B, H, Sq, 1), generator=g) if gated else None
+        okw = dict(base=base, causal=causal, clamp_min=causal, fq_scores=s_grid, fq_probs=p_grid, fq_ctx=c_grid if cq else None,
+                   ctx_quant_before_gate=(cq == "before"), gate=None if gate is None else gate.numpy())
+        want = O.attn_core(qd.numpy(), kd.numpy(), vd.numpy(), **okw)
+        FQ = ops.FakeQuantSpec
+        fq = ops.AttnFakeQuant(FQ(*s_grid), FQ(*p_grid), FQ(*c_grid) if cq else None, ctx_before_gate=(cq == "before"))
+        qc, kc = hv(ops.centre_indices(qi.cuda()), Sq), hv(ops.centre_indices(ki.cuda()), Sk)
+        vt = ops.centre_indices(vi.cuda()).view(B, Sk, H, 64).permute(0, 2, 3, 1).contiguous()
+        got = ops.attn_fwd_i8(qc, kc, vt, (ops.QuantGrid(sq, zq), ops.QuantGrid(sk_, zk), ops.QuantGrid(sv, zv)), out_dtype=torch.float32, scale=scaling,
+                              softmax=ops.SoftmaxSpec(base, False, 0.0, 1.0), causal=causal, clamp_min=causal, mask_min=fmin,
+                              gate=None if gate is None else gate.cuda(), fq=fq)
+        err = np.abs(_np32(got) - want)
+        if cq:
+            step = 0.03 * (float(gate.max()) if (gate is not None and cq == "before") else 1.0)
+            off = float((err > 1e-5 + 1e-5 * np.abs(want)).mean())
+            worst_off = max(worst_off, off)
+            assert err.max() <= 1.01 * step + 1e-5 and off <= 5e-4, f"case {n}: max err {err.max():.3e} (step {step:.3e}), {off:.2e} of the outputs off their grid point"
+        else:
+            assert (err <= 2e-5 + 2e-5 * np.abs(want)).all(), f"case {n}: max err {err.max():.3e} without a context quantiser"
+    print(f"int8 storage vs the oracle on ragged shapes: at most {worst_off:.2e} of the outputs one step off")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rule", ["flash_mq", "short_rows", "ragged_causal", "clip_two_pass", "int8_two_pass", "fp32_short_rows", "small_shape"])
+def test_both_sides_of_every_dispatch_rule_meet_the_contract(ops, rule):
+    """`pick_variant`'s size thresholds (profiles/r04_dispatch_ab.txt times both sides of each) only choose between
+    kernels that compute the same thing - so a rule can move after a re-measurement without a correctness review.  At a boundary shape
+    of every rule both sides are forced through `oeh_debug_set_variant` and checked against the ORACLE under the storage dtype's
+    contract; where the two kernels share their arithmetic (one-pass MQ1 / MQ2) the outputs are bitwise equal."""
+    from outeffhop_amd import _lib
+
+    lib = _lib.load()
+    fmin = float(np.finfo(np.float32).min)
+    H, D = 4, 64
+    # rule: (B, S, dtype, causal, clip, int8, pad, side A (off, mq), side B (off, mq), bitwise)
+    table = {
+        "flash_mq": (2, 512, torch.float16, True, False, False, False, (0, 1), (0, 2), True),
+        "short_rows": (3, 128, torch.float16, False, False, False, True, (2, 0), (256, 0), False),
+        "ragged_causal": (2, 320, torch.float16, True, False, False, False, (2, 0), (256, 0), False),
+        "clip_two_pass": (2, 512, torch.float16, True, True, False, False, (0, 0), (256, 0), False),
+        "int8_two_pass": (2, 512, torch.float16, True, False, True, False, (0, 0), (256, 0), False),
+        "fp32_short_rows": (3, 128, torch.float32, False, False, False, True, (64, 0), (256, 0), False),
+        "small_shape": (70, 28, torch.float32, False, False, False, False, (1 << 5, 0), (1 << 10, 0), False),
+    }
+    B, S, dt, causal, clip, int8, pad, side_a, side_b, bitwise = table[rule]
+    q = (_rand((B, H, S, D), 4401, dtype=torch.float32) * D ** -0.5).to(dt)
+    k, v = _rand((B, H, S, D), 4402, dtype=dt), _rand((B, H, S, D), 4403, dtype=dt)
+    padm = _pad_mask(B, S, [S - 11 * (b + 1) for b in range(B)], fmin) if pad else None
+    okw = dict(base=1, causal=causal, clamp_min=causal, pad_mask=padm, mask_min=fmin)
+    if clip:
+        okw.update(clip=True, gamma=-0.025, eta=1.1)
+    fq = None
+    if int8:
+        _, fp = O.attn_core(_np32(q), _np32(k), _np32(v), want=("scores", "probs"), **okw)
+        d_s = O.quant_range_to_params(*np.percentile(fp["scores"], (0.001, 99.999)))
+        d_p = O.quant_range_to_params(*np.percentile(fp["probs"], (0.001, 99.999)))
+        d_c = O.quant_range_to_params(*np.percentile(O.attn_core(_np32(q), _np32(k), _np32(v), **okw), (0.001, 99.999)))
+        okw.update(fq_scores=d_s, fq_probs=d_p, fq_ctx=d_c)
+        FQ = ops.FakeQuantSpec.from_delta
+        fq = ops.AttnFakeQuant(FQ(*d_s), FQ(*d_p), FQ(*d_c))
+    want = O.attn_core(_np32(q), _np32(k), _np32(v), **okw)
+    kw = dict(softmax=ops.SoftmaxSpec(1, clip, -0.025 if clip else 0.0, 1.1 if clip else 1.0), causal=causal, clamp_min=causal, mask_min=fmin,
+              key_pad_mask=None if padm is None else torch.from_numpy(padm).cuda(), fq=fq)
+    outs, names = [], []
+    try:
+        for side in (side_a, side_b):
+            lib.oeh_debug_set_variant(*side)
+            names.append(ops.attn_variant(B, H, S, S, D, dt, fq=int8, clip=clip, causal=causal, key_pad=pad, mask_min=fmin))
+            outs.append(ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), **kw))
+    finally:
+        lib.oeh_debug_set_variant(0, 0)
+    assert names[0] != names[1] or rule == "flash_mq", f"{rule}: both sides ran {names[0]}"
+    for name, got in zip(names, outs):
+        if int8:
+            step = float(np.float32(d_c[0]))
+            err = np.abs(_np32(got) - want)
+            assert err.max() <= 2.05 * step + 2e-3 and float((err > 0.5 * step + 1e-3).mean()) < 4e-3, f"{rule} {name}: {err.max() / step:.2f} steps"
+        elif dt == torch.float32:
+            _check(got, want, tol=dict(atol=5e-4, rtol=5e-4), msg=f"{rule} {name}")
+        else:
+            _check(got, want, msg=f"{rule} {name}")
+    if bitwise:
+        assert torch.equal(outs[0], outs[1]), f"{rule}: {names} differ"

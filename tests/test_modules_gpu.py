@@ -681,3 +681,81 @@ def test_fp32_gated_bert_module_uses_the_in_kernel_predictor(oa, monkeypatch):
             assert len(calls) == 1
             monkeypatch.undo()
         assert float((out - ref).abs().max()) < 1.5e-3 and float((probs - m.last_gate_all_probs).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_fused_calibration_vs_observable_16bit(oa, dt):
+    """in estimate_ranges state `_calibrate_fused` feeds the estimators fp32 values recomputed from the stored 16-bit
+    q / k (what the fused eval kernels quantise), the observable path the score / probability tensors ROUNDED to the storage dtype
+    (what the reference's own 16-bit module would hand `np.percentile`).  The two calibrations may differ by one storage ulp of a
+    percentile value (the context: of its 16-bit inputs' roundings) - documented in `_calibrate_fused`; bounded here at 2^-10 (fp16) / 2^-6 (bf16) relative on every delta -,
+    a forward hook on a quantiser module and a running average without momentum send the module down the observable path."""
+    from outeffhop_amd import quantization as Q
+
+    torch.manual_seed(11)
+    xs = [torch.randn(2, 96, 128, device="cuda", dtype=dt) for _ in range(3)]
+    deltas = {}
+    for fused in (True, False):
+        keep = Q.FUSED_CALIBRATION
+        Q.FUSED_CALIBRATION = fused
+        try:
+            org = oa.OPTAttentionWithExtras(128, 2, is_decoder=True, softmax_fn=oa.SOFTMAX_MAPPING["softmax1"])
+            torch.manual_seed(12)
+            for p in org.parameters():
+                torch.nn.init.normal_(p, std=0.08)
+            qm = oa.QuantizedOPTAttentionWithExtras(org.cuda().to(dt), **_qparams(oa)).cuda().eval()
+            qm.set_quant_state(weight_quant=True, act_quant=True)
+            with torch.no_grad():
+                for x in xs:
+                    qm(x)
+            assert (qm.__dict__.get("_fused_calib_calls", 0) == len(xs)) == fused
+            deltas[fused] = [float(getattr(qm, n).activation_quantizer.quantizer.delta)
+                             for n in ("attn_scores_act_quantizer", "attn_probs_act_quantizer", "context_act_quantizer")]
+        finally:
+            Q.FUSED_CALIBRATION = keep
+    lim = 2.0 ** -10 if dt == torch.float16 else 2.0 ** -6   # (measured: fp16 <= 3e-4; bf16 3e-4 / 3e-3 / 9e-3 for scores / probabilities / context)
+    for a, b in zip(deltas[True], deltas[False]):
+        assert abs(a - b) <= lim * abs(b), (dt, deltas)
+    # a hook on a quantiser module, or no momentum: the observable path (the hook fires; nothing is bypassed)
+    org = oa.OPTAttentionWithExtras(128, 2, is_decoder=True, softmax_fn=oa.SOFTMAX_MAPPING["softmax1"])
+    qm = oa.QuantizedOPTAttentionWithExtras(org.cuda().to(dt), **_qparams(oa)).cuda().eval()
+    qm.set_quant_state(weight_quant=True, act_quant=True)
+    seen = []
+    h = qm.attn_scores_act_quantizer.register_forward_hook(lambda m, i, o: seen.append(tuple(o.shape)))
+    with torch.no_grad():
+        qm(xs[0])
+    h.remove()
+    assert seen and qm.__dict__.get("_fused_calib_calls", 0) == 0
+    qm.attn_probs_act_quantizer.activation_quantizer.range_estimator.momentum = None   # (no running average: every batch assigns)
+    with torch.no_grad():
+        qm(xs[1])
+    assert qm.__dict__.get("_fused_calib_calls", 0) == 0
+
+
+def test_int8_storage_core_yields_to_forward_hooks(oa):
+    """the INT8-storage fast path reads the QuantLinear weights and quantiser grids directly - the forwards of
+    query / key / value (q_proj ...), of the consumer and of the three activation quantisers never run.  The reference's
+    `attach_act_hooks` registers a forward hook on every named module; with one present the module path runs and the hook fires."""
+    g = load_golden("int8_attn.npz")
+    calib = [torch.from_numpy(g[f"calib{i}"]).cuda() for i in range(4)]
+    evalx = torch.from_numpy(g["eval"]).cuda()
+    bmask = torch.from_numpy(g["bert_mask"]).cuda()
+    meta = json.loads(str(g["meta_json"]))[0]
+    pre = f"bert{meta['tag']}"
+    sd = {k[len(pre) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre + ".w.")}
+    org = oa.BertSelfAttentionWithExtras(Cfg(), softmax_fn=oa.SOFTMAX_MAPPING[meta["softmax"]], **gate_kwargs(meta["gate"]))
+    org.load_state_dict(sd, strict=True)
+    qm = oa.QuantizedBertSelfAttentionWithExtras(org.cuda(), **_qparams(oa)).cuda().eval()
+    qm.set_quant_state(weight_quant=True, act_quant=True)
+    with torch.no_grad():
+        for c in calib:
+            qm(c, attention_mask=bmask)
+        qm.fix_ranges()
+        plain = qm(evalx, attention_mask=bmask)[0]
+        fired = []
+        h = qm.key.register_forward_hook(lambda m, i, o: fired.append(1))
+        hooked = qm(evalx, attention_mask=bmask)[0]
+        h.remove()
+    assert fired, "the hook on `key` never fired: the fast path bypassed the module forward"
+    step = float(qm.context_act_quantizer.activation_quantizer.quantizer.delta)
+    assert float((plain - hooked).abs().max()) <= 1.05 * step

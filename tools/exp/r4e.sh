@@ -1,0 +1,11 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r4e
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/r4e/tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/r4e/tests.log
+grep -E "passed|failed|FAILED|rc=" gpurun_out/r4e/tests.log | tail -20
+L=$GRAFT_REPO_ROOT/outeffhop_amd/lib/r03/liboeh_hip.so
+python tools/microbench.py "B=16,H=12,S=512,D=64,causal=1,ab=$L" "B=16,H=12,S=512,D=64,causal=1,clip=1,ab=$L" "B=16,H=12,S=512,D=64,causal=1,int8=1,ab=$L" "B=32,H=12,S=128,D=64,pad=1,ab=$L" "B=16,H=12,S=512,D=64,causal=1,dtype=f32,ab=$L" "B=32,H=12,S=128,D=64,pad=1,base=0,ab=$L" "B=8,H=12,S=1024,D=64,pad=1,base=0,ab=$L" 2>&1 | grep -v amdgpu.ids > gpurun_out/r4e/ab_vs_r03.txt
+cat gpurun_out/r4e/ab_vs_r03.txt
+python tools/uniform_chain.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r4e/uniform_chain.txt
+cat gpurun_out/r4e/uniform_chain.txt
+python __graft_entry__.py smoke 2>&1 | tail -2

@@ -2,7 +2,7 @@
 """Kernel micro-benchmark (GPU box): mean launch time of oeh_attn_fwd for a list of shapes / options,
 rotating over enough buffer sets to exceed the 256 MiB Infinity Cache.  Usage:
     python tools/microbench.py "B=16,H=12,S=512,D=64,causal=1" "B=32,H=12,S=128,D=64,pad=1" ...
-keys: B H S D causal pad clip int8 dtype(f16|bf16|f32) full iters reps gate base graph(=launches per captured graph)
+keys: B H S Sk(keys per row, default S) D causal pad clip int8 dtype(f16|bf16|f32) full iters reps gate base graph(=launches per captured graph)
       gmlp (>= 0: per-token gate predictor with that many hidden units evaluated in the kernel; 0 = Linear)
       ab=<other liboeh_hip.so>: same-process A/B - blocks of launches alternate between the built library and the other one
       off (bit mask of kernel variants to disable: 2 = one-pass, 4 = full-row; 64 / 128 = their fp32-storage forms; 256 = one-pass also for Sk <= 128; 512 = no snake placement)  mq (force one-pass query blocks per wave)
@@ -21,16 +21,17 @@ from outeffhop_amd import _lib, ops
 
 
 def run(spec):
-    kv = dict(B=16, H=12, S=512, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, reps=1, graph=0, gmlp=-1, ab="", i8=0, hg=0, padbool=1)
+    kv = dict(B=16, H=12, S=512, Sk=0, D=64, causal=0, pad=0, clip=0, int8=0, dtype="f16", full=0, iters=300, gate=0, base=1, off=0, mq=0, reps=1, graph=0, gmlp=-1, ab="", i8=0, hg=0, padbool=1)
     for item in spec.split(","):
         k, v = item.split("=")
         kv[k] = v if k in ("dtype", "ab") else int(v)
     B, H, S, D = kv["B"], kv["H"], kv["S"], kv["D"]
+    Sk = kv["Sk"] or S  # keys per row (default: self attention)
     os.environ["OEH_HEAD_GROUP"] = str(kv["hg"])  # fp32-storage kernels: block order in groups of this many heads (debug hook)
     _lib.load().oeh_debug_set_variant(kv["off"], kv["mq"])
     dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[kv["dtype"]]
     eb = 4 if dt == torch.float32 else 2
-    per_set = 4 * B * H * S * D * eb
+    per_set = 2 * B * H * (S + Sk) * D * eb
     nsets = max(2, int(700e6 // per_set) + 1)
     nsets = min(nsets, 64)
     fmin = float(np.finfo(np.float32).min)
@@ -38,8 +39,8 @@ def run(spec):
     g = torch.Generator(device="cuda").manual_seed(0)
     for _ in range(nsets):
         q = (torch.randn(B, S, H * D, device="cuda", generator=g) * D ** -0.5).to(dt).view(B, S, H, D).permute(0, 2, 1, 3)
-        k = torch.randn(B, S, H * D, device="cuda", generator=g).to(dt).view(B, S, H, D).permute(0, 2, 1, 3)
-        v = torch.randn(B, S, H * D, device="cuda", generator=g).to(dt).view(B, S, H, D).permute(0, 2, 1, 3)
+        k = torch.randn(B, Sk, H * D, device="cuda", generator=g).to(dt).view(B, Sk, H, D).permute(0, 2, 1, 3)
+        v = torch.randn(B, Sk, H * D, device="cuda", generator=g).to(dt).view(B, Sk, H, D).permute(0, 2, 1, 3)
         sets.append((q, k, v))
     pad = None
     if kv["pad"]:
@@ -129,7 +130,7 @@ def run(spec):
         samples.append(e0.elapsed_time(e1) * 1e3 / n)
     us = float(np.median(samples))  # reps > 1: median of the repeats (boxes and clocks wander by a few %)
     alg = per_set
-    var = "i8mfma" if kv["i8"] else ops.attn_variant(B, H, S, S, D, dt, fq=bool(kv["int8"]), clip=bool(kv["clip"]))
+    var = "i8mfma" if kv["i8"] else ops.attn_variant(B, H, S, Sk, D, dt, fq=bool(kv["int8"]), clip=bool(kv["clip"]))
     print(f"{spec:60s} {us:8.2f} us  {alg / us / 1e3:8.1f} GB/s alg  frac {alg / us / 1e3 / 8000:.3f}  "
           f"{4 * B * H * S * S * D / us / 1e6:7.1f} TF(dense)  sets={nsets}  [{var}]", flush=True)
 

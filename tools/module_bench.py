@@ -112,7 +112,9 @@ def quantised():
                 qm(x_, attention_mask=mask)
             torch.cuda.synchronize()
             print(f"calibration, {'in-kernel statistics (oeh_attn_calibrate)' if fused else 'materialised score tensors':42s}: "
-                  f"{(time.perf_counter() - t0) * 1e3 / 3:.2f} ms per batch, peak extra memory {(torch.cuda.max_memory_allocated() - base) / 1e6:.0f} MB")
+                  f"{(time.perf_counter() - t0) * 1e3 / 3:.2f} ms per batch, peak extra memory {(torch.cuda.max_memory_allocated() - base) / 1e6:.0f} MB"
+                  f" = {(torch.cuda.max_memory_allocated() - base) / (B * S * E * 4):.1f} (B,S,E) fp32 tensors of {B * S * E * 4 / 1e6:.0f} MB (projection outputs, their"
+                  f" fake-quantised copies, the context); a (B,H,S,S) fp32 tensor would be {B * 12 * S * S * 4 / 1e6:.0f} MB")
         Q.FUSED_CALIBRATION = True
         qm.fix_ranges()
         x = torch.randn(B, S, E, device=dev)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic (GPU box): per-wave s_memtime timeline of the one-pass attention kernel: timeline.py causal B S [off_bits] [MQ].
+"""Diagnostic (GPU box): per-wave s_memtime timeline of the one-pass attention kernel: timeline.py causal B S [off_bits] [MQ] [Sk].
 Needs the stamped build: `make -C outeffhop_amd/csrc timeline` (-> outeffhop_amd/lib/timeline/liboeh_hip.so; the production
 kernels carry no stamp code), loaded here through OEH_LIB.
 Never quote run times from this build path: the stamps perturb the schedule; read the SHARES."""
@@ -20,12 +20,13 @@ lib = _lib.load()
 causal = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 B, H, S, D = (int(sys.argv[2]) if len(sys.argv) > 2 else 16), 12, (int(sys.argv[3]) if len(sys.argv) > 3 else 512), 64
 MQ = int(sys.argv[5]) if len(sys.argv) > 5 else 2   # query blocks per wave: workgroups of 64 * MQ rows
+SK = int(sys.argv[6]) if len(sys.argv) > 6 else S   # keys per row (cross attention: every workgroup the same number of key tiles)
 lib.oeh_debug_set_variant(256 | (int(sys.argv[4]) if len(sys.argv) > 4 else 0), MQ)
 lib.oeh_debug_set_stamps.argtypes = [C.c_void_p]
 g = torch.Generator(device="cuda").manual_seed(0)
 q = (torch.randn(B, S, H * D, device="cuda", generator=g) * D ** -0.5).half().view(B, S, H, D).permute(0, 2, 1, 3)
-k = torch.randn(B, S, H * D, device="cuda", generator=g).half().view(B, S, H, D).permute(0, 2, 1, 3)
-v = torch.randn(B, S, H * D, device="cuda", generator=g).half().view(B, S, H, D).permute(0, 2, 1, 3)
+k = torch.randn(B, SK, H * D, device="cuda", generator=g).half().view(B, SK, H, D).permute(0, 2, 1, 3)
+v = torch.randn(B, SK, H * D, device="cuda", generator=g).half().view(B, SK, H, D).permute(0, 2, 1, 3)
 kw = dict(causal=bool(causal), clamp_min=bool(causal), mask_min=float(np.finfo(np.float32).min))
 for _ in range(3):
     ops.attn_fwd(q, k, v, **kw)
@@ -67,7 +68,7 @@ cu = (hw >> 8) & 0xF
 sh = (hw >> 12) & 1
 se = (hw >> 13) & 7
 key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
-ntile = np.minimum((S + 63) // 64, MQ * (nqt - np.arange(nwg) // (B * H)))  if causal else np.full(nwg, (S + 63) // 64)
+ntile = np.minimum((SK + 63) // 64, MQ * (nqt - np.arange(nwg) // (B * H)))  if causal else np.full(nwg, (SK + 63) // 64)
 per_cu = {}
 for w in range(nwg):
     per_cu.setdefault(int(key[w]), []).append(w)
