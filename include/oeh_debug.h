@@ -15,7 +15,8 @@ extern "C" {
 /* off_mask: bit (1 << v) disables kernel variant v (1 one-pass, 2 full-row, 3 general, 4 any-shape, 5 small-shape; 6 / 7 the
  * fp32-storage forms of the one-pass / full-row kernels); bit 8 lets the one-pass kernel take rows of <= 128 keys too;
  * bit 9: plain block order in the one-pass kernel (no snake placement); bit 10: the small-shape kernel wherever it can run;
- * bit 11: the full-row kernel also for head dim 128 with clip / INT8 (otherwise the general kernel there).
+ * bit 11: the full-row kernel also for head dim 128 with clip / INT8 (otherwise the general kernel there);
+ * bit 12: the 32x32x16 form of the one-pass kernel (oeh_attn_wide.hip) wherever it applies.
  *  flash_mq_force != 0 fixes the one-pass kernel's query blocks per
  * wave.  (0, 0) restores the defaults.  Returns 0, or -95 when the hooks are not enabled. */
 int oeh_debug_set_variant(int off_mask, int flash_mq_force);

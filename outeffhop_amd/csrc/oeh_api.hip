@@ -22,6 +22,7 @@ int launch_attn_flash_d128(const AttnParams& P, int in, int mq, hipStream_t st);
 int launch_attn_generic(const AttnParams& P, int in, hipStream_t st);
 int launch_attn_small(const AttnParams& P, int in, hipStream_t st);
 int launch_attn_i8(const AttnParams& P, int out, hipStream_t st);
+int launch_attn_wide(const AttnParams& P, int in, hipStream_t st);
 int launch_softmax_rows(const void* x, void* y, long rows, int cols, int in, int base, int clip, float w, float g, hipStream_t st);
 int launch_fake_quant(const void* x, void* y, unsigned char* idx, long n, int in, FqP f, hipStream_t st);
 int launch_gate(const void* hidden, int in, int B, int T, int H, int d, long hs_b, long hs_t, const float* w1, const float* b1,
@@ -151,6 +152,7 @@ bool fast_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
 int g_force_flash = 0;                   // tools/microbench.py only
 int g_no_d128_rule = 0;                 // tests: the full-row kernel also for head dim 128 with clip / INT8 (the comparison against the general kernel)
 int g_force_small = 0;                   // tests: the small-shape kernel wherever it can run (no size heuristic)
+int g_wide = 0;                          // tools / tests: the 32x32x16 form of the one-pass kernel (oeh_attn_wide.hip) wherever it applies
 
 // The one-pass kernel (oeh_attn_flash.inl) additionally needs the plain softmax_n (no clip).  No Sk limit.
 bool flash_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq, bool short_rows_too = false) {
@@ -270,6 +272,14 @@ int flash_mq(const oeh_attn_desc* d) {
   return (d->Sq > 64 && wg2 >= 416) ? 2 : 1;  // (H=12 S=512 causal: B=8 - 384 workgroups - 10.8 vs 12.4 us with one block per wave, B=9 - 432 - 13.3 vs 12.8, B=10 14.5 vs 12.7, B=12 16.2 vs 13.5)
 }
 
+// The 32x32x16 form of the one-pass kernel (oeh_attn_wide.hip): plain softmax / softmax_1, 16-bit storage, head dim 64, masks none |
+// causal, gate values only.  Behind the diagnostic hook (oeh_debug_set_variant bit 12) until it is measured ahead.
+bool wide_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
+  if (!g_wide || d->D != 64 || (d->dtype != OEH_F16 && d->dtype != OEH_BF16) || want_out32(d)) return false;
+  if (d->clip || any_fq(fq) || d->key_pad_mask != nullptr || d->full_mask != nullptr || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
+  return d->Sq > 64;
+}
+
 // INT8 storage (oeh_attn_i8.hip): see include/oeh.h, oeh_attn_desc.q_grid
 bool i8_eligible(const oeh_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const oeh_fq_desc* fq) {
   if (d->dtype != OEH_I8 || d->D != 64 || d->Sk > 512 || (d->Sk & 15) != 0) return false;
@@ -380,7 +390,8 @@ const char* variant_name(Variant v, const oeh_attn_desc* d, bool fq) {
   if (v == V_NONE) return nullptr;
   const int nt = d->Sk <= 128 ? 8 : (d->Sk <= 256 ? 16 : 32);
   const char* dt = d->dtype == OEH_F16 ? "f16" : (d->dtype == OEH_BF16 ? "bf16" : "f32");
-  if (v == V_FLASH) std::snprintf(buf, sizeof(buf), "flash16/MQ%d/D%d/%s%s", flash_mq(d), d->D, dt, fq ? "/fq2p" : (d->clip ? "/clip2p" : ""));
+  if (v == V_FLASH && wide_eligible(d, nullptr) && !fq) std::snprintf(buf, sizeof(buf), "flash16w/D%d/%s", d->D, dt);
+  else if (v == V_FLASH) std::snprintf(buf, sizeof(buf), "flash16/MQ%d/D%d/%s%s", flash_mq(d), d->D, dt, fq ? "/fq2p" : (d->clip ? "/clip2p" : ""));
   else if (v == V_FAST) std::snprintf(buf, sizeof(buf), "fast16/NT%d/D%d/%s%s%s", nt, d->D, dt, d->clip ? "/clip" : "", fq ? "/fq" : "");
   else std::snprintf(buf, sizeof(buf), "mfma16/NT%d/D%d/%s%s", nt, d->D, dt, fq ? "/fq" : "");
   return buf;
@@ -428,6 +439,10 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
   }
   if (var == V_FLASH) {
     if (desc->scale_div != 0.0f) { P.scale = 1.0f / desc->scale_div; P.scale_div = 0.0f; }  // (fast_eligible: exact for a power of two)
+    if (wide_eligible(desc, fq)) {
+      P.nQT = (desc->Sq + 127) / 128;
+      return oeh::launch_attn_wide(P, desc->dtype, st);
+    }
     const int mq = flash_mq(desc);
     P.nQT = (desc->Sq + 64 * mq - 1) / (64 * mq);
     switch (desc->D) {
@@ -580,6 +595,7 @@ static bool debug_hooks_on() {
 }
 int oeh_debug_set_variant(int off_mask, int flash_mq_force) {
   if (!debug_hooks_on()) return OEH_ENOTSUP;
+  g_wide = (off_mask >> 12) & 1;
   g_variant_off = off_mask & 0xff; g_force_flash = (off_mask >> 8) & 1; g_flash_mq = flash_mq_force; g_place = (off_mask >> 9) & 1; g_force_small = (off_mask >> 10) & 1; g_no_d128_rule = (off_mask >> 11) & 1;
   { const char* e = std::getenv("OEH_HEAD_GROUP"); g_head_group = e != nullptr ? (std::atoi(e) & ~7) : 0; }
   return OEH_OK;

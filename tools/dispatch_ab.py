@@ -80,7 +80,7 @@ def ab(rule, shape, side_a, side_b, iters=120):
 
 def main():
     only = sys.argv[1:]
-    want = lambda r: not only or any(o in r for o in only)  # noqa: E731
+    want = lambda r: (not only and r != "wide") or any(o in r for o in only)  # noqa: E731  ("wide": an experiment, on request only)
     # 1. one-pass kernel, query blocks per wave: two (128-row workgroups) from 416 workgroups on  (oeh_api.hip: flash_mq)
     if want("flash_mq"):
         for B in (7, 8, 9, 10, 12):  # H=12 S=512: 4 workgroups of 128 rows per head -> 336, 384, 432, 480, 576
@@ -121,6 +121,11 @@ def main():
     if want("fp32_ragged_causal"):
         for S, B in ((192, 40), (320, 24), (448, 18)):
             ab("fp32 causal ragged <= 384: full-row", (B, 12, S, 64, "f32", 1, 0, 0, 0), (0, 0), ((256, 0) if S <= 384 else (64, 0)))
+    # the 32x32x16 form of the one-pass kernel (oeh_attn_wide.hip) against the production 16x16x32 form
+    if want("wide"):
+        for B, S, causal in ((16, 512, 1), (16, 512, 0), (8, 1024, 1), (4, 2048, 1), (32, 256, 1), (12, 512, 1)):
+            ab("wide (32x32x16) vs one-pass", (B, 12, S, 64, "f16", causal, 0, 0, 0), (0, 0), (4096, 0))
+        ab("wide (32x32x16) vs one-pass", (16, 12, 512, 64, "bf16", 1, 0, 0, 0), (0, 0), (4096, 0))
     # 9. the small-shape kernel: fp32 problems of at most 32 rows, >= 256 of them
     if want("small_shape"):
         for B, S in ((224, 28), (384, 32), (224, 48), (48, 28)):
