@@ -201,6 +201,13 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_wide_kernel(const AttnParams 
     }
     float mt_ = __builtin_fmaxf(__builtin_fmaxf(m4[0], m4[1]), __builtin_fmaxf(m4[2], m4[3]));
     const float thr = (i == 0) ? -1.0e20f : kThr;
+    // the exponentials are formed against the CURRENT reference straight away (they do not wait for the maximum chain and the branch);
+    // when some row has to move its reference - always on tile 0, rare afterwards - they are redone below
+    f16v e[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) e[kt][r] = __builtin_amdgcn_exp2f(s[kt][r]);
     if (__builtin_amdgcn_ballot_w64(mt_ > thr) != 0) {  // some row moves its reference (always on the first tile; later only beyond 2^8)
       mt_ = pair_allreduce_max(mt_);
       const float delta = (mt_ > thr) ? mt_ : 0.0f;
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_wide_kernel(const AttnParams 
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kt][r] -= delta;
+        for (int r = 0; r < 16; ++r) e[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - delta);
       if (i != 0) {
         const float alpha = __builtin_amdgcn_exp2f(-delta);
         lsum *= alpha;
@@ -220,9 +227,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_wide_kernel(const AttnParams 
       }
     }
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r]);
+    for (int kt = 0; kt < 2; ++kt) s[kt] = e[kt];
     {  // row sums as fp32 adds of the exponentials, four independent chains (a 32x32x16 ones-operand MFMA per 16 keys costs the matrix
        // pipe 128 cycles per tile and 16 accumulator registers; measured 3 - 9 % slower)
       float a4[4];

@@ -1967,3 +1967,34 @@ def test_both_sides_of_every_dispatch_rule_meet_the_contract(ops, rule):
             _check(got, want, msg=f"{rule} {name}")
     if bitwise:
         assert torch.equal(outs[0], outs[1]), f"{rule}: {names} differ"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_wide_mfma_form_of_the_one_pass_kernel(ops, dt):
+    """VERDICT r3 next #1, second candidate: the one-pass kernel on v_mfma_f32_32x32x16 (csrc/oeh_attn_wide.hip; 8 + 8 product MFMAs
+    per 32-row x 64-key tile instead of 16 + 16 + 4, one lane = 32 scores of one query).  Measured 3 - 7 % SLOWER than the 16x16x32
+    form on every shape (profiles/r04_wide_kernel_ab.txt), so it stays behind the diagnostic hook (oeh_debug_set_variant bit 12) - kept
+    correct here so that the comparison can be repeated: against the oracle on causal / dense / ragged / cross-attention shapes, and
+    against the production kernel (same contract, not the same bits: the row sums are fp32 adds of the exponentials there)."""
+    from outeffhop_amd import _lib
+
+    lib = _lib.load()
+    fmin = float(np.finfo(np.float32).min)
+    tol = F16_TOL if dt == torch.float16 else BF16_TOL
+    for n, (B, H, Sq, Sk, causal, base) in enumerate([(2, 3, 512, 512, True, 1), (2, 2, 512, 320, False, 1), (1, 2, 200, 200, True, 0), (2, 2, 100, 300, True, 1),
+                                                      (1, 2, 640, 640, True, 1), (1, 2, 257, 131, False, 0)]):
+        q = (_rand((B, H, Sq, 64), 4500 + n, dtype=torch.float32) * 0.125).to(dt)
+        k, v = _rand((B, H, Sk, 64), 4600 + n, dtype=dt), _rand((B, H, Sk, 64), 4700 + n, dtype=dt)
+        gate = np.random.default_rng(n).random((B, H, Sq, 1), dtype=np.float32)
+        want = O.attn_core(_np32(q), _np32(k), _np32(v), base=base, causal=causal, clamp_min=causal, gate=gate)
+        kw = dict(softmax=ops.SoftmaxSpec(base), causal=causal, clamp_min=causal, mask_min=fmin, gate=torch.from_numpy(gate).cuda())
+        try:
+            lib.oeh_debug_set_variant(4096, 0)
+            name = ops.attn_variant(B, H, Sq, Sk, 64, dt, base=base, causal=causal, mask_min=fmin)
+            got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), **kw)
+        finally:
+            lib.oeh_debug_set_variant(0, 0)
+        assert name.startswith("flash16w/"), name
+        _check(got, want, tol=tol, msg=f"wide form {(B, H, Sq, Sk, causal, base)}")
+    assert not ops.attn_variant(2, 3, 512, 512, 64, dt, causal=True, mask_min=fmin).startswith("flash16w/")  # (the hook is off again)
