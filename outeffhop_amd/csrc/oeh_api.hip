@@ -188,10 +188,14 @@ bool flash_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq, bool short_ro
 bool flash_clip_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
   oeh_attn_desc t = *d;
   if (t.dtype == OEH_F32) t.dtype = OEH_F16;  // fp32 storage: the SRC32 form (operand pairs), same conditions on the problem
+  // round 4: a (B,1,Sq,Sk) mask on rows of more than 512 keys too (the PAD variants read it per block, as the plain one-pass form does)
+  const bool long_full = d->full_mask != nullptr && d->Sk > 512 && (d->mask_min < -1.0e4f);
+  if (long_full) t.full_mask = nullptr;
   if (!d->clip || any_fq(fq) || !fast_eligible(&t, fq)) return false;  // (fast_eligible: gamma <= 0, masks, scale)
   if (d->gate == nullptr && d->gate_hidden != nullptr) return false;
-  if (d->key_pad_mask != nullptr && d->softmax_base != OEH_SOFTMAX_ONE) return false;  // (as in the one-pass form: trailing padded tiles are not streamed)
-  return d->Sk > 512 || (d->D == 128 && d->Sk >= 384) || g_force_flash;  // (d = 128, S = 512: 47.4 vs 58.2 us in the full-row kernel, causal 38.1 vs 41.2)
+  // (key padding / a full mask under the VANILLA softmax since round 4: a row without a visible key - uniform over all Sk keys in the
+  // reference - gets clip(w / Sk + gamma) times the sum of V in the epilogue, oeh_attn_flash.inl)
+  return d->Sk > 512 || (d->D == 128 && d->Sk >= 384 && d->full_mask == nullptr) || (g_force_flash && d->full_mask == nullptr);  // (d = 128, S = 512: 47.4 vs 58.2 us in the full-row kernel, causal 38.1 vs 41.2)
 }
 
 // The fused INT8 chain on rows of MORE than 512 keys: the one-pass kernel's two-pass form of the grid chain (TP = 2).  What

@@ -417,6 +417,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   float mcneg[MQ];
   float lsum[MQ], pinv[MQ];             // two-pass forms: this lane's share of the row sum of exp (statistics pass); 1 / denominator (final pass)
   float mrl[MQ];                        // TP = 2: the lane's running maximum of rel, then the row's
+  bool dead1[MQ];                       // TP = 1, vanilla softmax with masks: the row has no visible key
+#pragma unroll
+  for (int j = 0; j < MQ; ++j) dead1[j] = false;
   const float fq_k1 = sc * P.fq_s.rscale, fq_c2 = P.fq_s.c2;
 #pragma unroll
   for (int j = 0; j < MQ; ++j) { lsum[j] = 0.0f; pinv[j] = 1.0f; mrl[j] = kGridMagic + (P.fq_s.lo - 1.0f); }  // (one below every index: never a sentinel in exp2 arguments; rel is carried as M + rel, oeh_common.h: grid_rel_m)
@@ -731,6 +734,10 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
         l = row4_sum(l);
         if (P.base != 0) l = l + __builtin_amdgcn_exp2f(mcneg[j]);    // softmax_1: + 1*exp(-reference)
         pinv[j] = 1.0f / l;
+        if constexpr (PAD) {  // vanilla softmax, a row without a visible key (l == 0): no 0 * inf in the final pass - the epilogue forms the row
+          dead1[j] = (P.base == 0) && (l == 0.0f);
+          if (dead1[j]) pinv[j] = 0.0f;
+        }
       }
     }
   };
@@ -836,12 +843,13 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     if (P.base != 0) den = den + __builtin_amdgcn_exp2f(mcneg[j]);  // softmax_1: + 1*exp(-reference)  (vutils/softmax_1.py:18-20)
     float rowscale = 1.0f / den;
     if constexpr (TP != 0) rowscale = 1.0f;  // the clipped probabilities / the probability indices went into the product as they are
-    if constexpr (PAD && TP == 0) {
+    if constexpr (PAD && (TP == 0 || TP == 1)) {
       // Vanilla softmax and a row WITHOUT a visible key (a fully padded sample; a left-padded one under the causal mask): every score
       // of the reference is the same finfo.min, its probabilities are uniform over ALL Sk keys - which a kernel that skips masked
-      // tiles has not accumulated (l == 0 here).  Such rows - rare - take the mean of V straight from memory.
+      // tiles has not accumulated (l == 0 here).  Such rows - rare - take the mean of V straight from memory (the clipped two-pass
+      // form: clip(w / Sk + gamma, 0, 1) times the sum of V - models/softmax.py:10-13 on a uniform row).
       if (P.base == 0) {
-        const bool dead = den == 0.0f;
+        const bool dead = (TP == 1) ? dead1[j] : (den == 0.0f);
         if (__builtin_amdgcn_ballot_w64(dead) != 0) {
           if (dead) {
             f4 acc[DT];
@@ -862,7 +870,8 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
                                          In<IN>::to_f32((unsigned short)(w.y & 0xffffu)), In<IN>::to_f32((unsigned short)(w.y >> 16))};
                 }
             }
-            const float rs = 1.0f / (float)Sk;
+            float rs = 1.0f / (float)Sk;
+            if constexpr (TP == 1) rs = __builtin_fminf(__builtin_fmaxf(rs * P.clip_w + P.clip_g, 0.0f), 1.0f);  // the clipped uniform probability
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
               o[j][dt] = acc[dt] * rs;

@@ -245,14 +245,15 @@ def attn_fwd(
         fqd.ctx_quant_before_gate = int(bool(fq.ctx_before_gate))
         fqd.ctx_emit_index = int(bool(fq.ctx_emit_index))
     lib = _lib.load()
-    _warn_if_any_shape_kernel(lib, d, fqd, softmax)
     if _prepared is not None:  # hand back the prebuilt C call instead of launching (bench / hipGraph loops)
+        _warn_if_any_shape_kernel(lib, d, fqd, softmax)
         args = (C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), None if fqd is None else C.byref(fqd))
         _prepared.extend([lib.oeh_attn_fwd, args, (d, fqd, keep, q, k, v, out)])
         return out
     with _on_device(dev):
         rc = lib.oeh_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), None if fqd is None else C.byref(fqd), _stream())
     _lib.check(rc, "oeh_attn_fwd")
+    _warn_if_any_shape_kernel(lib, d, fqd, softmax)  # (after the launch: a call the library refuses raises above and has run nothing)
     return out
 
 

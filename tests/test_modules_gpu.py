@@ -476,8 +476,8 @@ def test_opt_consecutive_batches_with_different_padding(oa, quantised):
 
 def test_fused_gate_falls_back_when_the_library_refuses(oa, monkeypatch):
     """`except _lib.OehError` named a module attention.py never imported - the OEH_ENOTSUP fallback to
-    oeh_gate_fwd raised NameError.  Force the refusal (clipped vanilla softmax + key padding + 640 keys runs the any-shape kernel,
-    which has no in-kernel predictor) with the probe patched to say yes."""
+    oeh_gate_fwd raised NameError.  Force the refusal (clipped vanilla softmax + key padding + 640 keys: the two-pass clipped form has
+    no in-kernel predictor, nor has the any-shape kernel) with the probe patched to say yes."""
     from outeffhop_amd import attention as A, ops
 
     torch.manual_seed(3)
