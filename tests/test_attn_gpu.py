@@ -120,7 +120,8 @@ def test_opt_order_causal(ops, S, sm):
     k, v = _rand((B, H, S, D), 22), _rand((B, H, S, D), 23)
     lengths = [S, max(1, S - 37)]
     pad = _pad_mask(B, S, lengths, fmin)
-    full = (O.causal_additive(S, S, fmin)[None, None] + pad[:, None, None, :]).astype(np.float32)  # may be -inf: clamped
+    with np.errstate(over="ignore"):
+        full = (O.causal_additive(S, S, fmin)[None, None] + pad[:, None, None, :]).astype(np.float32)  # may be -inf: clamped
     want = O.attn_core(_np32(q), _np32(k), _np32(v), full_mask=full, clamp_min=True, **SPECS[sm])
     # (a) analytic causal flag + key padding vector
     got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=_spec(ops, sm), causal=True, clamp_min=True,
