@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   int kend_wg = Sk;
   if (P.skip_ok) kend_wg = min(Sk, max(0, qt * 64 + 64 + off));
   const int n_kt = (kend_wg + 63) >> 6;
-  const int T = 2 * n_kt;
+
 
   // ---- LDS-DMA stream, K tiles then V^T tiles, one 1-KiB piece per wave and tile: lane -> (row of the piece, 16-B chunk)
   const signed char* kbase = reinterpret_cast<const signed char*>(P.k) + bh_offset(b, P.ks_b, h, P.ks_h);
@@ -116,34 +116,37 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   const signed char* kcur = kbase;
   const signed char* vcur = vbase;
   const int kstep = 64 * (int)P.ks_s;
-  int nx = 0, nx_slot = 0;
-  auto issue_next = [&]() {
-    const bool isv = nx >= n_kt;
-    const int t = isv ? nx - n_kt : nx;
-    const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(((isv ? R : 0) + nx_slot) * TILEB + wave * 1024));
-    const bool tail = 64 * t + 64 > Sk;  // wave-uniform: only the last tile of a ragged Sk
-    if (isv) {
-      glds16_s(vcur, tail ? voff_tail : voff, slot);
-      vcur += 64;
-    } else {
-      glds16_s(kcur, tail ? koff_tail : koff, slot);
-      kcur += kstep;
-    }
-    ++nx;
-    nx_slot = (nx_slot == R - 1) ? 0 : nx_slot + 1;
-    if (nx == n_kt) nx_slot = 0;  // the V^T ring starts at its slot 0
+  // Round 4: two streams.  K tiles as before (tile t -> K slot t % R, PF ahead).  The V^T tiles are ALL requested at once when the K
+  // phase ends - they land during phase 2, a microsecond and more of pure vector work in which the memory system had nothing to do -
+  // and they all stay resident (V^T tile j -> V slot j for j < R, the freed K slots j - R beyond: n_kt <= 8 <= 2 R - 4), so the V^T
+  // phase has ONE wait + barrier instead of one per tile (it used to run at the pace its tiles arrived: PF = 2 requests in flight).
+  int nk = 0;
+  auto issue_k = [&]() {
+    const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((nk % R) * TILEB + wave * 1024));
+    glds16_s(kcur, (64 * nk + 64 > Sk) ? koff_tail : koff, slot);
+    kcur += kstep;
+    ++nk;
+  };
+  auto v_slot = [&](const int j) { return j < R ? R + j : j - R; };
+  int nv = 0;
+  auto issue_v = [&]() {
+    const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(v_slot(nv) * TILEB + wave * 1024));
+    glds16_s(vcur, (64 * nv + 64 > Sk) ? voff_tail : voff, slot);
+    vcur += 64;
+    ++nv;
   };
 #pragma unroll
   for (int p = 0; p < PF; ++p)
-    if (p < T) issue_next();
-  auto wait_tile = [&](const int i) {  // tile i of the stream has landed: all but the min(PF - 1, T - 1 - i) younger requests of this wave
-    const int younger = min(PF - 1, T - 1 - i);
+    if (p < n_kt) issue_k();
+  auto wait_k = [&](const int i) {  // K tile i has landed: all but the PF - 1 younger requests of this wave (K tiles, then the first V^T tiles)
+    const int younger = min(PF, n_kt) - 1;   // (every step so far has issued one request: the stream is min(PF, n_kt) ahead of tile i)
+    (void)i;
     if (younger >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if (younger == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
-  static_assert(PF <= 4 && PF <= R - 1, "wait_tile's immediates");
+  static_assert(PF <= 4 && PF <= R - 1 && NT / 4 <= 2 * R - 4, "wait_k's immediates; every V^T tile has a slot of its own");
 
   // ---- Q: global -> registers in the B-operand layout (query q0 + c, head dims 16 g ..), and its row sum
   i4 qf;
@@ -182,9 +185,10 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     if (kt < n_kt) {
-      wait_tile(kt);
+      wait_k(kt);
       barrier_mem();
-      if (kt + PF < T) issue_next();
+      if (kt + PF < n_kt) issue_k();
+      else issue_v();   // the K stream has run out: the first PF V^T tiles (V slots: no K slot is touched before the barrier below)
       const unsigned char* tb = lds + (kt % R) * TILEB;
       i4 kf[4], acc[4];
 #pragma unroll
@@ -206,6 +210,9 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
       }
     }
   }
+
+  barrier_mem();   // every wave has read its last K fragments: the K slots are free for V^T tiles R, R + 1
+  while (nv < n_kt) issue_v();
 
   // =========================== phase 2: the chain on the quantiser grid ===========================
   // element (kt, t, r) of lane (c, g) is key 64 kt + 16 g + 4 t + r of query q0 + c.  rel = idx - zp is carried as
@@ -334,11 +341,11 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     if (kt < n_kt) {
-      const int i = n_kt + kt;
-      wait_tile(i);
-      barrier_mem();
-      if (i + PF < T) issue_next();
-      const unsigned char* tb = lds + (R + kt % R) * TILEB;
+      if (kt == 0) {  // every V^T tile of every wave has landed (they were requested before phase 2)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        barrier_mem();
+      }
+      const unsigned char* tb = lds + v_slot(kt) * TILEB;
       const i4 pb = i4{(int)f32_bits(s[kt * 4 + 0][0]), (int)f32_bits(s[kt * 4 + 1][0]), (int)f32_bits(s[kt * 4 + 2][0]), (int)f32_bits(s[kt * 4 + 3][0])};
       i4 vf[DT];
 #pragma unroll
@@ -360,7 +367,10 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   asm volatile("" : "+v"(lane_e));
   const int ce = lane_e & 15, ge = lane_e >> 4;
   constexpr int ROWB = 2 * D;
-  unsigned char* ebase = lds + wave * (16 * ROWB);  // 16-bit output: staged through the (idle) K ring, whole rows stored
+  unsigned char* ebase = lds + wave * (16 * ROWB);  // 16-bit output: staged through K slots 0 and 1, whole rows stored
+  if constexpr (!OUT32) {
+    if (n_kt > R) barrier_mem();  // (those slots hold V^T tiles R, R + 1 of a long row: every wave must have left them)
+  }
   float xs[DT * 4], crel[DUMP ? DT * 4 : 1];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt)
