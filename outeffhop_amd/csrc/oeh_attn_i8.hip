@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   // R slots per ring, PF tiles requested ahead (PF <= R - 1: a slot is refilled only after the barrier that follows its last
   // readers).  PF = 2 (round 3; 4 before): a launch is one burst of every workgroup's requests against HBM, and tiles requested
   // far ahead only delay the tiles every workgroup needs first - same-process: S = 128 0.94, S = 256 0.97, S = 512 0.99 against
-  // PF = 4; PF = 3 in between; PF = 1 exposes the latency (S = 512 +8 %).
+  // PF = 4; PF = 3 in between; PF = 1 exposes the latency (S = 512 +8 %).  (Round 4, with the V^T tiles no longer part of this stream:
+  // PF = 3 for the K tiles alone 0.995 ... 1.02 of PF = 2 - no change.)
   constexpr int R = 6, PF = 2;
   constexpr float RELMASK = -1.0e30f;
   constexpr bool OUT32 = (OUT == IN_F32);
