@@ -56,4 +56,35 @@ case("two-pass INT8 + pad S=704", 8,12,704,64, lambda pad: dict(causal=True, cla
 case("two-pass clip + pad S=704", 8,12,704,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad, softmax=clipsm))
 case("one-pass vanilla + pad S=640", 8,12,640,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad, softmax=ops.SoftmaxSpec(0)))
 case("one-pass full mask S=640", 4,12,640,64, lambda pad: dict(scale_div=8.0, clamp_min=True, full_mask=(pad[:, None, None, :] + torch.zeros(pad.shape[0], 1, 640, 640, device="cuda")).contiguous()))
+# round 4: the INT8-storage core (every V^T tile requested when the K phase ends, resident through the V^T phase: DMA into freed K slots
+# behind one barrier, one wait + barrier for the whole phase), 16-bit output (staged through K slots 0, 1 behind a barrier on 8-tile rows)
+def case_i8(name, B, H, S, out_dtype, causal, padded):
+    global tot
+    g = torch.Generator(device="cuda").manual_seed(1)
+    qi, ki, vi = (torch.randint(0, 256, (B, S, H * 64), device="cuda", generator=g, dtype=torch.int32).to(torch.uint8) for _ in range(3))
+    qc = ops.centre_indices(qi).view(B, S, H, 64).permute(0, 2, 1, 3)
+    kc = ops.centre_indices(ki).view(B, S, H, 64).permute(0, 2, 1, 3)
+    vt = ops.centre_indices(vi).view(B, S, H, 64).permute(0, 2, 3, 1).contiguous()
+    grids = (ops.QuantGrid(0.03, 131.0), ops.QuantGrid(0.03, 120.0), ops.QuantGrid(0.03, 128.0))
+    pad = None
+    if padded:
+        pad = torch.zeros(B, S, device="cuda")
+        for b in range(B): pad[b, int(S * (0.5 + 0.5 * b / B)):] = fmin
+    kw = dict(fq=int8, out_dtype=out_dtype, scale=0.125, causal=causal, clamp_min=causal, mask_min=fmin, key_pad_mask=pad)
+    s2 = torch.cuda.Stream(); q2 = torch.randn(4, 8, 333, 64, device="cuda").half()
+    ref = ops.attn_fwd_i8(qc, kc, vt, grids, **kw).clone()
+    bad = 0
+    for it in range(N):
+        if it % 3 == 0:
+            with torch.cuda.stream(s2):
+                ops.attn_fwd(q2, q2, q2, causal=True, clamp_min=True, mask_min=fmin)
+        if not torch.equal(ops.attn_fwd_i8(qc, kc, vt, grids, **kw), ref): bad += 1
+    print(f"{name:34s}        : {bad} of {N} differ [i8mfma]"); tot += bad
+case_i8("int8 storage causal S=512 f32 out", 16, 12, 512, torch.float32, True, False)
+case_i8("int8 storage causal S=512 f16 out", 16, 12, 512, torch.float16, True, False)
+case_i8("int8 storage pad S=512 bf16 out", 16, 12, 512, torch.bfloat16, False, True)
+case_i8("int8 storage pad S=128 (BERT)", 32, 12, 128, torch.float32, False, True)
+case_i8("int8 storage causal S=448 f16 out", 16, 12, 448, torch.float16, True, True)
+case("two-pass clip + full mask S=640", 4,12,640,64, lambda pad: dict(scale_div=8.0, clamp_min=True, softmax=clipsm, full_mask=(pad[:, None, None, :] + torch.zeros(pad.shape[0], 1, 640, 640, device="cuda")).contiguous()))
+case("two-pass vanilla clip + pad S=704", 8,12,704,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad, softmax=ops.SoftmaxSpec(0, True, -0.003, 1.003)))
 sys.exit(1 if tot else 0)
