@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OEH_ABI_VERSION 5
+#define OEH_ABI_VERSION 6
 
 /* error codes (negative errno style) */
 #define OEH_OK 0
@@ -288,6 +288,34 @@ int oeh_split_pairs(const float* x, void* out_f16, int64_t rows, int32_t K, int6
  * This entry writes the activation side: x (rows, K) fp32 with row stride x_stride_row (elements) -> out_f16 (rows, 3K + 8) fp16,
  * contiguous; K % 8 == 0, 16-byte aligned rows.  Values beyond the fp16 range saturate (as in oeh_split_pairs). */
 int oeh_split_triples(const float* x, void* out_f16, int64_t rows, int32_t K, int64_t x_stride_row, void* stream);
+
+/* The q / k / v projections of a QuantLinear model as ONE matrix-core GEMM with the output quantisers in its epilogue (SURVEY 8f-1;
+ * quantized_opt.py:67-75 q_proj / k_proj / v_proj, quantized_bert.py:236-238 query / key / value: QuantLinear = weight fake-quant +
+ * F.linear + output fake-quant, hijacker.py:78-127): what a library GEMM over the stacked weights followed by three
+ * oeh_quantize_heads_i8 passes computes, without the (B*S, n_seg*E) accumulator ever reaching memory.
+ *   a: the activations (B*S rows, row stride lda elements, 16-byte aligned rows), fp16 - pairs == 0: (rows, K); pairs == 1: (rows, 2K),
+ *      the operand pairs [hi | lo] that oeh_split_pairs writes for an fp32 model;
+ *   w: (n_seg*E, K) fp16, row stride ldw: the QuantLinear weights' INTEGERS (w / weight scale: exact in fp16), the segments' rows
+ *      one after the other; pairs == 1 multiplies the lo half against w * 2^-11, formed in registers (exact on integers);
+ *   bias: (n_seg*E) fp32; segment i covers output columns [i*E, (i+1)*E) and turns the fp32 accumulator into
+ *      value = alpha * acc + bias[column],  c = clamp(rint(value / scale) + zero_point, 0, 255) - 128:
+ *      out  (may be NULL when y is given): int8, (B, S, E) [transpose == 0: q, k] or (B, E/64, 64, S) [transpose == 1: v, keys
+ *           contiguous] - the layouts oeh_attn_fwd takes with dtype OEH_I8; 16-byte aligned;
+ *      y    (optional): the dequantised values scale * (c + 128 - zero_point) as fp32, (B*S, E) with row stride y_stride_row
+ *           elements - a decoder's (k, v) cache.
+ * K % 32 == 0, E % 64 == 0, S % 16 == 0, n_seg in 1..3: OEH_ENOTSUP otherwise.  Same formulas as oeh_quantize_heads_i8; the
+ * accumulation order differs from a library GEMM's, so an index may differ by one step where the value sits on a rounding
+ * boundary to within the fp32 accumulation error (both are fp32-grade: |acc - exact| <~ 1e-6 of the row's scale). */
+typedef struct {
+  float alpha;
+  float scale, zero_point;
+  int8_t* out;
+  float* y;
+  int64_t y_stride_row;
+  int32_t transpose;
+} oeh_proj_seg;
+int oeh_proj_quant_i8(const void* a, int32_t pairs, const void* w, const float* bias, int64_t B, int32_t S, int32_t K, int32_t E, int32_t n_seg,
+                      const oeh_proj_seg* segs, int64_t lda, int64_t ldw, void* stream);
 
 /* library information (host side, no device work) */
 int oeh_abi_version(void);

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OEH_LIB: explicit path of another build of the same library (A/B timing of compiler flags; tools/ only)
 LIB_PATH = os.environ.get("OEH_LIB") or os.path.join(_HERE, "lib", "liboeh_hip.so")
 
-ABI_VERSION = 5  # include/oeh.h: OEH_ABI_VERSION
+ABI_VERSION = 6  # include/oeh.h: OEH_ABI_VERSION
 CALIB_WORK_BYTES = 36864  # include/oeh.h: OEH_CALIB_WORK_BYTES
 OEH_F16, OEH_BF16, OEH_F32, OEH_I8 = 0, 1, 2, 3
 OEH_SOFTMAX_VANILLA, OEH_SOFTMAX_ONE = 0, 1
@@ -59,9 +59,15 @@ class oeh_attn_desc(C.Structure):
     ]
 
 
+class oeh_proj_seg(C.Structure):
+    """include/oeh.h: one column segment (a projection) of oeh_proj_quant_i8."""
+    _fields_ = [("alpha", C.c_float), ("scale", C.c_float), ("zero_point", C.c_float), ("out", C.c_void_p), ("y", C.c_void_p),
+                ("y_stride_row", C.c_int64), ("transpose", C.c_int32)]
+
+
 # every symbol include/oeh.h declares (tests/test_abi.py checks the .so exports exactly these)
 EXPORTS = (
-    "oeh_attn_fwd", "oeh_softmax_rows", "oeh_fake_quant", "oeh_gate_fwd", "oeh_minmax", "oeh_percentile_ema", "oeh_fake_quant_range", "oeh_attn_calibrate", "oeh_quantize_heads_i8", "oeh_split_pairs", "oeh_split_triples",
+    "oeh_attn_fwd", "oeh_softmax_rows", "oeh_fake_quant", "oeh_gate_fwd", "oeh_minmax", "oeh_percentile_ema", "oeh_fake_quant_range", "oeh_attn_calibrate", "oeh_quantize_heads_i8", "oeh_split_pairs", "oeh_split_triples", "oeh_proj_quant_i8",
     "oeh_abi_version", "oeh_build_info", "oeh_strerror", "oeh_attn_variant",
 )
 
@@ -108,6 +114,8 @@ def load() -> C.CDLL:
     lib.oeh_split_pairs.restype = C.c_int
     lib.oeh_split_triples.argtypes = [vp, vp, i64, i32, i64, vp]
     lib.oeh_split_triples.restype = C.c_int
+    lib.oeh_proj_quant_i8.argtypes = [vp, i32, vp, vp, i64, i32, i32, i32, i32, C.POINTER(oeh_proj_seg), i64, i64, vp]
+    lib.oeh_proj_quant_i8.restype = C.c_int
     lib.oeh_abi_version.restype = C.c_int
     lib.oeh_build_info.restype = C.c_char_p
     lib.oeh_strerror.argtypes = [C.c_int]

@@ -2,6 +2,7 @@
 // variant selection and launch.  No allocation, no synchronisation: safe under hipGraph capture.
 #include "../../include/oeh.h"
 #include "../../include/oeh_debug.h"
+#include "oeh_gemm.h"
 #include "oeh_attn_params.h"
 
 #include <cmath>
@@ -576,6 +577,30 @@ int oeh_quantize_heads_i8(const void* x, int8_t* out, void* y, int64_t B, int32_
   f.en = 1; f.scale = scale; f.rscale = 1.0f / scale; f.zp = zero_point; f.qmax = 255.0f; f.lo = -zero_point; f.hi = 255.0f - zero_point;
   return oeh::launch_quantize_heads_i8(x, reinterpret_cast<signed char*>(out), y, B, S, H, x_stride[0], x_stride[1], y != nullptr ? y_stride[0] : 0,
                                        y != nullptr ? y_stride[1] : 0, dtype, f, transpose ? 1 : 0, alpha, bias, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oeh_proj_quant_i8(const void* a, int32_t pairs, const void* w, const float* bias, int64_t B, int32_t S, int32_t K, int32_t E, int32_t n_seg,
+                      const oeh_proj_seg* segs, int64_t lda, int64_t ldw, void* stream) {
+  if (a == nullptr || w == nullptr || bias == nullptr || segs == nullptr || B <= 0 || S <= 0 || K <= 0 || E <= 0 || n_seg < 1 || n_seg > 3) return OEH_EINVAL;
+  if ((K % oeh::kGemmBK) != 0 || (E & 63) != 0 || (S & 15) != 0 || B * (int64_t)S > 0x7fffffffLL) return OEH_ENOTSUP;
+  if (lda < (pairs ? 2 : 1) * (int64_t)K || ldw < K) return OEH_EINVAL;
+  if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w) | (uintptr_t)(lda * 2) | (uintptr_t)(ldw * 2)) & 15) != 0) return OEH_EALIGN;
+  if (B * (int64_t)S * lda * 2 >= 0xffffffffLL || (int64_t)n_seg * E * ldw * 2 >= 0xffffffffLL) return OEH_ENOTSUP;  // (32-bit lane offsets)
+  oeh::GemmParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.a = a; P.w = w; P.bias = bias; P.lda = lda; P.ldw = ldw; P.M = (int)(B * S); P.N = n_seg * E; P.K = K; P.pairs = pairs ? 1 : 0;
+  P.E = E; P.S = S; P.H = E / 64;
+  for (int i = 0; i < n_seg; ++i) {
+    const oeh_proj_seg& g = segs[i];
+    if (g.out == nullptr && g.y == nullptr) return OEH_EINVAL;
+    if (!(g.scale > 0.0f) || g.zero_point < 0.0f || g.zero_point > 255.0f || g.zero_point != std::nearbyint(g.zero_point)) return OEH_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(g.out) & 15) != 0 || (reinterpret_cast<uintptr_t>(g.y) & 3) != 0) return OEH_EALIGN;
+    if (g.y != nullptr && g.y_stride_row < E) return OEH_EINVAL;
+    oeh::GemmSeg& t = P.seg[i];
+    t.alpha = g.alpha; t.out = reinterpret_cast<signed char*>(g.out); t.y = g.y; t.y_ld = g.y_stride_row; t.transpose = g.transpose ? 1 : 0;
+    t.f.en = 1; t.f.scale = g.scale; t.f.rscale = 1.0f / g.scale; t.f.zp = g.zero_point; t.f.qmax = 255.0f; t.f.lo = -g.zero_point; t.f.hi = 255.0f - g.zero_point;
+  }
+  return oeh::launch_gemm(P, reinterpret_cast<hipStream_t>(stream));
 }
 
 int oeh_split_triples(const float* x, void* out_f16, int64_t rows, int32_t K, int64_t x_stride_row, void* stream) {

@@ -1,0 +1,274 @@
+// The q / k / v projections of a QuantLinear model as ONE matrix-core GEMM with the output quantisers in its epilogue (SURVEY 8f-1,
+// VERDICT r3 next #5): x (M, K) fp32 carried as fp16 operand pairs [hi | lo 2^11] (oeh_split_pairs), the three QuantLinear weight
+// matrices side by side as their 8-bit integers in fp16 (N = 3 E rows of K, exact), fp32 accumulation:
+//     acc[m][n] = sum_k hi[m][k] W[n][k] + sum_k lo[m][k] (W[n][k] 2^-11)
+// and, in the epilogue, per column segment (q | k | v): value = alpha acc + bias[n], the centred 8-bit index of the segment's
+// quantiser in the layout the INT8-storage attention core reads (q, k: (B, S, E) int8; v: (B, H, 64, S) int8), and optionally the
+// dequantised values (the decoder's (k, v) cache) - what the library GEMM + three `oeh_quantize_heads_i8` passes did, without the
+// (M, N) fp32 accumulator ever reaching memory.
+//
+// Shape of the kernel (gfx950): 128 x 288 output tile per workgroup of 4 waves (2 x 2: 64 x 144 per wave = 4 x 9 accumulator tiles of
+// v_mfma_f32_16x16x32_f16, 144 registers), K in steps of 32: one LDS slot holds hi (128 rows x 64 B), lo (the same) and W (288 rows x
+// 64 B) = 34 KB, filled by LDS-DMA (global_load_lds_dwordx4, 34 pieces of 1 KB over the 4 waves), two slots, one barrier per step; two
+// workgroups per CU (136 KB of LDS, 8 waves), which at M = 8192, N = 2304 is every workgroup of the launch resident at once
+// (64 x 8 = 512).  Per step and wave: 17 ds_read_b128 (4 hi + 4 lo + 9 W fragments), 36 v_pk_mul_f16 (W 2^-11: exact, the integers
+// are >= 1 in magnitude) and 72 MFMAs.  LDS image: rows of 64 B, 16-byte chunk c of row r stored at chunk c ^ ((r >> 2) & 3): the 16
+// lanes of one fragment read (rows r .. r + 15, one chunk) hit 16 different 16-byte bank groups; the DMA writes whole kilobytes and
+// applies the swizzle to its SOURCE address.
+#include "../../include/oeh.h"
+#include "oeh_common.h"
+#include "oeh_gemm.h"
+
+#include <cstdlib>
+
+namespace oeh {
+
+constexpr int GBM = 128, GBN = 288, GBK = kGemmBK, GROWB = 64;
+constexpr int G_AHI = 0, G_ALO = GBM * GROWB, G_W = 2 * GBM * GROWB, G_SLOT = G_W + GBN * GROWB;  // 34816
+constexpr int G_PITCH_C = GBM + 16, G_IMG_C = GBM * GBN, G_IMGS = G_IMG_C + GBN * G_PITCH_C;              // the epilogue's byte images: 36864 + 41472
+constexpr int G_LDS = 2 * G_SLOT > G_IMGS ? 2 * G_SLOT : G_IMGS;                                           // 78336: two workgroups per CU
+
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+
+template <bool PAIRS, bool RAW>
+__global__ __launch_bounds__(256, 2) void oeh_gemm_kernel(const GemmParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+  // tile of this workgroup: the eight XCDs (block id % 8) take contiguous ranges of row tiles, all column tiles of a row tile on one XCD
+  int mi, ni;
+  {
+    const int id = blockIdx.x;
+    if ((P.MT & 7) == 0) {
+      const int xcd = id & 7, s = id >> 3;
+      mi = xcd * (P.MT >> 3) + s / P.NT;
+      ni = s % P.NT;
+    } else {
+      mi = id / P.NT;
+      ni = id % P.NT;
+    }
+  }
+  const int m0 = mi * GBM, n0 = ni * GBN;
+  const int T = (P.dbg & 2) ? 2 : P.K / GBK;
+
+  // ---- LDS-DMA: piece p (1 KB = 16 rows x 64 B); lane -> row p * 16 + (lane >> 2), stored chunk lane & 3 = logical chunk ^ ((row >> 2) & 3)
+  const unsigned lds_base = lds_offset(lds);
+  const int prow = lane >> 2;
+  const int pchunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const unsigned char* ab = reinterpret_cast<const unsigned char*>(P.a);
+  const unsigned char* wb = reinterpret_cast<const unsigned char*>(P.w);
+  constexpr int NPA = GBM / 16, NPW = GBN / 16;                 // 8, 18
+  constexpr int NP = (PAIRS ? 2 * NPA : NPA) + NPW;             // 34 | 26
+  // piece p = 4 q + wave: q < QA -> hi rows, q < QL -> lo rows, else W rows (the kind of a piece depends on q only: 8 | 8 | 18 pieces).
+  // Lane byte offsets are constant over the K loop (rows clamped to the matrix: tails compute on repeated rows and are not stored); the
+  // scalar bases advance by 64 B per step.
+  constexpr int QA = NPA / 4, QL = PAIRS ? 2 * QA : QA, NQ = (NP + 3) / 4;
+  unsigned voff[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int p = 4 * q + wave;
+    if (q < QL) {
+      const int r = min(m0 + (p - (q < QA ? 0 : NPA)) * 16 + prow, P.M - 1);
+      voff[q] = (unsigned)(((long)r * P.lda) * 2 + pchunk * 16);
+    } else {
+      const int r = min(n0 + (p - QL * 4) * 16 + prow, P.N - 1);
+      voff[q] = (unsigned)(((long)r * P.ldw) * 2 + pchunk * 16);
+    }
+  }
+  auto issue_q = [&](int t, int q) {
+    const unsigned slot = lds_base + (unsigned)((t & 1) * G_SLOT);
+    const long kb = (long)t * (GBK * 2);
+    const int p = 4 * q + wave;
+    if (q < QA) glds16_s(ab + kb, voff[q], slot + G_AHI + p * 1024);
+    else if (q < QL) glds16_s(ab + (long)P.K * 2 + kb, voff[q], slot + G_ALO + (p - NPA) * 1024);
+    else if (q < NQ - 1 || wave < NP - 4 * (NQ - 1)) glds16_s(wb + kb, voff[q], slot + G_W + (p - QL * 4) * 1024);
+  };
+  auto issue = [&](int t) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) issue_q(t, q);
+  };
+
+  // ---- fragment addresses (constant per lane up to the slot)
+  const unsigned swz = (unsigned)((lq ^ (l15 >> 2)) << 4);
+  const unsigned a_off = (unsigned)((64 * wm + l15) * GROWB) + swz;
+  const unsigned w_off = (unsigned)(G_W + (144 * wn + l15) * GROWB) + swz;
+
+  f4 acc[4][9];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  for (int t = 0; t < T; ++t) {
+    if (!(P.dbg & 8)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      barrier_mem();
+    }
+    const bool more = t + 1 < T && !((P.dbg & 4) && t >= 1);
+    if ((P.dbg & 64) && more) issue(t + 1);
+    const unsigned char* sl = lds + (t & 1) * G_SLOT;
+    h8v ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const h8v*>(sl + G_AHI + a_off + i * 16 * GROWB);
+      if constexpr (PAIRS) al[i] = *reinterpret_cast<const h8v*>(sl + G_ALO + a_off + i * 16 * GROWB);
+    }
+    // every fragment of the step is requested before the first MFMA (17 ds_read_b128 in flight: the matrix core never waits for
+    // LDS behind the first group); the compiler's counted lgkmcnt waits release the groups in order
+    h8v bf[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) bf[j] = *reinterpret_cast<const h8v*>(sl + w_off + j * 16 * GROWB);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bf[j], acc[i][j], 0, 0, 0);
+      if constexpr (PAIRS) {
+        const h8v bs = bf[j] * (_Float16)0.00048828125f;  // 2^-11: exact on the 8-bit integers
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bs, acc[i][j], 0, 0, 0);
+      }
+      // the next tile's LDS-DMA pieces go out between the first MFMA groups (two per group): the matrix core has work queued while the
+      // wave spends its issue slots on them, and every piece is under way before the middle of the step
+      if (2 * j < NQ) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(P.dbg & 64) && more) {
+          issue_q(t + 1, 2 * j);
+          if (2 * j + 1 < NQ) issue_q(t + 1, 2 * j + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // ---- epilogue.  C[row 16 i + 4 lq + r][col 16 j + l15]
+  if (P.dbg & 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
+  if constexpr (RAW) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const int n = n0 + 144 * wn + 16 * j + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + 64 * wm + 16 * i + 4 * lq + r;
+          if (m < P.M && n < P.N) P.c[(long)m * P.ldc + n] = acc[i][j][r];
+        }
+      }
+  } else {
+    // per accumulator column tile (16 columns: inside one segment and one head): value -> index byte (+ dequantised value).
+    // The index bytes go through LDS so that they leave as whole 16-byte pieces of contiguous output: columns of a plain segment
+    // (q, k) as a [row][288] image, columns of a transposed segment (v) as a [column][128 rows] image (pitch 144 B).
+    barrier_mem();  // the slots are free: every wave is past its last fragment read
+    unsigned char* img_r = lds;
+    unsigned char* img_c = lds + G_IMG_C;
+    const int c4 = l15 & 3, a4 = l15 >> 2;
+    const unsigned sel_t = (unsigned)c4 | ((unsigned)(4 + c4) << 8);   // v_perm_b32 selector: byte c4 of the second / of the first source
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int nl = 144 * wn + 16 * j;              // tile-local first column (wave-uniform)
+      const int n = n0 + nl;
+      if (n < P.N) {
+        const int sg = n / P.E;
+        const GemmSeg& g = P.seg[sg];
+        const FqP f = g.f;
+        const float alpha = g.alpha;
+        const float bia = P.bias[n + l15];
+        float* yp = g.y != nullptr ? g.y + (long)(m0 + 64 * wm + 4 * lq) * g.y_ld + (n - sg * P.E) + l15 : nullptr;
+        const long y_ld = g.y_ld;
+        const bool idx_r = g.out != nullptr && !g.transpose, idx_c = g.out != nullptr && g.transpose;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned word = 0;
+          const int rl = 64 * wm + 16 * i + 4 * lq;  // tile-local first row of the lane's four
+          if (yp != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float rel = fq_rel(__builtin_fmaf(acc[i][j][r], alpha, bia), f);
+              word = __builtin_amdgcn_cvt_pk_u8_f32(rel + f.zp, r, word);
+              if (m0 + rl + r < P.M && !(P.dbg & 16)) yp[(long)(16 * i + r) * y_ld] = f.scale * rel;
+            }
+          } else {
+            // (no values wanted: the conversion's saturation to [0, 255] is the clamp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              word = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fq_quot(__builtin_fmaf(acc[i][j][r], alpha, bia), f)) + f.zp, r, word);
+          }
+          word ^= 0x80808080u;
+          if (idx_c) *reinterpret_cast<unsigned*>(img_c + (nl + l15) * G_PITCH_C + rl) = word;
+          if (idx_r) {
+            // 4 x 4 byte transpose inside the quad of lanes (columns 4 a4 .. 4 a4 + 3): lane c4 ends with row rl + c4, four columns
+            const unsigned t0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0x00, 0xf, 0xf, false);
+            const unsigned t1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0x55, 0xf, 0xf, false);
+            const unsigned t2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0xaa, 0xf, 0xf, false);
+            const unsigned t3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0xff, 0xf, 0xf, false);
+            const unsigned lo2 = __builtin_amdgcn_perm(t1, t0, sel_t), hi2 = __builtin_amdgcn_perm(t3, t2, sel_t);
+            *reinterpret_cast<unsigned*>(img_r + (rl + c4) * GBN + nl + 4 * a4) = __builtin_amdgcn_perm(hi2, lo2, 0x05040100u);
+          }
+        }
+      }
+    }
+    barrier_mem();
+    if (P.dbg & 32) return;
+    // plain segments: 128 rows x 18 pieces, consecutive threads on consecutive pieces of a row
+    for (int e = tid; e < GBM * (GBN / 16); e += 256) {
+      const int row = e / (GBN / 16), c16 = e - row * (GBN / 16);
+      const int n = n0 + 16 * c16, m = m0 + row;
+      if (n < P.N && m < P.M) {
+        const int sg = n / P.E;
+        const GemmSeg& g = P.seg[sg];
+        if (g.out != nullptr && !g.transpose)
+          *reinterpret_cast<u4*>(g.out + (long)m * P.E + (n - sg * P.E)) = *reinterpret_cast<const u4*>(img_r + row * GBN + 16 * c16);
+      }
+    }
+    // transposed segments: 288 columns x 8 pieces of 16 rows (= 16 keys of one batch element: S % 16 == 0)
+    for (int e = tid; e < GBN * (GBM / 16); e += 256) {
+      const int col = e >> 3, pc = e & 7;
+      const int n = n0 + col, m = m0 + 16 * pc;
+      if (n < P.N && m < P.M) {
+        const int sg = n / P.E;
+        const GemmSeg& g = P.seg[sg];
+        if (g.out != nullptr && g.transpose) {
+          const int ns = n - sg * P.E;
+          const int bidx = m / P.S, srow = m - bidx * P.S;
+          *reinterpret_cast<u4*>(g.out + (((long)bidx * P.H + (ns >> 6)) * 64 + (ns & 63)) * P.S + srow) =
+              *reinterpret_cast<const u4*>(img_c + col * G_PITCH_C + 16 * pc);
+        }
+      }
+    }
+  }
+}
+
+template <bool PAIRS, bool RAW>
+static int launch_gemm_t(const GemmParams& P, hipStream_t st) {
+  static bool attr = false;
+  const int ldsb = RAW ? 2 * G_SLOT : G_LDS;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&oeh_gemm_kernel<PAIRS, RAW>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return -5;
+    attr = true;
+  }
+  hipLaunchKernelGGL((oeh_gemm_kernel<PAIRS, RAW>), dim3(P.MT * P.NT), dim3(256), ldsb, st, P);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int launch_gemm(const GemmParams& P0, hipStream_t st) {
+  GemmParams P = P0;
+  { static const int dbg = [] { const char* e = getenv("OEH_GEMM_DBG"); return e ? atoi(e) : 0; }(); P.dbg = dbg; }
+  P.MT = (P.M + GBM - 1) / GBM;
+  P.NT = (P.N + GBN - 1) / GBN;
+  if (P.c != nullptr) return P.pairs ? launch_gemm_t<true, true>(P, st) : launch_gemm_t<false, true>(P, st);
+  return P.pairs ? launch_gemm_t<true, false>(P, st) : launch_gemm_t<false, false>(P, st);
+}
+
+}  // namespace oeh
+

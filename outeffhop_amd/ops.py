@@ -377,6 +377,41 @@ def quantize_heads_i8(x: torch.Tensor, spec: "FakeQuantSpec", H: int, transpose:
     return (idx, y) if want_values else idx
 
 
+def proj_quant_i8(a: torch.Tensor, w_int: torch.Tensor, bias: torch.Tensor, B: int, S: int, segs, *, pairs: bool):
+    """The q / k / v projections of a QuantLinear model as ONE GEMM with the output quantisers in its epilogue (`oeh_proj_quant_i8`):
+    a (B*S, K) fp16 activations or (B*S, 2K) operand pairs of an fp32 model (`split_pairs`), w_int (n*E, K) fp16 = the weights'
+    integers, the segments one after the other, bias (n*E) fp32; `segs` = one (alpha, FakeQuantSpec, transpose, want_values) per
+    segment.  Returns per segment what `quantize_heads_i8` returns: the centred int8 indices as a logical (B,H,S,64) view of
+    (B,S,E), or the contiguous (B,H,64,S) tensor with `transpose`, and with `want_values` the pair (indices, values (B,S,E) fp32)."""
+    dev = _need_gpu(a, w_int, bias)
+    K = w_int.shape[1]
+    n = len(segs)
+    if a.dtype != torch.float16 or w_int.dtype != torch.float16 or bias.dtype != torch.float32 or a.dim() != 2 or w_int.dim() != 2:
+        raise ValueError("a, w_int must be 2-D fp16 and bias fp32")
+    if a.shape != (B * S, (2 if pairs else 1) * K) or w_int.shape[0] % n != 0 or bias.numel() != w_int.shape[0] or not bias.is_contiguous():
+        raise ValueError("shapes: a (B*S, K or 2K), w_int (n*E, K), bias (n*E)")
+    if a.stride(1) != 1 or w_int.stride(1) != 1:
+        raise ValueError("a and w_int must have contiguous rows")
+    E = w_int.shape[0] // n
+    H = E // 64
+    arr = (_lib.oeh_proj_seg * n)()
+    keep, res = [], []
+    for i, (alpha, spec, transpose, want_values) in enumerate(segs):
+        if spec.qmax != 255.0:
+            raise ValueError("the output grids must be 8-bit")
+        out = torch.empty((B, H, 64, S) if transpose else (B, S, E), dtype=torch.int8, device=a.device)
+        y = torch.empty((B, S, E), dtype=torch.float32, device=a.device) if want_values else None
+        keep.append((out, y))
+        arr[i].alpha, arr[i].scale, arr[i].zero_point = float(alpha), float(spec.scale), float(spec.zero_point)
+        arr[i].out, arr[i].y, arr[i].y_stride_row, arr[i].transpose = _ptr(out), _ptr(y), E, int(bool(transpose))
+        idx = out if transpose else out.view(B, S, H, 64).permute(0, 2, 1, 3)
+        res.append((idx, y) if want_values else idx)
+    with _on_device(dev):
+        rc = _lib.load().oeh_proj_quant_i8(_ptr(a), int(bool(pairs)), _ptr(w_int), _ptr(bias), B, S, K, E, n, arr, a.stride(0), w_int.stride(0), _stream())
+    _lib.check(rc, "oeh_proj_quant_i8")
+    return res
+
+
 def attn_fwd_i8(q: torch.Tensor, k: torch.Tensor, v_t: torch.Tensor, grids, *, fq: AttnFakeQuant, out_dtype=torch.float16,
                 softmax: SoftmaxSpec = SoftmaxSpec(), scale: float = 1.0, scale_div: float = 0.0, causal: bool = False, clamp_min: bool = False,
                 mask_min: Optional[float] = None, gate: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,

@@ -550,6 +550,20 @@ class QuantLinear(QuantizedModule, nn.Linear):
             self.__dict__["_pair_cache"] = hit
         return hit[1], hit[2]
 
+    def _int_weights(self):
+        """The quantised weight's integers Iw (N, K) as fp16 (exact) and the fp32 weight scale, cached - the weight operand of
+        `ops.proj_quant_i8`, which forms Iw * 2^-11 for the lo half of the operand pairs in registers."""
+        qz = self.weight_quantizer.quantizer
+        key = (self.weight.data_ptr(), self.weight._version, qz._delta.data_ptr(), qz._delta._version)
+        hit = self.__dict__.get("_int_cache")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                iw = qz.to_integer_forward(self.weight.detach()).to(torch.float16).contiguous()
+                s32 = float(np.float32(float(qz.scale)))
+            hit = (key, iw, s32)
+            self.__dict__["_int_cache"] = hit
+        return hit[1], hit[2]
+
     def pair_gemm_ok(self, x) -> bool:
         """fp32 inference on the GPU with per-tensor symmetric <= 8-bit weights: the operand-pair GEMM applies."""
         qz = self.weight_quantizer.quantizer
@@ -766,6 +780,19 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
             self.__dict__["_qkv_pair_cache"] = hit
         return hit[1], [p[1] for p in parts]
 
+    def _qkv_int_weights(self, lins):
+        """The three projections' integer weights one after the other, (3E, K) fp16, their biases (3E) fp32 and their fp32 weight
+        scales (`ops.proj_quant_i8`); rebuilt when a weight, a weight range or a bias changed."""
+        parts = [m._int_weights() for m in lins]
+        bkey = tuple((m.bias.data_ptr(), m.bias._version) for m in lins)
+        hit = self.__dict__.get("_qkv_int_cache")
+        if hit is None or hit[1] != bkey or any(a is not b for a, (b, _) in zip(hit[0], parts)):
+            with torch.no_grad():
+                hit = (tuple(p[0] for p in parts), bkey, torch.cat([p[0] for p in parts], dim=0).contiguous(),
+                       torch.cat([m.bias.detach().float() for m in lins]).contiguous())
+            self.__dict__["_qkv_int_cache"] = hit
+        return hit[2], hit[3], [p[1] for p in parts]
+
     def _int8_storage_core(self, hidden_states, lins, H, head_dim, *, scale, scale_div, causal, padvec, mask_min, gate, fq, want_values,
                            consumer=None):
         """the q/k/v projections are QuantLinear - their outputs ARE 8-bit indices on calibrated grids
@@ -796,7 +823,20 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
         E = H * head_dim
         outs, grids = [], []
         pairs, acc3 = None, None
-        if all(m.pair_gemm_ok(hidden_states) and m.bias is not None for m in lins):
+        all_pairs = all(m.pair_gemm_ok(hidden_states) and m.bias is not None for m in lins)
+        K_in = hidden_states.shape[-1]
+        if (FUSED_PROJ and all_pairs and K_in % 32 == 0 and all(m.in_features == K_in and m.out_features == E for m in lins)
+                and all(type(m.activation_quantizer.quantizer) is AsymmetricUniformQuantizer for m in lins)):
+            # fp32 model, ONE kernel: the pair GEMM against the three integer weight matrices with weight scale, bias and the three output
+            # quantisers in its epilogue (`oeh_proj_quant_i8`) - the (B*T, 3E) accumulator never reaches memory
+            pairs = ops.split_pairs(hidden_states.reshape(-1, K_in))
+            w3, b3, scales3 = self._qkv_int_weights(lins)
+            specs = [m.activation_quantizer.quantizer.spec() for m in lins]
+            outs = ops.proj_quant_i8(pairs, w3, b3, bsz, tgt_len, [(scales3[n_], specs[n_], n_ == 2, n_ > 0 and want_values) for n_ in range(3)], pairs=True)
+            grids = [ops.QuantGrid.of(sp) for sp in specs]
+            self.__dict__["_fused_proj_calls"] = self.__dict__.get("_fused_proj_calls", 0) + 1  # (tests: which path ran)
+            lins = ()
+        elif all_pairs:
             # fp32 model: the input as fp16 operand pairs, split once, and ONE fp16 GEMM against the three integer weight
             # matrices side by side; each projection's weight scale and bias are folded into its quantiser pass
             pairs = ops.split_pairs(hidden_states.reshape(-1, hidden_states.shape[-1]))
@@ -1012,6 +1052,9 @@ FUSED_CALIBRATION = True
 # OPT's out_proj on the context quantiser's INTEGERS (ops ... ctx_emit_index + QuantLinear.linear_index): one 16-bit GEMM of
 # integers instead of the split pass + the operand-pair GEMM.  False: the core writes float values, out_proj runs as any QuantLinear.
 INDEX_GEMM = True
+# The q / k / v projections of the INT8-storage path as ONE GEMM with the output quantisers in its epilogue (ops.proj_quant_i8;
+# include/oeh.h: oeh_proj_quant_i8).  False: the library pair GEMM + three `oeh_quantize_heads_i8` passes (tests compare the two).
+FUSED_PROJ = True
 # The INT8-storage attention core (integer matrix cores) is used by QuantizedOPTAttentionWithExtras whenever it applies;
 # False: always the fake-quant kernels on float values (tests compare the two).
 INT8_STORAGE = True

@@ -36,7 +36,7 @@ def test_library_loads_and_exports_every_symbol():
     if out is not None and out.returncode == 0:
         exported = {ln.split()[-1] for ln in out.stdout.splitlines() if " T " in ln}
         assert set(_declared()) <= exported
-    assert lib.oeh_abi_version() == 5
+    assert lib.oeh_abi_version() == 6
     assert b"gfx950" in lib.oeh_build_info()
     assert lib.oeh_strerror(-22) == b"invalid argument"
 
@@ -57,6 +57,12 @@ def test_argument_validation_without_gpu():
     assert lib.oeh_fake_quant(one, one, None, 4, 0, 0.0, 0.0, 255.0, None) == -22  # scale must be > 0
     assert lib.oeh_fake_quant(one, one, one, 4, 0, 1.0, 0.0, 1023.0, None) == -95  # uint8 dump of a 10-bit grid
     assert lib.oeh_percentile_ema(one, 0, 2, 0.001, 99.999, 0.9, 1, one, one, None) == -22  # empty tensor
+    segs = (_lib.oeh_proj_seg * 3)()
+    assert lib.oeh_proj_quant_i8(one, 1, one, one, 2, 64, 768, 768, 3, None, 1536, 768, None) == -22  # no segments
+    assert lib.oeh_proj_quant_i8(one, 1, one, one, 2, 64, 772, 768, 3, segs, 1544, 772, None) == -95  # K % 32
+    assert lib.oeh_proj_quant_i8(one, 1, one, one, 2, 60, 768, 768, 3, segs, 1536, 768, None) == -95  # S % 16
+    assert lib.oeh_proj_quant_i8(one, 1, one, one, 2, 64, 768, 768, 3, segs, 768, 768, None) == -22  # pairs need lda >= 2K
+    assert lib.oeh_proj_quant_i8(one, 1, one, one, 2, 64, 768, 768, 3, segs, 1536, 768, None) == -22  # a segment with neither out nor y
     assert lib.oeh_percentile_ema(one, 8, 2, 0.001, 100.5, 0.9, 1, one, one, None) == -22  # percent out of range
     assert lib.oeh_percentile_ema(one, 8, 2, 0.001, 99.999, 0.9, 1, C.c_void_p(20), one, None) == -14  # state not 8-byte aligned
     assert lib.oeh_fake_quant_range(one, one, 8, 2, None, 8, 1e-8, None) == -22

@@ -459,7 +459,10 @@ def test_opt_consecutive_batches_with_different_padding(oa, quantised):
             err = (fused - seen).abs()
             steps, off = float(err.max()) / step, float((err > 0.5 * step).float().mean())
             print(f"quantised OPT, batch {trial}: fused vs observable path max {steps:.2f} steps, {off:.2e} of the outputs more than half a step apart")
-            assert steps <= 1.05 and off <= 1e-3, (trial, steps, off)  # measured: 0.00 steps, 0 outputs apart
+            # (the observable path's projections accumulate in the library GEMM's order, the fused path's in ops.proj_quant_i8's: a
+            # projection value on a rounding boundary to within the fp32 accumulation error lands one step apart - a few in 10^5 -
+            # and moves the outputs of its token by at most a step; measured: 0 ... 1.2e-3 of the outputs, never more than 1 step)
+            assert steps <= 1.05 and off <= 5e-3, (trial, steps, off)
         else:
             _close(fused, seen.cpu().numpy(), f"batch {trial} fused vs observable", tol)
             # the reference op chain on the module's own projections
@@ -544,7 +547,11 @@ def test_quantised_opt_uses_the_int8_storage_core(oa, monkeypatch):
     for a, b_ in ((out8, outf), (out8n, outfn)):
         err = (a - b_).abs()
         assert float(err.max()) <= 2.05 * step and float((err > 0.5 * step).float().mean()) < 5e-3, (float(err.max()), step)
-    assert torch.equal(past8[0], pastf[0]) and torch.equal(past8[1], pastf[1])
+    # (the integer path's projections accumulate in their own order - ops.proj_quant_i8 - so a value on a rounding boundary may land
+    # one step away from the float path's: rare, never more than one step of the projection's grid)
+    for n_, lin in ((0, qm.k_proj), (1, qm.v_proj)):
+        dp = (past8[n_] - pastf[n_]).abs()
+        assert float(dp.max()) <= 1.001 * float(lin.activation_quantizer.quantizer.delta) and float((dp > 0).float().mean()) < 1e-4
     # a batch with padded keys (causal + finfo.min columns) runs the integer core too (its key-padding variant), same outputs
     # as the fake-quant kernels on floats up to rare single steps; a mask that is not causal + padding does not
     padded = _decoder_mask(B, T, [T, T - 5, T - 40], torch.float32, dev)
@@ -561,6 +568,42 @@ def test_quantised_opt_uses_the_int8_storage_core(oa, monkeypatch):
         assert len(calls) == 3
     err = (outp8 - outpf).abs()
     assert float(err.max()) <= 2.05 * step and float((err > 0.5 * step).float().mean()) < 5e-3, (float(err.max()), step)
+
+
+def test_quantised_modules_fuse_the_projections_into_one_gemm_with_quantiser_epilogue(oa, monkeypatch):
+    """SURVEY 8f-1 / VERDICT r3 next #5: on the INT8-storage path the three QuantLinear projections (quantized_opt.py:67-75,
+    quantized_bert.py:236-238) run as ONE kernel - pair GEMM, weight scale, bias, the three 8-bit output quantisers
+    (`ops.proj_quant_i8`); same module outputs and (k, v) cache as with the library GEMM + three quantiser passes up to rare single
+    steps (a value on a rounding boundary to within the fp32 accumulation error)."""
+    from outeffhop_amd import ops, quantization as Q
+
+    torch.manual_seed(23)
+    dev = torch.device("cuda:0")
+    B, T, E, H = 2, 128, 768, 12
+    org = oa.OPTAttentionWithExtras(E, H, is_decoder=True, softmax_fn=oa.SOFTMAX_MAPPING["softmax1"]).to(dev).eval()
+    qm = oa.QuantizedOPTAttentionWithExtras(org, **_qparams(oa)).to(dev).eval()
+    qm.set_quant_state(weight_quant=True, act_quant=True)
+    mask = _decoder_mask(B, T, [T] * B, torch.float32, dev)
+    with torch.no_grad():
+        for _ in range(3):
+            qm(torch.randn(B, T, E, device=dev), attention_mask=mask)
+        qm.fix_ranges()
+        x = torch.randn(B, T, E, device=dev)
+        calls = []
+        real = ops.proj_quant_i8
+        monkeypatch.setattr(ops, "proj_quant_i8", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        out1, _, past1 = qm(x, attention_mask=mask)
+        assert len(calls) == 1 and qm.__dict__.get("_fused_proj_calls", 0) == 1 and qm.__dict__.get("_i8_calls", 0) >= 1
+        monkeypatch.setattr(Q, "FUSED_PROJ", False)
+        out0, _, past0 = qm(x, attention_mask=mask)
+        assert len(calls) == 1
+    step = float(qm.out_proj.activation_quantizer.quantizer.delta)
+    err = (out1 - out0).abs()
+    print(f"quantised OPT, fused projections vs library GEMM + quantiser passes: max {float(err.max()) / step:.2f} steps, {float((err > 0.5 * step).float().mean()):.2e} of the outputs apart")
+    assert float(err.max()) <= 2.05 * step and float((err > 0.5 * step).float().mean()) < 2e-3
+    for n_, lin in ((0, qm.k_proj), (1, qm.v_proj)):
+        dp = (past1[n_] - past0[n_]).abs()
+        assert float(dp.max()) <= 1.001 * float(lin.activation_quantizer.quantizer.delta) and float((dp > 0).float().mean()) < 1e-4
 
 
 def test_quantised_bert_uses_the_int8_storage_core(oa, monkeypatch):

@@ -1,0 +1,94 @@
+"""`oeh_proj_quant_i8` - the q / k / v projections of a QuantLinear model as ONE GEMM with the output quantisers in its epilogue
+(quantized_opt.py:67-75, quantized_bert.py:236-238, hijacker.py:78-127) - against the exact arithmetic: float64
+products of the same operands, the reference's quantiser formula (uniform_quantizers.py:114-148: clamp(round(x / scale) +
+zero_point, 0, 255)), and against the path it replaces (library pair GEMM + `oeh_quantize_heads_i8`)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _exact_indices(v64, spec, B, S, H, transpose):
+    idx = (torch.clamp(torch.round(v64 / float(spec.scale)) + spec.zero_point, 0, 255) - 128).to(torch.int32).view(B, S, H, 64).permute(0, 2, 1, 3)
+    return (idx.permute(0, 1, 3, 2) if transpose else idx).contiguous()
+
+
+def _grid(v64):
+    lo, hi = v64.min().item() * 0.9, v64.max().item() * 0.9  # (a little clipping at both ends)
+    sc = np.float32((hi - lo) / 255.0)
+    return float(sc), float(np.clip(np.rint(-lo / sc), 0, 255))
+
+
+@pytest.mark.parametrize("B,S,H,K,want", [(16, 512, 12, 768, True), (4, 128, 12, 768, False), (3, 48, 2, 64, True), (5, 80, 12, 768, True), (2, 16, 1, 32, True),
+                                          (7, 144, 5, 320, False)])
+def test_pair_gemm_with_quantiser_epilogue_vs_exact_arithmetic(B, S, H, K, want):
+    """fp32 activations as operand pairs: every index within one step of the exact one and all but a few in 10^5 equal to it
+    (the value sits on a rounding boundary to within the fp32 accumulation error: the library GEMM + quantiser pass it replaces
+    shows the same rate), the written values are scale * (index - zero_point) exactly, all layouts, ragged tiles."""
+    from outeffhop_amd import ops
+
+    torch.manual_seed(B * 1000 + S)
+    E, M = H * 64, B * S
+    x = torch.randn(B, S, K, device="cuda")
+    x[..., ::37] *= 30.0
+    wi = torch.randint(-128, 128, (3 * E, K), device="cuda").to(torch.float16)
+    bias = torch.randn(3 * E, device="cuda") * 0.1
+    alphas = [0.003, 0.0025, 0.002]
+    pairs = ops.split_pairs(x.view(M, K))
+    ref64 = x.view(M, K).double() @ wi.double().t()
+    vals = [ref64[:, n * E:(n + 1) * E] * alphas[n] + bias[n * E:(n + 1) * E].double() for n in range(3)]
+    specs = [ops.FakeQuantSpec(*_grid(v)) for v in vals]
+    new = ops.proj_quant_i8(pairs, wi, bias, B, S, [(alphas[n], specs[n], n == 2, n > 0 and want) for n in range(3)], pairs=True)
+    ww3 = torch.cat([wi, wi * 2.0 ** -11], dim=1).t().contiguous()
+    acc3 = torch.mm(pairs, ww3, out_dtype=torch.float32).view(B, S, 3 * E)
+    for n in range(3):
+        idx, y = new[n] if (n > 0 and want) else (new[n], None)
+        assert idx.shape == ((B, H, 64, S) if n == 2 else (B, H, S, 64)) and idx.dtype == torch.int8
+        got = idx.contiguous().to(torch.int32)
+        ex = _exact_indices(vals[n], specs[n], B, S, H, n == 2)
+        d = (got - ex).abs()
+        old = ops.quantize_heads_i8(acc3[..., n * E:(n + 1) * E], specs[n], H, transpose=(n == 2), alpha=alphas[n], bias=bias[n * E:(n + 1) * E].contiguous())
+        d_old = (old.contiguous().to(torch.int32) - ex).abs()
+        rate, rate_old = float((d != 0).float().mean()), float((d_old != 0).float().mean())
+        print(f"B={B} S={S} H={H} K={K} [{'qkv'[n]}]: index != exact {rate:.1e} (library GEMM + quantiser pass: {rate_old:.1e}), max {int(d.max())} step")
+        assert int(d.max()) <= 1 and rate <= max(3e-5, 3.0 * rate_old)
+        if y is not None:
+            rows = got.permute(0, 1, 3, 2) if n == 2 else got          # (B, H, S, 64)
+            want_y = np.float32(specs[n].scale) * (rows.permute(0, 2, 1, 3).reshape(B, S, E).float() + 128.0 - specs[n].zero_point)
+            assert y.shape == (B, S, E) and y.dtype == torch.float32 and torch.equal(y, want_y)
+
+
+@pytest.mark.parametrize("pairs", [False, True])
+def test_projection_gemm_is_exact_on_exactly_representable_sums(pairs):
+    """Small integers on both sides: every partial sum is an integer below 2^24, so any accumulation order gives the same fp32
+    accumulator and the indices must equal the exact ones bit for bit (fp16 activations, and operand pairs of the same values)."""
+    from outeffhop_amd import ops
+
+    torch.manual_seed(5)
+    B, S, H, K = 3, 160, 3, 96
+    E, M = H * 64, B * S
+    xi = torch.randint(-40, 41, (M, K), device="cuda")
+    wi = torch.randint(-128, 128, (3 * E, K), device="cuda").to(torch.float16)
+    bias = torch.randint(-50, 51, (3 * E,), device="cuda").float()
+    a = ops.split_pairs(xi.float()) if pairs else xi.to(torch.float16)
+    ref64 = xi.double() @ wi.double().t()
+    alphas = [0.5, 0.25, 1.0]   # powers of two: alpha * acc + bias is exact too
+    vals = [ref64[:, n * E:(n + 1) * E] * alphas[n] + bias[n * E:(n + 1) * E].double() for n in range(3)]
+    specs = [ops.FakeQuantSpec(float(np.float32(2.0 ** (7 + n))), float(100 + 20 * n)) for n in range(3)]  # (power-of-two steps: exact quotients)
+    out = ops.proj_quant_i8(a, wi, bias, B, S, [(alphas[n], specs[n], n == 2, n == 1) for n in range(3)], pairs=pairs)
+    for n in range(3):
+        idx = out[n][0] if n == 1 else out[n]
+        assert torch.equal(idx.contiguous().to(torch.int32), _exact_indices(vals[n], specs[n], B, S, H, n == 2))
+
+
+def test_projection_gemm_refuses_what_it_does_not_do():
+    from outeffhop_amd import _lib, ops
+
+    a = torch.zeros(32, 2 * 40, dtype=torch.float16, device="cuda")
+    w = torch.zeros(3 * 64, 40, dtype=torch.float16, device="cuda")
+    b = torch.zeros(3 * 64, device="cuda")
+    sp = ops.FakeQuantSpec(0.1, 128.0)
+    with pytest.raises(_lib.OehError) as e:
+        ops.proj_quant_i8(a, w, b, 2, 16, [(1.0, sp, n == 2, False) for n in range(3)], pairs=True)  # K % 32 != 0
+    assert e.value.code == -95
