@@ -23,16 +23,23 @@
 
 namespace oeh {
 
-constexpr int GBM = 128, GBN = 288, GBK = kGemmBK, GROWB = 64;
-constexpr int G_AHI = 0, G_ALO = GBM * GROWB, G_W = 2 * GBM * GROWB, G_SLOT = G_W + GBN * GROWB;  // 34816
-constexpr int G_PITCH_C = GBM + 16, G_IMG_C = GBM * GBN, G_IMGS = G_IMG_C + GBN * G_PITCH_C;              // the epilogue's byte images: 36864 + 41472
-constexpr int G_LDS = 2 * G_SLOT > G_IMGS ? 2 * G_SLOT : G_IMGS;                                           // 78336: two workgroups per CU
+constexpr int GBK = kGemmBK, GROWB = 64;
+
+// tile geometry for MI x NJ accumulator tiles (16 x 16) per wave, waves 2 x 2
+template <int MI, int NJ>
+struct Geo {
+  static constexpr int BM = 32 * MI, BN = 32 * NJ;
+  static constexpr int AHI = 0, ALO = BM * GROWB, W = 2 * BM * GROWB, SLOT = W + BN * GROWB;
+  static constexpr int PITCH_C = BM + 16, IMG_C = BM * BN, IMGS = IMG_C + BN * PITCH_C;   // the epilogue's byte images
+  static constexpr int LDS = 2 * SLOT > IMGS ? 2 * SLOT : IMGS;
+};
 
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
-typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 
-template <bool PAIRS, bool RAW>
-__global__ __launch_bounds__(256, 2) void oeh_gemm_kernel(const GemmParams P) {
+template <bool PAIRS, bool RAW, int MI, int NJ>
+__global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(const GemmParams P) {
+  typedef Geo<MI, NJ> G;
+  constexpr int GBM = G::BM, GBN = G::BN, G_AHI = G::AHI, G_ALO = G::ALO, G_W = G::W, G_SLOT = G::SLOT, G_PITCH_C = G::PITCH_C, G_IMG_C = G::IMG_C;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,14 +100,14 @@ __global__ __launch_bounds__(256, 2) void oeh_gemm_kernel(const GemmParams P) {
 
   // ---- fragment addresses (constant per lane up to the slot)
   const unsigned swz = (unsigned)((lq ^ (l15 >> 2)) << 4);
-  const unsigned a_off = (unsigned)((64 * wm + l15) * GROWB) + swz;
-  const unsigned w_off = (unsigned)(G_W + (144 * wn + l15) * GROWB) + swz;
+  const unsigned a_off = (unsigned)((16 * MI * wm + l15) * GROWB) + swz;
+  const unsigned w_off = (unsigned)(G_W + (16 * NJ * wn + l15) * GROWB) + swz;
 
-  f4 acc[4][9];
+  f4 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 9; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
   issue(0);
   for (int t = 0; t < T; ++t) {
@@ -111,26 +118,26 @@ __global__ __launch_bounds__(256, 2) void oeh_gemm_kernel(const GemmParams P) {
     const bool more = t + 1 < T && !((P.dbg & 4) && t >= 1);
     if ((P.dbg & 64) && more) issue(t + 1);
     const unsigned char* sl = lds + (t & 1) * G_SLOT;
-    h8v ah[4], al[4];
+    h8v ah[MI], al[MI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       ah[i] = *reinterpret_cast<const h8v*>(sl + G_AHI + a_off + i * 16 * GROWB);
       if constexpr (PAIRS) al[i] = *reinterpret_cast<const h8v*>(sl + G_ALO + a_off + i * 16 * GROWB);
     }
     // every fragment of the step is requested before the first MFMA (17 ds_read_b128 in flight: the matrix core never waits for
     // LDS behind the first group); the compiler's counted lgkmcnt waits release the groups in order
-    h8v bf[9];
+    h8v bf[NJ];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) bf[j] = *reinterpret_cast<const h8v*>(sl + w_off + j * 16 * GROWB);
+    for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const h8v*>(sl + w_off + j * 16 * GROWB);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
+    for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bf[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bf[j], acc[i][j], 0, 0, 0);
       if constexpr (PAIRS) {
         const h8v bs = bf[j] * (_Float16)0.00048828125f;  // 2^-11: exact on the 8-bit integers
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bs, acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bs, acc[i][j], 0, 0, 0);
       }
       // the next tile's LDS-DMA pieces go out between the first MFMA groups (two per group): the matrix core has work queued while the
       // wave spends its issue slots on them, and every piece is under way before the middle of the step
@@ -148,20 +155,20 @@ __global__ __launch_bounds__(256, 2) void oeh_gemm_kernel(const GemmParams P) {
   // ---- epilogue.  C[row 16 i + 4 lq + r][col 16 j + l15]
   if (P.dbg & 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 9; ++j) asm volatile("" ::"v"(acc[i][j]));
+      for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
   if constexpr (RAW) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 9; ++j) {
-        const int n = n0 + 144 * wn + 16 * j + l15;
+      for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + 16 * NJ * wn + 16 * j + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int m = m0 + 64 * wm + 16 * i + 4 * lq + r;
+          const int m = m0 + 16 * MI * wm + 16 * i + 4 * lq + r;
           if (m < P.M && n < P.N) P.c[(long)m * P.ldc + n] = acc[i][j][r];
         }
       }
@@ -175,8 +182,8 @@ __global__ __launch_bounds__(256, 2) void oeh_gemm_kernel(const GemmParams P) {
     const int c4 = l15 & 3, a4 = l15 >> 2;
     const unsigned sel_t = (unsigned)c4 | ((unsigned)(4 + c4) << 8);   // v_perm_b32 selector: byte c4 of the second / of the first source
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const int nl = 144 * wn + 16 * j;              // tile-local first column (wave-uniform)
+    for (int j = 0; j < NJ; ++j) {
+      const int nl = 16 * NJ * wn + 16 * j;          // tile-local first column (wave-uniform)
       const int n = n0 + nl;
       if (n < P.N) {
         const int sg = n / P.E;
@@ -184,13 +191,13 @@ __global__ __launch_bounds__(256, 2) void oeh_gemm_kernel(const GemmParams P) {
         const FqP f = g.f;
         const float alpha = g.alpha;
         const float bia = P.bias[n + l15];
-        float* yp = g.y != nullptr ? g.y + (long)(m0 + 64 * wm + 4 * lq) * g.y_ld + (n - sg * P.E) + l15 : nullptr;
+        float* yp = g.y != nullptr ? g.y + (long)(m0 + 16 * MI * wm + 4 * lq) * g.y_ld + (n - sg * P.E) + l15 : nullptr;
         const long y_ld = g.y_ld;
         const bool idx_r = g.out != nullptr && !g.transpose, idx_c = g.out != nullptr && g.transpose;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
           unsigned word = 0;
-          const int rl = 64 * wm + 16 * i + 4 * lq;  // tile-local first row of the lane's four
+          const int rl = 16 * MI * wm + 16 * i + 4 * lq;  // tile-local first row of the lane's four
           if (yp != nullptr) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -231,9 +238,9 @@ __global__ __launch_bounds__(256, 2) void oeh_gemm_kernel(const GemmParams P) {
           *reinterpret_cast<u4*>(g.out + (long)m * P.E + (n - sg * P.E)) = *reinterpret_cast<const u4*>(img_r + row * GBN + 16 * c16);
       }
     }
-    // transposed segments: 288 columns x 8 pieces of 16 rows (= 16 keys of one batch element: S % 16 == 0)
+    // transposed segments: BN columns x BM / 16 pieces of 16 rows (= 16 keys of one batch element: S % 16 == 0)
     for (int e = tid; e < GBN * (GBM / 16); e += 256) {
-      const int col = e >> 3, pc = e & 7;
+      const int col = e / (GBM / 16), pc = e - col * (GBM / 16);
       const int n = n0 + col, m = m0 + 16 * pc;
       if (n < P.N && m < P.M) {
         const int sg = n / P.E;
@@ -249,26 +256,35 @@ __global__ __launch_bounds__(256, 2) void oeh_gemm_kernel(const GemmParams P) {
   }
 }
 
-template <bool PAIRS, bool RAW>
+template <bool PAIRS, bool RAW, int MI, int NJ>
 static int launch_gemm_t(const GemmParams& P, hipStream_t st) {
   static bool attr = false;
-  const int ldsb = RAW ? 2 * G_SLOT : G_LDS;
+  const int ldsb = RAW ? 2 * Geo<MI, NJ>::SLOT : Geo<MI, NJ>::LDS;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&oeh_gemm_kernel<PAIRS, RAW>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return -5;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&oeh_gemm_kernel<PAIRS, RAW, MI, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return -5;
     attr = true;
   }
-  hipLaunchKernelGGL((oeh_gemm_kernel<PAIRS, RAW>), dim3(P.MT * P.NT), dim3(256), ldsb, st, P);
+  hipLaunchKernelGGL((oeh_gemm_kernel<PAIRS, RAW, MI, NJ>), dim3(P.MT * P.NT), dim3(256), ldsb, st, P);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
+// Tile choice.  128 x 288 (two workgroups per CU, 144 accumulator registers) when the problem fills the chip with such tiles and the
+// columns divide evenly enough; 64 x 192 (four workgroups per CU) otherwise: narrow outputs (out_proj: N = 768 is 4 x 192) and
+// problems of fewer than 512 large tiles.
 int launch_gemm(const GemmParams& P0, hipStream_t st) {
   GemmParams P = P0;
-  { static const int dbg = [] { const char* e = getenv("OEH_GEMM_DBG"); return e ? atoi(e) : 0; }(); P.dbg = dbg; }
-  P.MT = (P.M + GBM - 1) / GBM;
-  P.NT = (P.N + GBN - 1) / GBN;
-  if (P.c != nullptr) return P.pairs ? launch_gemm_t<true, true>(P, st) : launch_gemm_t<false, true>(P, st);
-  return P.pairs ? launch_gemm_t<true, false>(P, st) : launch_gemm_t<false, false>(P, st);
+  static const int dbg = [] { const char* e = getenv("OEH_GEMM_DBG"); return e ? atoi(e) : 0; }();
+  static const int force = [] { const char* e = getenv("OEH_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  P.dbg = dbg;
+  const long t0 = (long)((P.M + 127) / 128) * ((P.N + 287) / 288);
+  const double waste0 = (double)t0 * 128.0 * 288.0 / ((double)P.M * (double)P.N);
+  const bool big = force ? force == 1 : (t0 >= 512 && waste0 <= 1.06);
+  if (big) {
+    P.MT = (P.M + 127) / 128; P.NT = (P.N + 287) / 288;
+    return P.pairs ? launch_gemm_t<true, false, 4, 9>(P, st) : launch_gemm_t<false, false, 4, 9>(P, st);
+  }
+  P.MT = (P.M + 63) / 64; P.NT = (P.N + 191) / 192;
+  return P.pairs ? launch_gemm_t<true, false, 2, 6>(P, st) : launch_gemm_t<false, false, 2, 6>(P, st);
 }
 
 }  // namespace oeh
-

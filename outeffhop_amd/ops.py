@@ -412,6 +412,29 @@ def proj_quant_i8(a: torch.Tensor, w_int: torch.Tensor, bias: torch.Tensor, B: i
     return res
 
 
+def proj_quant_values(a: torch.Tensor, w_int: torch.Tensor, bias: torch.Tensor, alpha: float, spec: "FakeQuantSpec", *, pairs: bool) -> torch.Tensor:
+    """A whole QuantLinear in one kernel (`oeh_proj_quant_i8`, values only): fake_quant(alpha * (a @ w_int^T) + bias) as fp32 (rows, N) -
+    a (rows, K) fp16 (e.g. the integers of the producer's quantiser: exact products) or (rows, 2K) operand pairs, w_int (N, K) fp16 the
+    weight's integers, `spec` the frozen 8-bit output quantiser.  rows % 16 == 0, K % 32 == 0, N % 64 == 0."""
+    dev = _need_gpu(a, w_int, bias)
+    N, K = w_int.shape
+    rows = a.shape[0]
+    if a.dtype != torch.float16 or w_int.dtype != torch.float16 or bias.dtype != torch.float32 or a.dim() != 2 or a.shape[1] != (2 if pairs else 1) * K:
+        raise ValueError("a (rows, K or 2K) fp16, w_int (N, K) fp16, bias (N) fp32")
+    if a.stride(1) != 1 or w_int.stride(1) != 1 or not bias.is_contiguous() or bias.numel() != N or spec.qmax != 255.0:
+        raise ValueError("contiguous rows, a bias of N and an 8-bit grid")
+    if rows % 16 != 0:
+        raise ValueError("rows must be a multiple of 16")
+    y = torch.empty((rows, N), dtype=torch.float32, device=a.device)
+    seg = (_lib.oeh_proj_seg * 1)()
+    seg[0].alpha, seg[0].scale, seg[0].zero_point = float(alpha), float(spec.scale), float(spec.zero_point)
+    seg[0].out, seg[0].y, seg[0].y_stride_row, seg[0].transpose = None, _ptr(y), N, 0
+    with _on_device(dev):
+        rc = _lib.load().oeh_proj_quant_i8(_ptr(a), int(bool(pairs)), _ptr(w_int), _ptr(bias), rows // 16, 16, K, N, 1, seg, a.stride(0), w_int.stride(0), _stream())
+    _lib.check(rc, "oeh_proj_quant_i8")
+    return y
+
+
 def attn_fwd_i8(q: torch.Tensor, k: torch.Tensor, v_t: torch.Tensor, grids, *, fq: AttnFakeQuant, out_dtype=torch.float16,
                 softmax: SoftmaxSpec = SoftmaxSpec(), scale: float = 1.0, scale_div: float = 0.0, causal: bool = False, clamp_min: bool = False,
                 mask_min: Optional[float] = None, gate: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,

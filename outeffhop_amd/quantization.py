@@ -605,13 +605,21 @@ class QuantLinear(QuantizedModule, nn.Linear):
         with exact products and fp32 accumulation - half the operand-pair GEMM and no split pass - then scale, bias and the
         frozen output quantiser in one pass over the accumulator (the reference: a float GEMM of the dequantised values,
         quantized_opt.py:271; the two agree to fp32 rounding of the sum)."""
-        ww, s32 = self._pair_weights()
         K = self.in_features
-        acc = torch.mm(rel.reshape(-1, K), ww[:K], out_dtype=torch.float32)
-        alpha = float(np.float32(xscale) * np.float32(s32))
         shape = (*rel.shape[:-1], self.out_features)
         aq = self.activation_quantizer
-        if (self._qa and self.out_features % 64 == 0 and aq.is_fixed and type(aq.quantizer) is AsymmetricUniformQuantizer and aq.quantizer.n_bits == 8):
+        fixed8 = (self._qa and self.out_features % 64 == 0 and aq.is_fixed and type(aq.quantizer) is AsymmetricUniformQuantizer and aq.quantizer.n_bits == 8)
+        rel2 = rel.reshape(-1, K)
+        if (FUSED_PROJ and fixed8 and K % 32 == 0 and rel2.shape[0] % 16 == 0 and rel2.dtype == torch.float16 and rel2.stride(1) == 1
+                and self.bias is not None):
+            # ONE kernel: the GEMM of integers, scale, bias and the output quantiser in its epilogue (`oeh_proj_quant_i8`, values only)
+            iw, s32 = self._int_weights()
+            y = ops.proj_quant_values(rel2, iw, self.bias.detach(), float(np.float32(xscale) * np.float32(s32)), aq.quantizer.spec(), pairs=False)
+            return y.view(shape).to(out_dtype)
+        ww, s32 = self._pair_weights()
+        acc = torch.mm(rel2, ww[:K], out_dtype=torch.float32)
+        alpha = float(np.float32(xscale) * np.float32(s32))
+        if fixed8:
             y = ops.quantize_heads_i8(acc.view(1, -1, self.out_features), aq.quantizer.spec(), self.out_features // 64, want_values=True,
                                       alpha=alpha, bias=self.bias.detach(), want_indices=False)
             return y.view(shape).to(out_dtype)
