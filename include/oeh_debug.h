@@ -25,6 +25,12 @@ int oeh_debug_set_variant(int off_mask, int flash_mq_force);
  * (tools/timeline.py); NULL switches the stamps off.  Returns 0, or -95 when the hooks are not enabled. */
 int oeh_debug_set_stamps(void* device_buffer);
 
+/* Environment switches of the projection GEMM (oeh_proj_quant_i8; csrc/oeh_gemm.hip), read once, inert unless OEH_DEBUG_HOOKS=1:
+ *   OEH_GEMM_TILE = 1 | 2   force the 128 x 288 | 64 x 192 output tile;
+ *   OEH_GEMM_DBG  = bits    knock parts of the kernel out for timing - the results are then WRONG (tools/exp/proj_time.py):
+ *                           1 no epilogue, 4 no LDS-DMA after the first step, 8 no wait + barrier per step, 16 no value stores,
+ *                           32 no index output stage, 64 the whole next tile's DMA issued at the top of a step. */
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,12 +18,12 @@ struct GemmSeg {            // one column segment (a projection): columns [n0, n
 struct GemmParams {
   const void* a;            // (M, 2K) fp16 pairs, or (M, K) fp16 [pairs == 0]
   const void* w;            // (N, K) fp16
-  float* c;                 // raw accumulator (M, N) fp32 (diagnostic form), or nullptr
   const float* bias;        // (N) fp32
-  long lda, ldw, ldc;       // row strides in elements
+  long lda, ldw;            // row strides in elements
   int M, N, K, pairs;
   int MT, NT;               // tiles
-  int dbg;
+  int dbg;                  // diagnostic knock-outs (oeh_gemm.hip: launch_gemm), 0 in production
+  unsigned magic_s;         // floor(2^32 / S)
   int E, S, H;              // segment width, rows per batch element, heads per segment (E = 64 H)
   GemmSeg seg[3];
 };

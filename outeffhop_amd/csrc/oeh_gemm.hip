@@ -1,20 +1,31 @@
-// The q / k / v projections of a QuantLinear model as ONE matrix-core GEMM with the output quantisers in its epilogue (SURVEY 8f-1,
-// VERDICT r3 next #5): x (M, K) fp32 carried as fp16 operand pairs [hi | lo 2^11] (oeh_split_pairs), the three QuantLinear weight
-// matrices side by side as their 8-bit integers in fp16 (N = 3 E rows of K, exact), fp32 accumulation:
+// A QuantLinear projection - or the three of an attention layer side by side - as ONE matrix-core GEMM with the output quantisers in its
+// epilogue (include/oeh.h: oeh_proj_quant_i8).  Activations (M, K) fp16, or an fp32 model's activations
+// as fp16 operand pairs [hi | lo 2^11] (oeh_split_pairs); the QuantLinear weights as their 8-bit integers in fp16 (N rows of K,
+// exact); fp32 accumulation:
 //     acc[m][n] = sum_k hi[m][k] W[n][k] + sum_k lo[m][k] (W[n][k] 2^-11)
-// and, in the epilogue, per column segment (q | k | v): value = alpha acc + bias[n], the centred 8-bit index of the segment's
-// quantiser in the layout the INT8-storage attention core reads (q, k: (B, S, E) int8; v: (B, H, 64, S) int8), and optionally the
-// dequantised values (the decoder's (k, v) cache) - what the library GEMM + three `oeh_quantize_heads_i8` passes did, without the
+// and, in the epilogue, per column segment (q | k | v): value = alpha acc + bias[n], the centred 8-bit index of the segment's quantiser in
+// the layout the INT8-storage attention core reads (q, k: (B, S, E) int8; v: (B, H, 64, S) int8) and / or the dequantised values (the
+// decoder's (k, v) cache; out_proj's output) - what the library GEMM + one `oeh_quantize_heads_i8` pass per segment did, without the
 // (M, N) fp32 accumulator ever reaching memory.
 //
-// Shape of the kernel (gfx950): 128 x 288 output tile per workgroup of 4 waves (2 x 2: 64 x 144 per wave = 4 x 9 accumulator tiles of
-// v_mfma_f32_16x16x32_f16, 144 registers), K in steps of 32: one LDS slot holds hi (128 rows x 64 B), lo (the same) and W (288 rows x
-// 64 B) = 34 KB, filled by LDS-DMA (global_load_lds_dwordx4, 34 pieces of 1 KB over the 4 waves), two slots, one barrier per step; two
-// workgroups per CU (136 KB of LDS, 8 waves), which at M = 8192, N = 2304 is every workgroup of the launch resident at once
-// (64 x 8 = 512).  Per step and wave: 17 ds_read_b128 (4 hi + 4 lo + 9 W fragments), 36 v_pk_mul_f16 (W 2^-11: exact, the integers
-// are >= 1 in magnitude) and 72 MFMAs.  LDS image: rows of 64 B, 16-byte chunk c of row r stored at chunk c ^ ((r >> 2) & 3): the 16
-// lanes of one fragment read (rows r .. r + 15, one chunk) hit 16 different 16-byte bank groups; the DMA writes whole kilobytes and
-// applies the swizzle to its SOURCE address.
+// Shape of the kernel (gfx950).  A workgroup of 4 waves (2 x 2) owns an output tile of 32 MI x 32 NJ; a wave MI x NJ accumulator tiles
+// of v_mfma_f32_16x16x32_f16.  Two instantiations: MI x NJ = 4 x 9 (128 x 288, 144 accumulator registers, 232 VGPRs, two workgroups
+// per CU: at M = 8192, N = 2304 every workgroup of the launch is resident at once, 64 x 8 = 512) and 2 x 6 (64 x 192, four per CU: narrow
+// outputs such as out_proj's N = 768 and problems of fewer than 512 large tiles).  K in steps of 32: one LDS slot holds hi (BM rows x
+// 64 B), lo (the same) and W (BN rows x 64 B) - 34 KB for the large tile - filled by LDS-DMA (global_load_lds_dwordx4, pieces of 1 KB =
+// 16 rows, spread over the 4 waves, scalar base + constant lane offsets); two slots, one counted-to-zero wait + one barrier per step; the
+// next step's pieces are issued two at a time behind the first MFMA groups of the current one.  Per step and wave (large tile): 17
+// ds_read_b128, all requested before the first MFMA (4 hi + 4 lo + 9 W fragments), 36 v_pk_mul_f16 (W 2^-11: exact, the integers are
+// >= 1 in magnitude) and 72 MFMAs.  LDS image: rows of 64 B, 16-byte chunk c of row r stored at chunk c ^ ((r >> 2) & 3): the 16 lanes of
+// one fragment read (rows r .. r + 15, one chunk) hit 16 different 16-byte bank groups; the DMA writes whole kilobytes and applies the
+// swizzle to its SOURCE address.  Workgroup -> tile: the eight XCDs take contiguous ranges of row tiles, all column tiles of a row tile on
+// one XCD (an activation tile is fetched once per XCD and hit in its L2 by the other column tiles).
+// Epilogue: 7 vector instructions per output (fma, the three-instruction exact quotient, rint, + zero point, v_cvt_pk_u8_f32 whose
+// saturation is the clamp; 9 with values), index bytes through LDS images (4 x 4 byte transposes inside lane quads for the row-major
+// one) so that they leave as whole 16-byte pieces of contiguous output; values straight from the accumulator layout, write-through.
+// Measured (one MI355X, M = 8192, K = 768): q/k/v (N = 2304, pairs) 74 us with the (k, v) values, 63 us without, against 107 / 91 us
+// for the library GEMM (hipBLASLt, 70 us) + three quantiser passes; out_proj (N = 768, integers) 20.5 against 31.8 us.  The loop alone
+// is 52-55 us = 1.1 PFLOP/s (40 us with the DMA and the barriers knocked out: the matrix core at the clock it holds under this load).
 #include "../../include/oeh.h"
 #include "oeh_common.h"
 #include "oeh_gemm.h"
@@ -23,7 +34,13 @@
 
 namespace oeh {
 
+// The outputs leave WRITE-THROUGH (as the attention kernels' do, oeh_common.h: store_wt16): a plain store leaves the line dirty in the XCD's L2
+// and what is still there at the end of the kernel goes to memory after the last wave, where nothing overlaps it (out_proj, 25 MB of
+// values: 24.4 -> 20.7 us; the q/k/v launch with its 69 MB is bound by the write itself either way).
+__device__ __forceinline__ void store_wt4(float* dst, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory"); }
+
 constexpr int GBK = kGemmBK, GROWB = 64;
+constexpr int kPer = 2;  // LDS-DMA pieces issued behind each of the first MFMA groups of a step (3 and 5 measured the same or slower)
 
 // tile geometry for MI x NJ accumulator tiles (16 x 16) per wave, waves 2 x 2
 template <int MI, int NJ>
@@ -36,7 +53,7 @@ struct Geo {
 
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 
-template <bool PAIRS, bool RAW, int MI, int NJ>
+template <bool PAIRS, int MI, int NJ>
 __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(const GemmParams P) {
   typedef Geo<MI, NJ> G;
   constexpr int GBM = G::BM, GBN = G::BN, G_AHI = G::AHI, G_ALO = G::ALO, G_W = G::W, G_SLOT = G::SLOT, G_PITCH_C = G::PITCH_C, G_IMG_C = G::IMG_C;
@@ -141,11 +158,12 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
       }
       // the next tile's LDS-DMA pieces go out between the first MFMA groups (two per group): the matrix core has work queued while the
       // wave spends its issue slots on them, and every piece is under way before the middle of the step
-      if (2 * j < NQ) {
+      if (kPer * j < NQ) {
         __builtin_amdgcn_sched_barrier(0);
         if (!(P.dbg & 64) && more) {
-          issue_q(t + 1, 2 * j);
-          if (2 * j + 1 < NQ) issue_q(t + 1, 2 * j + 1);
+#pragma unroll
+          for (int u = 0; u < kPer; ++u)
+            if (kPer * j + u < NQ) issue_q(t + 1, kPer * j + u);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -160,19 +178,7 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
       for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  if constexpr (RAW) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + 16 * NJ * wn + 16 * j + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + 16 * MI * wm + 16 * i + 4 * lq + r;
-          if (m < P.M && n < P.N) P.c[(long)m * P.ldc + n] = acc[i][j][r];
-        }
-      }
-  } else {
+  {
     // per accumulator column tile (16 columns: inside one segment and one head): value -> index byte (+ dequantised value).
     // The index bytes go through LDS so that they leave as whole 16-byte pieces of contiguous output: columns of a plain segment
     // (q, k) as a [row][288] image, columns of a transposed segment (v) as a [column][128 rows] image (pitch 144 B).
@@ -180,17 +186,20 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
     unsigned char* img_r = lds;
     unsigned char* img_c = lds + G_IMG_C;
     const int c4 = l15 & 3, a4 = l15 >> 2;
+    float biav[NJ];  // (all of the lane's bias values in one round trip)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) biav[j] = P.bias[min(n0 + 16 * NJ * wn + 16 * j + l15, P.N - 1)];
     const unsigned sel_t = (unsigned)c4 | ((unsigned)(4 + c4) << 8);   // v_perm_b32 selector: byte c4 of the second / of the first source
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int nl = 16 * NJ * wn + 16 * j;          // tile-local first column (wave-uniform)
       const int n = n0 + nl;
       if (n < P.N) {
-        const int sg = n / P.E;
+        const int sg = (n >= P.E) + (n >= 2 * P.E);
         const GemmSeg& g = P.seg[sg];
         const FqP f = g.f;
         const float alpha = g.alpha;
-        const float bia = P.bias[n + l15];
+        const float bia = biav[j];
         float* yp = g.y != nullptr ? g.y + (long)(m0 + 16 * MI * wm + 4 * lq) * g.y_ld + (n - sg * P.E) + l15 : nullptr;
         const long y_ld = g.y_ld;
         const bool idx_r = g.out != nullptr && !g.transpose, idx_c = g.out != nullptr && g.transpose;
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
             for (int r = 0; r < 4; ++r) {
               const float rel = fq_rel(__builtin_fmaf(acc[i][j][r], alpha, bia), f);
               word = __builtin_amdgcn_cvt_pk_u8_f32(rel + f.zp, r, word);
-              if (m0 + rl + r < P.M && !(P.dbg & 16)) yp[(long)(16 * i + r) * y_ld] = f.scale * rel;
+              if (m0 + rl + r < P.M && !(P.dbg & 16)) store_wt4(yp + (long)(16 * i + r) * y_ld, f.scale * rel);
             }
           } else {
             // (no values wanted: the conversion's saturation to [0, 255] is the clamp)
@@ -227,12 +236,12 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
     }
     barrier_mem();
     if (P.dbg & 32) return;
-    // plain segments: 128 rows x 18 pieces, consecutive threads on consecutive pieces of a row
+    // plain segments: BM rows x BN / 16 pieces, consecutive threads on consecutive pieces of a row
     for (int e = tid; e < GBM * (GBN / 16); e += 256) {
       const int row = e / (GBN / 16), c16 = e - row * (GBN / 16);
       const int n = n0 + 16 * c16, m = m0 + row;
       if (n < P.N && m < P.M) {
-        const int sg = n / P.E;
+        const int sg = (n >= P.E) + (n >= 2 * P.E);
         const GemmSeg& g = P.seg[sg];
         if (g.out != nullptr && !g.transpose)
           *reinterpret_cast<u4*>(g.out + (long)m * P.E + (n - sg * P.E)) = *reinterpret_cast<const u4*>(img_r + row * GBN + 16 * c16);
@@ -243,11 +252,12 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
       const int col = e / (GBM / 16), pc = e - col * (GBM / 16);
       const int n = n0 + col, m = m0 + 16 * pc;
       if (n < P.N && m < P.M) {
-        const int sg = n / P.E;
+        const int sg = (n >= P.E) + (n >= 2 * P.E);
         const GemmSeg& g = P.seg[sg];
         if (g.out != nullptr && g.transpose) {
           const int ns = n - sg * P.E;
-          const int bidx = m / P.S, srow = m - bidx * P.S;
+          int bidx, srow;
+          div_magic((unsigned)m, (unsigned)P.S, P.magic_s, bidx, srow);
           *reinterpret_cast<u4*>(g.out + (((long)bidx * P.H + (ns >> 6)) * 64 + (ns & 63)) * P.S + srow) =
               *reinterpret_cast<const u4*>(img_c + col * G_PITCH_C + 16 * pc);
         }
@@ -256,15 +266,15 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
   }
 }
 
-template <bool PAIRS, bool RAW, int MI, int NJ>
+template <bool PAIRS, int MI, int NJ>
 static int launch_gemm_t(const GemmParams& P, hipStream_t st) {
   static bool attr = false;
-  const int ldsb = RAW ? 2 * Geo<MI, NJ>::SLOT : Geo<MI, NJ>::LDS;
+  const int ldsb = Geo<MI, NJ>::LDS;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&oeh_gemm_kernel<PAIRS, RAW, MI, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return -5;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&oeh_gemm_kernel<PAIRS, MI, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return -5;
     attr = true;
   }
-  hipLaunchKernelGGL((oeh_gemm_kernel<PAIRS, RAW, MI, NJ>), dim3(P.MT * P.NT), dim3(256), ldsb, st, P);
+  hipLaunchKernelGGL((oeh_gemm_kernel<PAIRS, MI, NJ>), dim3(P.MT * P.NT), dim3(256), ldsb, st, P);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
@@ -273,18 +283,22 @@ static int launch_gemm_t(const GemmParams& P, hipStream_t st) {
 // problems of fewer than 512 large tiles.
 int launch_gemm(const GemmParams& P0, hipStream_t st) {
   GemmParams P = P0;
-  static const int dbg = [] { const char* e = getenv("OEH_GEMM_DBG"); return e ? atoi(e) : 0; }();
-  static const int force = [] { const char* e = getenv("OEH_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  // diagnostic switches (include/oeh_debug.h), inert unless OEH_DEBUG_HOOKS=1: OEH_GEMM_DBG knocks parts of the kernel out for timing
+  // (results are then wrong), OEH_GEMM_TILE = 1 | 2 forces the 128 x 288 | 64 x 192 tile
+  static const bool hooks = [] { const char* e = getenv("OEH_DEBUG_HOOKS"); return e != nullptr && e[0] == '1'; }();
+  static const int dbg = [] { const char* e = getenv("OEH_GEMM_DBG"); return e ? atoi(e) : 0; }() * (hooks ? 1 : 0);
+  static const int force = [] { const char* e = getenv("OEH_GEMM_TILE"); return e ? atoi(e) : 0; }() * (hooks ? 1 : 0);
   P.dbg = dbg;
+  P.magic_s = P.S > 1 ? (unsigned)(0x100000000ULL / (unsigned long long)P.S) : 0xffffffffu;
   const long t0 = (long)((P.M + 127) / 128) * ((P.N + 287) / 288);
   const double waste0 = (double)t0 * 128.0 * 288.0 / ((double)P.M * (double)P.N);
   const bool big = force ? force == 1 : (t0 >= 512 && waste0 <= 1.06);
   if (big) {
     P.MT = (P.M + 127) / 128; P.NT = (P.N + 287) / 288;
-    return P.pairs ? launch_gemm_t<true, false, 4, 9>(P, st) : launch_gemm_t<false, false, 4, 9>(P, st);
+    return P.pairs ? launch_gemm_t<true, 4, 9>(P, st) : launch_gemm_t<false, 4, 9>(P, st);
   }
   P.MT = (P.M + 63) / 64; P.NT = (P.N + 191) / 192;
-  return P.pairs ? launch_gemm_t<true, false, 2, 6>(P, st) : launch_gemm_t<false, false, 2, 6>(P, st);
+  return P.pairs ? launch_gemm_t<true, 2, 6>(P, st) : launch_gemm_t<false, 2, 6>(P, st);
 }
 
 }  // namespace oeh

@@ -2,6 +2,7 @@
 """Launch times of oeh_proj_quant_i8 (OEH_GEMM_DBG bits: diagnostic; OEH_GEMM_TILE=1|2 forces the 128x288 | 64x192 tile) and of what it
 replaces, on the OPT-125m and BERT-base layer shapes; the prepared calls are replayed from a HIP graph so that host time stays out."""
 import os, sys
+os.environ.setdefault("OEH_DEBUG_HOOKS", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from outeffhop_amd import ops
