@@ -92,3 +92,43 @@ def test_projection_gemm_refuses_what_it_does_not_do():
     with pytest.raises(_lib.OehError) as e:
         ops.proj_quant_i8(a, w, b, 2, 16, [(1.0, sp, n == 2, False) for n in range(3)], pairs=True)  # K % 32 != 0
     assert e.value.code == -95
+
+
+def test_projection_gemm_random_shapes_against_the_library_path():
+    """Random (B, S, H, K), one to three segments, both operand forms, values on / off per segment, both tile shapes (the library
+    picks by problem size; the diagnostic switch forces the other): every index within one step of the library GEMM + quantiser
+    pass on the same operands, all but a few in 10^5 equal; values consistent with the indices."""
+    import os
+    from outeffhop_amd import ops
+
+    rng = np.random.default_rng(7)
+    for trial in range(24):
+        B, S = int(rng.integers(1, 9)), 16 * int(rng.integers(1, 20))
+        H, K = int(rng.integers(1, 7)), 32 * int(rng.integers(1, 13))
+        nseg = int(rng.integers(1, 4))
+        pairs = bool(rng.integers(0, 2))
+        E, M = H * 64, B * S
+        torch.manual_seed(trial)
+        x = torch.randn(M, K, device="cuda")
+        wi = torch.randint(-128, 128, (nseg * E, K), device="cuda").to(torch.float16)
+        bias = torch.randn(nseg * E, device="cuda") * 0.2
+        a = ops.split_pairs(x) if pairs else x.to(torch.float16)
+        ww = (torch.cat([wi, wi * 2.0 ** -11], dim=1) if pairs else wi).t().contiguous()
+        acc = torch.mm(a, ww, out_dtype=torch.float32).view(B, S, nseg * E)
+        alphas = [float(rng.uniform(1e-3, 4e-3)) for _ in range(nseg)]
+        segs, specs = [], []
+        for n in range(nseg):
+            v = acc[..., n * E:(n + 1) * E] * alphas[n] + bias[n * E:(n + 1) * E]
+            specs.append(ops.FakeQuantSpec(*_grid(v.double())))
+            segs.append((alphas[n], specs[n], bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
+        new = ops.proj_quant_i8(a, wi, bias, B, S, segs, pairs=pairs)
+        for n, (al, sp, tr, want) in enumerate(segs):
+            old = ops.quantize_heads_i8(acc[..., n * E:(n + 1) * E], sp, H, transpose=tr, want_values=want, alpha=al, bias=bias[n * E:(n + 1) * E].contiguous())
+            io, yo = old if want else (old, None)
+            inw, yn = new[n] if want else (new[n], None)
+            d = (io.contiguous().to(torch.int32) - inw.contiguous().to(torch.int32)).abs()
+            assert int(d.max()) <= 1 and float((d != 0).float().mean()) <= 1e-4, (trial, B, S, H, K, nseg, pairs, n, int(d.max()), float((d != 0).float().mean()))
+            if want:
+                rows = inw.permute(0, 1, 3, 2) if tr else inw
+                want_y = np.float32(sp.scale) * (rows.permute(0, 2, 1, 3).reshape(B, S, E).float() + 128.0 - sp.zero_point)
+                assert torch.equal(yn, want_y)
