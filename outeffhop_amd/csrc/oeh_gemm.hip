@@ -275,11 +275,13 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
 
 template <bool PAIRS, int MI, int NJ>
 static int launch_gemm_t(const GemmParams& P, hipStream_t st) {
-  static bool attr = false;
+  static bool attr[64] = {};   // (the LDS opt-in is per device: a process that drives several GPUs sets it on each)
   const int ldsb = Geo<MI, NJ>::LDS;
-  if (!attr) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -5;
+  if (!attr[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&oeh_gemm_kernel<PAIRS, MI, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return -5;
-    attr = true;
+    attr[dev] = true;
   }
   hipLaunchKernelGGL((oeh_gemm_kernel<PAIRS, MI, NJ>), dim3(P.MT * P.NT), dim3(256), ldsb, st, P);
   return hipGetLastError() == hipSuccess ? 0 : -5;

@@ -817,16 +817,26 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
         # this path reads the QuantLinear weights and quantiser grids directly: the forwards of the projections, of the consumer and
         # of the three activation quantisers never run, so forward hooks on any of them (attach_act_hooks registers one on every
         # named module) would be bypassed silently - the module path then (as bert_attention.py / opt_attention.py do)
-        bypassed = [m for top in (*lins, consumer, self.attn_scores_act_quantizer, self.attn_probs_act_quantizer, self.context_act_quantizer)
-                    if top is not None for m in top.modules()]
-        if has_hooks(*bypassed):
+        # (the flattened module list is remembered per set of top modules: walking `.modules()` of seven modules was a sixth of this
+        # path's host time, and the eager forward is host-bound; hooks registered later on any of them are still seen - the hook
+        # dictionaries are read on every call - only a submodule swapped in afterwards under the same top module would not be)
+        tops = (*lins, consumer, self.attn_scores_act_quantizer, self.attn_probs_act_quantizer, self.context_act_quantizer)
+        bkey = tuple(id(t) for t in tops)
+        bhit = self.__dict__.get("_bypassed_cache")
+        if bhit is None or bhit[0] != bkey:
+            bhit = (bkey, [m for top in tops if top is not None for m in top.modules()])
+            self.__dict__["_bypassed_cache"] = bhit
+        if has_hooks(*bhit[1]):
             return None
         spec = spec_of(self.softmax_fn)
         bsz, tgt_len, _ = hidden_states.shape
         if spec is None or (spec.clip and spec.gamma > 0.0) or tgt_len % 16 != 0 or tgt_len > 512 or fq.probs is None or fq.probs.qmax != 255.0 or fq.scores is None:
             return None
-        if not all(isinstance(m, QuantLinear) and m._qa and m.activation_quantizer.is_fixed and m.activation_quantizer.quantizer.n_bits == 8
-                   and m.activation_function is None for m in lins):
+        if not all(isinstance(m, QuantLinear) for m in lins):
+            return None
+        aqs = [m.activation_quantizer for m in lins]
+        qzs = [a.quantizer for a in aqs]
+        if not all(m._qa and a.is_fixed and z.n_bits == 8 and m.activation_function is None for m, a, z in zip(lins, aqs, qzs)):
             return None
         E = H * head_dim
         outs, grids = [], []
@@ -834,12 +844,12 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
         all_pairs = all(m.pair_gemm_ok(hidden_states) and m.bias is not None for m in lins)
         K_in = hidden_states.shape[-1]
         if (FUSED_PROJ and all_pairs and K_in % 32 == 0 and all(m.in_features == K_in and m.out_features == E for m in lins)
-                and all(type(m.activation_quantizer.quantizer) is AsymmetricUniformQuantizer for m in lins)):
+                and all(type(z) is AsymmetricUniformQuantizer for z in qzs)):
             # fp32 model, ONE kernel: the pair GEMM against the three integer weight matrices with weight scale, bias and the three output
             # quantisers in its epilogue (`oeh_proj_quant_i8`) - the (B*T, 3E) accumulator never reaches memory
             pairs = ops.split_pairs(hidden_states.reshape(-1, K_in))
             w3, b3, scales3 = self._qkv_int_weights(lins)
-            specs = [m.activation_quantizer.quantizer.spec() for m in lins]
+            specs = [z.spec() for z in qzs]
             outs = ops.proj_quant_i8(pairs, w3, b3, bsz, tgt_len, [(scales3[n_], specs[n_], n_ == 2, n_ > 0 and want_values) for n_ in range(3)], pairs=True)
             grids = [ops.QuantGrid.of(sp) for sp in specs]
             self.__dict__["_fused_proj_calls"] = self.__dict__.get("_fused_proj_calls", 0) + 1  # (tests: which path ran)
