@@ -87,4 +87,31 @@ case_i8("int8 storage pad S=128 (BERT)", 32, 12, 128, torch.float32, False, True
 case_i8("int8 storage causal S=448 f16 out", 16, 12, 448, torch.float16, True, True)
 case("two-pass clip + full mask S=640", 4,12,640,64, lambda pad: dict(scale_div=8.0, clamp_min=True, softmax=clipsm, full_mask=(pad[:, None, None, :] + torch.zeros(pad.shape[0], 1, 640, 640, device="cuda")).contiguous()))
 case("two-pass vanilla clip + pad S=704", 8,12,704,64, lambda pad: dict(scale_div=8.0, key_pad_mask=pad, softmax=ops.SoftmaxSpec(0, True, -0.003, 1.003)))
+# round 4: the projection GEMM (LDS-DMA ring of two slots ordered by vmcnt(0) + one barrier per step; the epilogue's LDS images reuse
+# the slots behind a barrier) - both tile shapes, the pair and the plain operand form
+def case_proj(name, B, S, H, K, pairs, values):
+    global tot
+    torch.manual_seed(3)
+    E, M = H * 64, B * S
+    x = torch.randn(M, K, device="cuda")
+    a = ops.split_pairs(x) if pairs else x.half()
+    wi = torch.randint(-128, 128, (3 * E, K), device="cuda").to(torch.float16)
+    bias = torch.randn(3 * E, device="cuda") * 0.1
+    sp = [ops.FakeQuantSpec(0.03, 131.0), ops.FakeQuantSpec(0.035, 124.0), ops.FakeQuantSpec(0.03, 128.0)]
+    segs = [(0.003, sp[n], n == 2, n > 0 and values) for n in range(3)]
+    flat = lambda r: [t for o in r for t in (o if isinstance(o, tuple) else (o,))]
+    ref = [t.clone() for t in flat(ops.proj_quant_i8(a, wi, bias, B, S, segs, pairs=pairs))]
+    s2 = torch.cuda.Stream(); q2 = torch.randn(4, 8, 333, 64, device="cuda").half()
+    bad = 0
+    for it in range(N):
+        if it % 3 == 0:
+            with torch.cuda.stream(s2):
+                ops.attn_fwd(q2, q2, q2, causal=True, clamp_min=True, mask_min=fmin)
+        got = flat(ops.proj_quant_i8(a, wi, bias, B, S, segs, pairs=pairs))
+        if not all(torch.equal(g, r) for g, r in zip(got, ref)): bad += 1
+    print(f"{name:34s}        : {bad} of {N} differ [oeh_gemm]"); tot += bad
+case_proj("projections OPT pairs + values", 16, 512, 12, 768, True, True)
+case_proj("projections BERT pairs (small tile)", 32, 128, 12, 768, True, False)
+case_proj("projections fp16 activations", 16, 512, 12, 768, False, False)
+case_proj("projections ragged 5 x 80", 5, 80, 12, 768, True, True)
 sys.exit(1 if tot else 0)
