@@ -853,14 +853,13 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
             outs = ops.proj_quant_i8(pairs, w3, b3, bsz, tgt_len, [(scales3[n_], specs[n_], n_ == 2, n_ > 0 and want_values) for n_ in range(3)], pairs=True)
             grids = [ops.QuantGrid.of(sp) for sp in specs]
             self.__dict__["_fused_proj_calls"] = self.__dict__.get("_fused_proj_calls", 0) + 1  # (tests: which path ran)
-            lins = ()
         elif all_pairs:
             # fp32 model: the input as fp16 operand pairs, split once, and ONE fp16 GEMM against the three integer weight
             # matrices side by side; each projection's weight scale and bias are folded into its quantiser pass
             pairs = ops.split_pairs(hidden_states.reshape(-1, hidden_states.shape[-1]))
             ww3, scales3 = self._qkv_pair_weights(lins)
             acc3 = torch.mm(pairs, ww3, out_dtype=torch.float32).view(bsz, tgt_len, 3 * E)
-        for n_, m in enumerate(lins):  # GEMM, then ONE kernel: centred int8 indices in the core's layout (v transposed) [+ the cache's floats]
+        for n_, m in enumerate(() if outs else lins):  # (not fused:) GEMM, then ONE kernel: centred int8 indices in the core's layout (v transposed) [+ the cache's floats]
             alpha, qbias = 1.0, None
             if acc3 is not None:
                 res, alpha, qbias = acc3[..., n_ * E:(n_ + 1) * E], scales3[n_], m.bias.detach()
