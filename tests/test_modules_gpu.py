@@ -228,6 +228,9 @@ def test_int8_modules_calibrate_fix_eval(oa, fam, accel):
                 qm.fix_ranges()
                 assert qm._fq(fam == "opt") is not None
                 out = fwd(evalx)
+                if accel == "default" and qm.__dict__.get("_i8_calls", 0):
+                    # (round 4) the integer core's operands came from the ONE-kernel projections (oeh_proj_quant_i8), not from library GEMMs
+                    assert qm.__dict__.get("_fused_proj_calls", 0) == qm.__dict__["_i8_calls"], "the projections ran as library GEMM + quantiser passes"
             d_err = 0.0
             for name in ("attn_scores_act_quantizer", "attn_probs_act_quantizer", "context_act_quantizer"):
                 qz = getattr(qm, name).activation_quantizer.quantizer
