@@ -293,10 +293,12 @@ int oeh_split_triples(const float* x, void* out_f16, int64_t rows, int32_t K, in
  * quantized_opt.py:67-75 q_proj / k_proj / v_proj, quantized_bert.py:236-238 query / key / value: QuantLinear = weight fake-quant +
  * F.linear + output fake-quant, hijacker.py:78-127): what a library GEMM over the stacked weights followed by three
  * oeh_quantize_heads_i8 passes computes, without the (B*S, n_seg*E) accumulator ever reaching memory.
- *   a: the activations (B*S rows, row stride lda elements, 16-byte aligned rows), fp16 - pairs == 0: (rows, K); pairs == 1: (rows, 2K),
- *      the operand pairs [hi | lo] that oeh_split_pairs writes for an fp32 model;
+ *   a: the activations (B*S rows, row stride lda elements, 16-byte aligned rows) - pairs == 0: fp16 (rows, K); pairs == 1: fp16
+ *      (rows, 2K), the operand pairs [hi | lo] that oeh_split_pairs writes for an fp32 model; pairs == 2: the fp32 activations (rows, K)
+ *      themselves - the kernel forms the same (hi, lo) pairs when a wave reads its operand fragments: same result as pairs == 1,
+ *      bit for bit, without the split pass;
  *   w: (n_seg*E, K) fp16, row stride ldw: the QuantLinear weights' INTEGERS (w / weight scale: exact in fp16), the segments' rows
- *      one after the other; pairs == 1 multiplies the lo half against w * 2^-11, formed in registers (exact on integers);
+ *      one after the other; pairs != 0 multiplies the lo half against w * 2^-11, formed in registers (exact on integers);
  *   bias: (n_seg*E) fp32; segment i covers output columns [i*E, (i+1)*E) and turns the fp32 accumulator into
  *      value = alpha * acc + bias[column],  c = clamp(rint(value / scale) + zero_point, 0, 255) - 128:
  *      out  (may be NULL when y is given): int8, (B, S, E) [transpose == 0: q, k] or (B, E/64, 64, S) [transpose == 1: v, keys

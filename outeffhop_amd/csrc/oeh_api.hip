@@ -583,12 +583,14 @@ int oeh_proj_quant_i8(const void* a, int32_t pairs, const void* w, const float* 
                       const oeh_proj_seg* segs, int64_t lda, int64_t ldw, void* stream) {
   if (a == nullptr || w == nullptr || bias == nullptr || segs == nullptr || B <= 0 || S <= 0 || K <= 0 || E <= 0 || n_seg < 1 || n_seg > 3) return OEH_EINVAL;
   if ((K % oeh::kGemmBK) != 0 || (E & 63) != 0 || (S & 15) != 0 || B * (int64_t)S > 0x7fffffffLL) return OEH_ENOTSUP;
-  if (lda < (pairs ? 2 : 1) * (int64_t)K || ldw < K) return OEH_EINVAL;
-  if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w) | (uintptr_t)(lda * 2) | (uintptr_t)(ldw * 2)) & 15) != 0) return OEH_EALIGN;
-  if (B * (int64_t)S * lda * 2 >= 0xffffffffLL || (int64_t)n_seg * E * ldw * 2 >= 0xffffffffLL) return OEH_ENOTSUP;  // (32-bit lane offsets)
+  if (pairs < 0 || pairs > 2) return OEH_EINVAL;
+  const int64_t aeb = pairs == 2 ? 4 : 2;  // (pairs == 2: a is the fp32 activation matrix itself)
+  if (lda < (pairs == 1 ? 2 : 1) * (int64_t)K || ldw < K) return OEH_EINVAL;
+  if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w) | (uintptr_t)(lda * aeb) | (uintptr_t)(ldw * 2)) & 15) != 0) return OEH_EALIGN;
+  if (B * (int64_t)S * lda * aeb >= 0xffffffffLL || (int64_t)n_seg * E * ldw * 2 >= 0xffffffffLL) return OEH_ENOTSUP;  // (32-bit lane offsets)
   oeh::GemmParams P;
   std::memset(&P, 0, sizeof(P));
-  P.a = a; P.w = w; P.bias = bias; P.lda = lda; P.ldw = ldw; P.M = (int)(B * S); P.N = n_seg * E; P.K = K; P.pairs = pairs ? 1 : 0;
+  P.a = a; P.w = w; P.bias = bias; P.lda = lda; P.ldw = ldw; P.M = (int)(B * S); P.N = n_seg * E; P.K = K; P.pairs = pairs;
   P.E = E; P.S = S; P.H = E / 64;
   for (int i = 0; i < n_seg; ++i) {
     const oeh_proj_seg& g = segs[i];

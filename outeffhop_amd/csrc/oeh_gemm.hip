@@ -1,6 +1,7 @@
 // A QuantLinear projection - or the three of an attention layer side by side - as ONE matrix-core GEMM with the output quantisers in its
 // epilogue (include/oeh.h: oeh_proj_quant_i8).  Activations (M, K) fp16, or an fp32 model's activations
-// as fp16 operand pairs [hi | lo 2^11] (oeh_split_pairs); the QuantLinear weights as their 8-bit integers in fp16 (N rows of K,
+// as fp16 operand pairs [hi | lo 2^11] (oeh_split_pairs' output, or the fp32 matrix itself: its rows go to LDS as they are and a wave
+// forms (hi, lo) from the 8 values of a fragment when it reads them - split8, the split pass's own arithmetic); the QuantLinear weights as their 8-bit integers in fp16 (N rows of K,
 // exact); fp32 accumulation:
 //     acc[m][n] = sum_k hi[m][k] W[n][k] + sum_k lo[m][k] (W[n][k] 2^-11)
 // and, in the epilogue, per column segment (q | k | v): value = alpha acc + bias[n], the centred 8-bit index of the segment's quantiser in
@@ -25,8 +26,9 @@
 // Epilogue: 7 vector instructions per output (fma, the three-instruction exact quotient, rint, + zero point, v_cvt_pk_u8_f32 whose
 // saturation is the clamp; 9 with values), index bytes through LDS images (4 x 4 byte transposes inside lane quads for the row-major
 // one) so that they leave as whole 16-byte pieces of contiguous output; values straight from the accumulator layout, write-through.
-// Measured (one MI355X, M = 8192, K = 768): q/k/v (N = 2304, pairs) 74 us with the (k, v) values, 63 us without, against 107 / 91 us
-// for the library GEMM (hipBLASLt, 70 us) + three quantiser passes; out_proj (N = 768, integers) 20.5 against 31.8 us.  The loop alone
+// Measured (one MI355X, M = 8192, K = 768): q/k/v (N = 2304) from operand pairs 74 us with the (k, v) values, 63 us without, against 107 /
+// 91 us for the library GEMM (hipBLASLt, 70 us) + three quantiser passes; from the fp32 activations 76 / 70 us against 116 / 100 with the
+// 8.9-us split pass in front; out_proj (N = 768, integers) 20.5 against 31.8 us.  The loop alone
 // is 52-55 us = 1.1 PFLOP/s (40 us with the DMA and the barriers knocked out: the matrix core at the clock it holds under this load).
 #include "../../include/oeh.h"
 #include "oeh_common.h"
@@ -46,6 +48,10 @@ __device__ __forceinline__ void store_wt4_s(const void* sbase, unsigned voff, fl
 constexpr int GBK = kGemmBK, GROWB = 64;
 constexpr int kPer = 2;  // LDS-DMA pieces issued behind each of the first MFMA groups of a step (3 and 5 measured the same or slower)
 
+// activation forms: fp16 values; fp16 operand pairs [hi | lo] (oeh_split_pairs); fp32 values, split into (hi, lo) when a wave reads its
+// fragments (the split pass folded into the kernel: same arithmetic, oeh_common.h: split8)
+enum { A_F16 = 0, A_PAIRS = 1, A_F32 = 2 };
+
 // tile geometry for MI x NJ accumulator tiles (16 x 16) per wave, waves 2 x 2
 template <int MI, int NJ>
 struct Geo {
@@ -57,9 +63,15 @@ struct Geo {
 
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 
-template <bool PAIRS, int MI, int NJ>
+// swizzle of the fp32 activation image (rows of 128 B = eight 16-byte chunks): chunk c of row r is stored at c ^ swz32(r), swz32 = g[(r >> 1) & 7]
+// with g = (0, 2, 4, 5, 6, 7, 1, 3) - under ds_read_b128's lane groups (rows 0-3 and 12-15 of chunk c together with rows 4-11 of chunk c + 2) the
+// sixteen lanes of a group then hit sixteen different 16-byte bank groups, for both reads of a fragment
+__device__ __forceinline__ int swz32(int row) { return (int)((0x31765420u >> (4 * ((row >> 1) & 7))) & 7u); }
+
+template <int AM, int MI, int NJ>
 __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(const GemmParams P) {
   typedef Geo<MI, NJ> G;
+  constexpr bool PAIRS = AM != A_F16;   // two MFMA products per term: (hi, lo) of fp32 activations
   constexpr int GBM = G::BM, GBN = G::BN, G_AHI = G::AHI, G_ALO = G::ALO, G_W = G::W, G_SLOT = G::SLOT, G_PITCH_C = G::PITCH_C, G_IMG_C = G::IMG_C;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -99,8 +111,16 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
   for (int q = 0; q < NQ; ++q) {
     const int p = 4 * q + wave;
     if (q < QL) {
-      const int r = min(m0 + (p - (q < QA ? 0 : NPA)) * 16 + prow, P.M - 1);
-      voff[q] = (unsigned)(((long)r * P.lda) * 2 + pchunk * 16);
+      if constexpr (AM == A_F32) {
+        // fp32 rows of 128 B (32 values = one K step): a piece = 8 rows, lane -> row 8 p + (lane >> 3), stored chunk lane & 7 = logical
+        // chunk ^ swz32(row); the q < QL rounds carry the 2 NPA pieces of the fp32 image (the footprint of hi + lo)
+        const int rl = 8 * p + (lane >> 3);
+        const int r = min(m0 + rl, P.M - 1);
+        voff[q] = (unsigned)(((long)r * P.lda) * 4 + ((lane & 7) ^ swz32(rl)) * 16);
+      } else {
+        const int r = min(m0 + (p - (q < QA ? 0 : NPA)) * 16 + prow, P.M - 1);
+        voff[q] = (unsigned)(((long)r * P.lda) * 2 + pchunk * 16);
+      }
     } else {
       const int r = min(n0 + (p - QL * 4) * 16 + prow, P.N - 1);
       voff[q] = (unsigned)(((long)r * P.ldw) * 2 + pchunk * 16);
@@ -110,7 +130,8 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
     const unsigned slot = lds_base + (unsigned)((t & 1) * G_SLOT);
     const long kb = (long)t * (GBK * 2);
     const int p = 4 * q + wave;
-    if (q < QA) glds16_s(ab + kb, voff[q], slot + G_AHI + p * 1024);
+    if (AM == A_F32 && q < QL) glds16_s(ab + 2 * kb, voff[q], slot + G_AHI + p * 1024);
+    else if (q < QA) glds16_s(ab + kb, voff[q], slot + G_AHI + p * 1024);
     else if (q < QL) glds16_s(ab + (long)P.K * 2 + kb, voff[q], slot + G_ALO + (p - NPA) * 1024);
     else if (q < NQ - 1 || wave < NP - 4 * (NQ - 1)) glds16_s(wb + kb, voff[q], slot + G_W + (p - QL * 4) * 1024);
   };
@@ -123,6 +144,9 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
   const unsigned swz = (unsigned)((lq ^ ((-(l15 >> 2)) & 3)) << 4);
   const unsigned a_off = (unsigned)((16 * MI * wm + l15) * GROWB) + swz;
   const unsigned w_off = (unsigned)(G_W + (16 * NJ * wn + l15) * GROWB) + swz;
+  // fp32 image: the lane's 8 values of a fragment are chunks 2 lq and 2 lq + 1 of its row (two ds_read_b128, 16 B apart after the swizzle)
+  const unsigned a32_off = (unsigned)((16 * MI * wm + l15) * 128) + (unsigned)(((2 * lq) ^ swz32(l15)) << 4);
+  if constexpr (AM == A_F32) fp16_overflow_clamp();  // the split saturates beyond the fp16 range, as oeh_split_pairs does
 
   f4 acc[MI][NJ];
 #pragma unroll
@@ -140,10 +164,16 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
     if ((P.dbg & 64) && more) issue(t + 1);
     const unsigned char* sl = lds + (t & 1) * G_SLOT;
     h8v ah[MI], al[MI];
+    f4 x32[AM == A_F32 ? MI : 1][2];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      ah[i] = *reinterpret_cast<const h8v*>(sl + G_AHI + a_off + i * 16 * GROWB);
-      if constexpr (PAIRS) al[i] = *reinterpret_cast<const h8v*>(sl + G_ALO + a_off + i * 16 * GROWB);
+      if constexpr (AM == A_F32) {
+        x32[i][0] = *reinterpret_cast<const f4*>(sl + G_AHI + a32_off + i * 16 * 128);
+        x32[i][1] = *reinterpret_cast<const f4*>(sl + G_AHI + (a32_off ^ 16u) + i * 16 * 128);
+      } else {
+        ah[i] = *reinterpret_cast<const h8v*>(sl + G_AHI + a_off + i * 16 * GROWB);
+        if constexpr (PAIRS) al[i] = *reinterpret_cast<const h8v*>(sl + G_ALO + a_off + i * 16 * GROWB);
+      }
     }
     // every fragment of the step is requested before the first MFMA (17 ds_read_b128 in flight: the matrix core never waits for
     // LDS behind the first group); the compiler's counted lgkmcnt waits release the groups in order
@@ -151,6 +181,15 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const h8v*>(sl + w_off + j * 16 * GROWB);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (AM == A_F32) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {  // (hi, lo) = (RN16(x), RN16((x - hi) 2^11)): oeh_split_pairs' arithmetic on the fragment
+        u4 hi, lo;
+        split8(x32[i][0], x32[i][1], hi, lo);
+        ah[i] = __builtin_bit_cast(h8v, hi);
+        al[i] = __builtin_bit_cast(h8v, lo);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
 #pragma unroll
@@ -273,17 +312,17 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
   }
 }
 
-template <bool PAIRS, int MI, int NJ>
+template <int AM, int MI, int NJ>
 static int launch_gemm_t(const GemmParams& P, hipStream_t st) {
   static bool attr[64] = {};   // (the LDS opt-in is per device: a process that drives several GPUs sets it on each)
   const int ldsb = Geo<MI, NJ>::LDS;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -5;
   if (!attr[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&oeh_gemm_kernel<PAIRS, MI, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return -5;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&oeh_gemm_kernel<AM, MI, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return -5;
     attr[dev] = true;
   }
-  hipLaunchKernelGGL((oeh_gemm_kernel<PAIRS, MI, NJ>), dim3(P.MT * P.NT), dim3(256), ldsb, st, P);
+  hipLaunchKernelGGL((oeh_gemm_kernel<AM, MI, NJ>), dim3(P.MT * P.NT), dim3(256), ldsb, st, P);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
@@ -304,10 +343,10 @@ int launch_gemm(const GemmParams& P0, hipStream_t st) {
   const bool big = force ? force == 1 : (t0 >= 512 && waste0 <= 1.06);
   if (big) {
     P.MT = (P.M + 127) / 128; P.NT = (P.N + 287) / 288;
-    return P.pairs ? launch_gemm_t<true, 4, 9>(P, st) : launch_gemm_t<false, 4, 9>(P, st);
+    return P.pairs == 2 ? launch_gemm_t<A_F32, 4, 9>(P, st) : P.pairs ? launch_gemm_t<A_PAIRS, 4, 9>(P, st) : launch_gemm_t<A_F16, 4, 9>(P, st);
   }
   P.MT = (P.M + 63) / 64; P.NT = (P.N + 191) / 192;
-  return P.pairs ? launch_gemm_t<true, 2, 6>(P, st) : launch_gemm_t<false, 2, 6>(P, st);
+  return P.pairs == 2 ? launch_gemm_t<A_F32, 2, 6>(P, st) : P.pairs ? launch_gemm_t<A_PAIRS, 2, 6>(P, st) : launch_gemm_t<A_F16, 2, 6>(P, st);
 }
 
 }  // namespace oeh

@@ -379,15 +379,20 @@ def quantize_heads_i8(x: torch.Tensor, spec: "FakeQuantSpec", H: int, transpose:
 
 def proj_quant_i8(a: torch.Tensor, w_int: torch.Tensor, bias: torch.Tensor, B: int, S: int, segs, *, pairs: bool):
     """The q / k / v projections of a QuantLinear model as ONE GEMM with the output quantisers in its epilogue (`oeh_proj_quant_i8`):
-    a (B*S, K) fp16 activations or (B*S, 2K) operand pairs of an fp32 model (`split_pairs`), w_int (n*E, K) fp16 = the weights'
+    a (B*S, K) fp16 activations, (B*S, 2K) operand pairs of an fp32 model (`split_pairs`) or the fp32 activations (B*S, K) themselves
+    (split inside the kernel: same result as the pairs, without the pass), w_int (n*E, K) fp16 = the weights'
     integers, the segments one after the other, bias (n*E) fp32; `segs` = one (alpha, FakeQuantSpec, transpose, want_values) per
     segment.  Returns per segment what `quantize_heads_i8` returns: the centred int8 indices as a logical (B,H,S,64) view of
     (B,S,E), or the contiguous (B,H,64,S) tensor with `transpose`, and with `want_values` the pair (indices, values (B,S,E) fp32)."""
     dev = _need_gpu(a, w_int, bias)
     K = w_int.shape[1]
     n = len(segs)
-    if a.dtype != torch.float16 or w_int.dtype != torch.float16 or bias.dtype != torch.float32 or a.dim() != 2 or w_int.dim() != 2:
-        raise ValueError("a, w_int must be 2-D fp16 and bias fp32")
+    if a.dtype == torch.float32:  # the fp32 activations themselves: split into (hi, lo) inside the kernel, `pairs` is implied
+        form, pairs = 2, False
+    else:
+        form = 1 if pairs else 0
+    if a.dtype not in (torch.float16, torch.float32) or w_int.dtype != torch.float16 or bias.dtype != torch.float32 or a.dim() != 2 or w_int.dim() != 2:
+        raise ValueError("a 2-D fp16 (values or operand pairs) or fp32, w_int 2-D fp16, bias fp32")
     if a.shape != (B * S, (2 if pairs else 1) * K) or w_int.shape[0] % n != 0 or bias.numel() != w_int.shape[0] or not bias.is_contiguous():
         raise ValueError("shapes: a (B*S, K or 2K), w_int (n*E, K), bias (n*E)")
     if a.stride(1) != 1 or w_int.stride(1) != 1:
@@ -407,7 +412,7 @@ def proj_quant_i8(a: torch.Tensor, w_int: torch.Tensor, bias: torch.Tensor, B: i
         idx = out if transpose else out.view(B, S, H, 64).permute(0, 2, 1, 3)
         res.append((idx, y) if want_values else idx)
     with _on_device(dev):
-        rc = _lib.load().oeh_proj_quant_i8(_ptr(a), int(bool(pairs)), _ptr(w_int), _ptr(bias), B, S, K, E, n, arr, a.stride(0), w_int.stride(0), _stream())
+        rc = _lib.load().oeh_proj_quant_i8(_ptr(a), form, _ptr(w_int), _ptr(bias), B, S, K, E, n, arr, a.stride(0), w_int.stride(0), _stream())
     _lib.check(rc, "oeh_proj_quant_i8")
     return res
 

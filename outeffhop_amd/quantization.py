@@ -847,10 +847,14 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
                 and all(type(z) is AsymmetricUniformQuantizer for z in qzs)):
             # fp32 model, ONE kernel: the pair GEMM against the three integer weight matrices with weight scale, bias and the three output
             # quantisers in its epilogue (`oeh_proj_quant_i8`) - the (B*T, 3E) accumulator never reaches memory
-            pairs = ops.split_pairs(hidden_states.reshape(-1, K_in))
+            # (the fp32 activations go in as they are: the (hi, lo) operand split happens when a wave reads its fragments - the same
+            # values as `ops.split_pairs` would write, without the pass)
+            x2 = hidden_states.reshape(-1, K_in)
+            if x2.stride(1) != 1 or (x2.stride(0) * 4) % 16 != 0 or x2.data_ptr() % 16 != 0:
+                x2 = x2.contiguous()
             w3, b3, scales3 = self._qkv_int_weights(lins)
             specs = [z.spec() for z in qzs]
-            outs = ops.proj_quant_i8(pairs, w3, b3, bsz, tgt_len, [(scales3[n_], specs[n_], n_ == 2, n_ > 0 and want_values) for n_ in range(3)], pairs=True)
+            outs = ops.proj_quant_i8(x2, w3, b3, bsz, tgt_len, [(scales3[n_], specs[n_], n_ == 2, n_ > 0 and want_values) for n_ in range(3)], pairs=True)
             grids = [ops.QuantGrid.of(sp) for sp in specs]
             self.__dict__["_fused_proj_calls"] = self.__dict__.get("_fused_proj_calls", 0) + 1  # (tests: which path ran)
         elif all_pairs:

@@ -132,3 +132,25 @@ def test_projection_gemm_random_shapes_against_the_library_path():
                 rows = inw.permute(0, 1, 3, 2) if tr else inw
                 want_y = np.float32(sp.scale) * (rows.permute(0, 2, 1, 3).reshape(B, S, E).float() + 128.0 - sp.zero_point)
                 assert torch.equal(yn, want_y)
+
+
+@pytest.mark.parametrize("B,S,H,K", [(16, 512, 12, 768), (4, 128, 12, 768), (3, 48, 2, 64), (5, 80, 12, 768)])
+def test_fp32_activations_split_inside_the_kernel_equal_the_operand_pairs(B, S, H, K):
+    """`a` as the fp32 activation matrix (the (hi, lo) split at fragment-read time, oeh_common.h: split8) against the same call on
+    `oeh_split_pairs`' output: the same operands in the same accumulation order - bit-identical indices and values, values beyond the
+    fp16 range included (both saturate)."""
+    from outeffhop_amd import ops
+
+    torch.manual_seed(11 + S)
+    E, M = H * 64, B * S
+    x = torch.randn(M, K, device="cuda")
+    x[:, ::53] *= 40.0
+    x[0, 1], x[1, 2] = 7.0e4, -3.0e5     # beyond fp16
+    wi = torch.randint(-128, 128, (3 * E, K), device="cuda").to(torch.float16)
+    bias = torch.randn(3 * E, device="cuda") * 0.1
+    specs = [ops.FakeQuantSpec(0.03, 131.0), ops.FakeQuantSpec(0.035, 124.0), ops.FakeQuantSpec(0.03, 128.0)]
+    segs = [(0.003, specs[n], n == 2, n > 0) for n in range(3)]
+    flat = lambda r: [t_ for o in r for t_ in (o if isinstance(o, tuple) else (o,))]  # noqa: E731
+    a = flat(ops.proj_quant_i8(ops.split_pairs(x), wi, bias, B, S, segs, pairs=True))
+    b = flat(ops.proj_quant_i8(x, wi, bias, B, S, segs, pairs=True))
+    assert len(a) == len(b) == 5 and all(torch.equal(p_, q_) for p_, q_ in zip(a, b))

@@ -65,6 +65,10 @@ def main():
             line += f" (library GEMM + pass {gtime(oldo):.1f})"
         t = gtime(lambda: ops.split_pairs(x.view(M, K)))
         line += f" | split_pairs {t:.1f} us"
+        x2 = x.view(M, K)
+        for want in (True, False):
+            t = gtime(lambda: ops.proj_quant_i8(x2, wi, bias, B, S, [(0.003, sp, n == 2, n > 0 and want) for n in range(3)], pairs=True))
+            line += f" | qkv from fp32 (split inside) values={int(want)} {t:.1f} us"
         print(line, flush=True)
 
 
