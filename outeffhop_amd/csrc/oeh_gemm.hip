@@ -182,33 +182,52 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
     for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const h8v*>(sl + w_off + j * 16 * GROWB);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (AM == A_F32) {
+      // fragment-major first sweep: (hi, lo) of fragment i + 1 are formed (split8: oeh_split_pairs' arithmetic, ~25 vector instructions)
+      // while the matrix core works through the NJ hi products of fragment i; then the lo products column-major as in the other forms
+      constexpr int PI = (NQ + MI - 1) / MI;   // LDS-DMA pieces of the next tile issued behind each fragment's group
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {  // (hi, lo) = (RN16(x), RN16((x - hi) 2^11)): oeh_split_pairs' arithmetic on the fragment
+      for (int i = 0; i < MI; ++i) {
         u4 hi, lo;
         split8(x32[i][0], x32[i][1], hi, lo);
         ah[i] = __builtin_bit_cast(h8v, hi);
         al[i] = __builtin_bit_cast(h8v, lo);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bf[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(P.dbg & 64) && more) {
+#pragma unroll
+          for (int u = 0; u < PI; ++u)
+            if (PI * i + u < NQ) issue_q(t + 1, PI * i + u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-    }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bf[j], acc[i][j], 0, 0, 0);
-      if constexpr (PAIRS) {
+      for (int j = 0; j < NJ; ++j) {
         const h8v bs = bf[j] * (_Float16)0.00048828125f;  // 2^-11: exact on the 8-bit integers
 #pragma unroll
         for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bs, acc[i][j], 0, 0, 0);
       }
-      // the next tile's LDS-DMA pieces go out between the first MFMA groups (two per group): the matrix core has work queued while the
-      // wave spends its issue slots on them, and every piece is under way before the middle of the step
-      if (kPer * j < NQ) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(P.dbg & 64) && more) {
+    } else {
 #pragma unroll
-          for (int u = 0; u < kPer; ++u)
-            if (kPer * j + u < NQ) issue_q(t + 1, kPer * j + u);
+      for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bf[j], acc[i][j], 0, 0, 0);
+        if constexpr (PAIRS) {
+          const h8v bs = bf[j] * (_Float16)0.00048828125f;  // 2^-11: exact on the 8-bit integers
+#pragma unroll
+          for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bs, acc[i][j], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        // the next tile's LDS-DMA pieces go out between the first MFMA groups (two per group): the matrix core has work queued while the
+        // wave spends its issue slots on them, and every piece is under way before the middle of the step
+        if (kPer * j < NQ) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(P.dbg & 64) && more) {
+#pragma unroll
+            for (int u = 0; u < kPer; ++u)
+              if (kPer * j + u < NQ) issue_q(t + 1, kPer * j + u);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   }
