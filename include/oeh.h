@@ -147,7 +147,8 @@ typedef struct oeh_attn_desc {
    *   (for q: AFTER OPT's `* scaling`, i.e. fold head_dim^-0.5 into q_grid.scale or pass it as `scale`);
    *   q, k: (B,H,S,D) views as usual (strides in elements = bytes); v TRANSPOSED: a (B,H,D,Sk) view, keys contiguous,
    *   v_stride = (batch, head, d row) - the second product sums over keys;
-   *   o has dtype o_dtype (OEH_F16 | OEH_BF16 | OEH_F32).
+   *   o has dtype o_dtype (OEH_F16 | OEH_BF16 | OEH_F32; ABI 6: OEH_I8 with oeh_fq_desc.ctx_emit_index on a full 8-bit context grid with a
+   *   whole zero point - o then holds the context quantiser's CENTRED indices idx - 128 as int8, what oeh_proj_quant_i8 takes with pairs == 3).
    * Requires D == 64, Sk <= 512 and a multiple of 16, 16-byte aligned rows, masks none | causal | key_pad_mask (with or
    * without causal) whose entries are 0 (visible) or <= -1e4 (padded: HF's extended masks hold 0 / finfo.min) - a padded key is
    * dropped exactly like a causally hidden one, other mask values are NOT added to the scores on this path -, clipping only with gamma <= 0 (the reference's registry), and `fq`
@@ -296,8 +297,10 @@ int oeh_split_triples(const float* x, void* out_f16, int64_t rows, int32_t K, in
  *   a: the activations (B*S rows, row stride lda elements, 16-byte aligned rows) - pairs == 0: fp16 (rows, K); pairs == 1: fp16
  *      (rows, 2K), the operand pairs [hi | lo] that oeh_split_pairs writes for an fp32 model; pairs == 2: the fp32 activations (rows, K)
  *      themselves - the kernel forms the same (hi, lo) pairs when a wave reads its operand fragments: same result as pairs == 1,
- *      bit for bit, without the split pass;
- *   w: (n_seg*E, K) fp16, row stride ldw: the QuantLinear weights' INTEGERS (w / weight scale: exact in fp16), the segments' rows
+ *      bit for bit, without the split pass; pairs == 3: int8 (rows, K) - e.g. the centred indices idx - 128 of the producer's 8-bit
+ *      quantiser (oeh_attn_fwd, dtype OEH_I8, o_dtype OEH_I8) - against int8 weights on the integer matrix cores (K % 64 == 0): exact
+ *      int32 sums; with acc_add[n] = (128 - zero_point) * sum_k w[n][k] the accumulator is the sum over idx - zero_point;
+ *   w: (n_seg*E, K) fp16 (int8 with pairs == 3), row stride ldw: the QuantLinear weights' INTEGERS (w / weight scale: exact in fp16), the segments' rows
  *      one after the other; pairs != 0 multiplies the lo half against w * 2^-11, formed in registers (exact on integers);
  *   bias: (n_seg*E) fp32; segment i covers output columns [i*E, (i+1)*E) and turns the fp32 accumulator into
  *      value = alpha * acc + bias[column],  c = clamp(rint(value / scale) + zero_point, 0, 255) - 128:
@@ -315,6 +318,7 @@ typedef struct {
   float* y;
   int64_t y_stride_row;
   int32_t transpose;
+  const int32_t* acc_add;   /* pairs == 3 only: E integers added to the int32 accumulator before alpha (NULL: none) */
 } oeh_proj_seg;
 int oeh_proj_quant_i8(const void* a, int32_t pairs, const void* w, const float* bias, int64_t B, int32_t S, int32_t K, int32_t E, int32_t n_seg,
                       const oeh_proj_seg* segs, int64_t lda, int64_t ldw, void* stream);

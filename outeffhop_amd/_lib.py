@@ -62,7 +62,7 @@ class oeh_attn_desc(C.Structure):
 class oeh_proj_seg(C.Structure):
     """include/oeh.h: one column segment (a projection) of oeh_proj_quant_i8."""
     _fields_ = [("alpha", C.c_float), ("scale", C.c_float), ("zero_point", C.c_float), ("out", C.c_void_p), ("y", C.c_void_p),
-                ("y_stride_row", C.c_int64), ("transpose", C.c_int32)]
+                ("y_stride_row", C.c_int64), ("transpose", C.c_int32), ("acc_add", C.c_void_p)]
 
 
 # every symbol include/oeh.h declares (tests/test_abi.py checks the .so exports exactly these)

@@ -46,7 +46,7 @@ using oeh::FqP;
 namespace {
 
 bool dtype_ok(int d) { return d == OEH_F16 || d == OEH_BF16 || d == OEH_F32; }
-int elem_bytes(int d) { return d == OEH_F32 ? 4 : 2; }
+int elem_bytes(int d) { return d == OEH_F32 ? 4 : d == OEH_I8 ? 1 : 2; }
 
 // RN(scale * log2(e)), the product formed in double
 float scale_log2e(float scale) { return (float)((double)scale * 1.4426950408889634074); }
@@ -84,7 +84,10 @@ int validate(const oeh_attn_desc* d, const void* q, const void* k, const void* v
   if (d->B <= 0 || d->H <= 0 || d->Sq <= 0 || d->Sk <= 0 || d->D <= 0) return OEH_EINVAL;
   if (!dtype_ok(d->dtype) && d->dtype != OEH_I8) return OEH_EINVAL;
   if (d->dtype == OEH_I8) {
-    if (!dtype_ok(d->o_dtype)) return OEH_EINVAL;
+    if (!dtype_ok(d->o_dtype) && d->o_dtype != OEH_I8) return OEH_EINVAL;
+    // (an int8 output is the context quantiser's centred indices: only with ctx_emit_index on a full 8-bit grid with a whole zero point)
+    if (d->o_dtype == OEH_I8 && (fq == nullptr || !fq->ctx_emit_index || !fq->ctx.enable || fq->ctx.qmax != 255.0f || fq->ctx.zero_point != std::nearbyint(fq->ctx.zero_point)))
+      return OEH_EINVAL;
     const float zs[3] = {d->q_grid.zero_point, d->k_grid.zero_point, d->v_grid.zero_point};
     const float ss[3] = {d->q_grid.scale, d->k_grid.scale, d->v_grid.scale};
     for (int i = 0; i < 3; ++i)
@@ -385,7 +388,7 @@ const char* variant_name(Variant v, const oeh_attn_desc* d, bool fq) {
   if (v == V_GENERIC) return "generic";
   if (v == V_I8) {
     std::snprintf(buf, sizeof(buf), "i8mfma/NT%d/D64/%s", d->Sk <= 128 ? 8 : (d->Sk <= 256 ? 16 : 32),
-                  d->o_dtype == OEH_F16 ? "f16" : (d->o_dtype == OEH_BF16 ? "bf16" : "f32"));
+                  d->o_dtype == OEH_F16 ? "f16" : (d->o_dtype == OEH_BF16 ? "bf16" : (d->o_dtype == OEH_I8 ? "i8" : "f32")));
     return buf;
   }
   if (v == V_SMALL) {
@@ -583,11 +586,13 @@ int oeh_proj_quant_i8(const void* a, int32_t pairs, const void* w, const float* 
                       const oeh_proj_seg* segs, int64_t lda, int64_t ldw, void* stream) {
   if (a == nullptr || w == nullptr || bias == nullptr || segs == nullptr || B <= 0 || S <= 0 || K <= 0 || E <= 0 || n_seg < 1 || n_seg > 3) return OEH_EINVAL;
   if ((K % oeh::kGemmBK) != 0 || (E & 63) != 0 || (S & 15) != 0 || B * (int64_t)S > 0x7fffffffLL) return OEH_ENOTSUP;
-  if (pairs < 0 || pairs > 2) return OEH_EINVAL;
-  const int64_t aeb = pairs == 2 ? 4 : 2;  // (pairs == 2: a is the fp32 activation matrix itself)
+  if (pairs < 0 || pairs > 3) return OEH_EINVAL;
+  const int64_t aeb = pairs == 2 ? 4 : pairs == 3 ? 1 : 2;  // (pairs == 2: a is the fp32 activation matrix itself; 3: int8 a and w)
+  const int64_t web = pairs == 3 ? 1 : 2;
+  if (pairs == 3 && (K & 63) != 0) return OEH_ENOTSUP;
   if (lda < (pairs == 1 ? 2 : 1) * (int64_t)K || ldw < K) return OEH_EINVAL;
-  if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w) | (uintptr_t)(lda * aeb) | (uintptr_t)(ldw * 2)) & 15) != 0) return OEH_EALIGN;
-  if (B * (int64_t)S * lda * aeb >= 0xffffffffLL || (int64_t)n_seg * E * ldw * 2 >= 0xffffffffLL) return OEH_ENOTSUP;  // (32-bit lane offsets)
+  if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w) | (uintptr_t)(lda * aeb) | (uintptr_t)(ldw * web)) & 15) != 0) return OEH_EALIGN;
+  if (B * (int64_t)S * lda * aeb >= 0xffffffffLL || (int64_t)n_seg * E * ldw * web >= 0xffffffffLL) return OEH_ENOTSUP;  // (32-bit lane offsets)
   oeh::GemmParams P;
   std::memset(&P, 0, sizeof(P));
   P.a = a; P.w = w; P.bias = bias; P.lda = lda; P.ldw = ldw; P.M = (int)(B * S); P.N = n_seg * E; P.K = K; P.pairs = pairs;
@@ -600,6 +605,8 @@ int oeh_proj_quant_i8(const void* a, int32_t pairs, const void* w, const float* 
     if (g.y != nullptr && g.y_stride_row < E) return OEH_EINVAL;
     oeh::GemmSeg& t = P.seg[i];
     t.alpha = g.alpha; t.out = reinterpret_cast<signed char*>(g.out); t.y = g.y; t.y_ld = g.y_stride_row; t.transpose = g.transpose ? 1 : 0;
+    t.acc_add = pairs == 3 ? g.acc_add : nullptr;
+    if ((reinterpret_cast<uintptr_t>(g.acc_add) & 3) != 0) return OEH_EALIGN;
     t.f.en = 1; t.f.scale = g.scale; t.f.rscale = 1.0f / g.scale; t.f.zp = g.zero_point; t.f.qmax = 255.0f; t.f.lo = -g.zero_point; t.f.hi = 255.0f - g.zero_point;
   }
   return oeh::launch_gemm(P, reinterpret_cast<hipStream_t>(stream));

@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   constexpr int R = 6, PF = 2;
   constexpr float RELMASK = -1.0e30f;
   constexpr bool OUT32 = (OUT == IN_F32);
+  constexpr bool OUT8 = (OUT == 3);  // the context quantiser's CENTRED INDICES idx - 128 as int8 (fq.ctx_emit_index with o_dtype OEH_I8)
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * R * TILEB];
   // PAD: per key +big (visible), the sentinel (padded) or -inf (key >= Sk: not even a masked key - a fully masked row of the
   // vanilla softmax is uniform over the Sk keys, as in the reference): rel = min(rel, flag), one instruction per element
@@ -367,8 +368,8 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
   const int ce = lane_e & 15, ge = lane_e >> 4;
-  constexpr int ROWB = 2 * D;
-  unsigned char* ebase = lds + wave * (16 * ROWB);  // 16-bit output: staged through K slots 0 and 1, whole rows stored
+  constexpr int ROWB = OUT8 ? D : 2 * D;
+  unsigned char* ebase = lds + wave * (16 * ROWB);  // 16-bit / int8 output: staged through K slots 0 and 1, whole rows stored
   if constexpr (!OUT32) {
     if (n_kt > R) barrier_mem();  // (those slots hold V^T tiles R, R + 1 of a long row: every wave must have left them)
   }
@@ -394,6 +395,12 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
       if (q0 + ce < P.Sq)
         store_wt16(reinterpret_cast<float*>(P.o) + bh_offset(b, P.os_b, h, P.os_h) + (long)(q0 + ce) * P.os_s + 16 * dt + 4 * ge,
                    u4{f32_bits(ov[0]), f32_bits(ov[1]), f32_bits(ov[2]), f32_bits(ov[3])});
+    } else if constexpr (OUT8) {
+      // ov = idx - zp (the quantiser's integers, oscale 1): idx by v_cvt_pk_u8_f32 (exact on whole numbers in [0, 255]), centred by the XOR
+      unsigned w8 = 0u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w8 = __builtin_amdgcn_cvt_pk_u8_f32(ov[r] + P.fq_c.zp, r, w8);
+      *reinterpret_cast<unsigned*>(ebase + ce * ROWB + 16 * dt + 4 * ge) = w8 ^ 0x80808080u;
     } else {
       u2 w;
       if constexpr (OUT == IN_BF16) { w.x = pack2_bf16(ov[0], ov[1]); w.y = pack2_bf16(ov[2], ov[3]); }
@@ -401,7 +408,13 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
       *reinterpret_cast<u2*>(ebase + ce * ROWB + ((((2 * dt + (ge >> 1)) ^ (ce & 7)) << 4) | ((ge & 1) << 3))) = w;
     }
   }
-  if constexpr (!OUT32) {
+  if constexpr (OUT8) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    unsigned char* obase8 = reinterpret_cast<unsigned char*>(P.o) + bh_offset(b, P.os_b, h, P.os_h);
+    const int row = lane_e >> 2, lc = lane_e & 3;  // 4 chunks of 16 B per 64-B row, 16 rows in one pass
+    const u4 w = *reinterpret_cast<const u4*>(ebase + row * ROWB + (lc << 4));
+    if (q0 + row < P.Sq) store_wt16(obase8 + (long)(q0 + row) * P.os_s + lc * 16, w);
+  } else if constexpr (!OUT32) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     unsigned short* obase = reinterpret_cast<unsigned short*>(P.o) + bh_offset(b, P.os_b, h, P.os_h);
     const int lr = lane_e >> 3, lc = lane_e & 7;  // 8 chunks of 16 B per 128-B row, 8 rows per pass
@@ -438,6 +451,7 @@ static int launch_i8_nt(const AttnParams& P, int out, hipStream_t st) {
   switch (out) {
     case IN_F16: launch_i8_variant<NT, IN_F16, false>(P, grid, st); break;
     case IN_BF16: launch_i8_variant<NT, IN_BF16, false>(P, grid, st); break;
+    case 3: launch_i8_variant<NT, 3, false>(P, grid, st); break;  // int8 centred indices (ctx_emit_index)
     default: launch_i8_variant<NT, IN_F32, false>(P, grid, st); break;
   }
   return hipGetLastError() == hipSuccess ? 0 : -5;

@@ -13,6 +13,7 @@ struct GemmSeg {            // one column segment (a projection): columns [n0, n
   float* y;                 // dequantised values (B, S, E) fp32 with row stride y_ld, or nullptr
   long y_ld;
   int transpose;
+  const int* acc_add;       // int8 form: per-column integer added to the int32 accumulator (E entries), or nullptr
 };
 
 struct GemmParams {
@@ -28,7 +29,7 @@ struct GemmParams {
   GemmSeg seg[3];
 };
 
-constexpr int kGemmBK = 32;  // K must be a multiple
+constexpr int kGemmBK = 32;  // K must be a multiple (64 in the int8 form: a step is 64 bytes of a row)
 
 int launch_gemm(const GemmParams& P, hipStream_t st);
 

@@ -49,8 +49,9 @@ constexpr int GBK = kGemmBK, GROWB = 64;
 constexpr int kPer = 2;  // LDS-DMA pieces issued behind each of the first MFMA groups of a step (3 and 5 measured the same or slower)
 
 // activation forms: fp16 values; fp16 operand pairs [hi | lo] (oeh_split_pairs); fp32 values, split into (hi, lo) when a wave reads its
-// fragments (the split pass folded into the kernel: same arithmetic, oeh_common.h: split8)
-enum { A_F16 = 0, A_PAIRS = 1, A_F32 = 2 };
+// fragments (the split pass folded into the kernel: same arithmetic, oeh_common.h: split8); int8 values against int8 weights on
+// v_mfma_i32_16x16x64_i8 (a K step is 64 elements = the same 64-byte rows; exact int32 sums, + a per-column integer in the epilogue)
+enum { A_F16 = 0, A_PAIRS = 1, A_F32 = 2, A_I8 = 3 };
 
 // tile geometry for MI x NJ accumulator tiles (16 x 16) per wave, waves 2 x 2
 template <int MI, int NJ>
@@ -62,6 +63,7 @@ struct Geo {
 };
 
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef int i4 __attribute__((ext_vector_type(4)));
 
 // swizzle of the fp32 activation image (rows of 128 B = eight 16-byte chunks): chunk c of row r is stored at c ^ swz32(r), swz32 = g[(r >> 1) & 7]
 // with g = (0, 2, 4, 5, 6, 7, 1, 3) - under ds_read_b128's lane groups (rows 0-3 and 12-15 of chunk c together with rows 4-11 of chunk c + 2) the
@@ -71,7 +73,8 @@ __device__ __forceinline__ int swz32(int row) { return (int)((0x31765420u >> (4 
 template <int AM, int MI, int NJ>
 __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(const GemmParams P) {
   typedef Geo<MI, NJ> G;
-  constexpr bool PAIRS = AM != A_F16;   // two MFMA products per term: (hi, lo) of fp32 activations
+  constexpr bool PAIRS = AM == A_PAIRS || AM == A_F32;   // two MFMA products per term: (hi, lo) of fp32 activations
+  constexpr int EB = AM == A_I8 ? 1 : 2;               // bytes per element of a and w (a K step is 64 bytes of a row either way)
   constexpr int GBM = G::BM, GBN = G::BN, G_AHI = G::AHI, G_ALO = G::ALO, G_W = G::W, G_SLOT = G::SLOT, G_PITCH_C = G::PITCH_C, G_IMG_C = G::IMG_C;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
     }
   }
   const int m0 = mi * GBM, n0 = ni * GBN;
-  const int T = (P.dbg & 2) ? 2 : P.K / GBK;
+  const int T = (P.dbg & 2) ? 2 : P.K * EB / (GBK * 2);
 
   // ---- LDS-DMA: piece p (1 KB = 16 rows x 64 B); lane -> row p * 16 + (lane >> 2), stored chunk lane & 3 = logical chunk ^ (-(row >> 2) & 3)
   const unsigned lds_base = lds_offset(lds);
@@ -119,11 +122,11 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
         voff[q] = (unsigned)(((long)r * P.lda) * 4 + ((lane & 7) ^ swz32(rl)) * 16);
       } else {
         const int r = min(m0 + (p - (q < QA ? 0 : NPA)) * 16 + prow, P.M - 1);
-        voff[q] = (unsigned)(((long)r * P.lda) * 2 + pchunk * 16);
+        voff[q] = (unsigned)(((long)r * P.lda) * EB + pchunk * 16);
       }
     } else {
       const int r = min(n0 + (p - QL * 4) * 16 + prow, P.N - 1);
-      voff[q] = (unsigned)(((long)r * P.ldw) * 2 + pchunk * 16);
+      voff[q] = (unsigned)(((long)r * P.ldw) * EB + pchunk * 16);
     }
   }
   auto issue_q = [&](int t, int q) {
@@ -211,7 +214,13 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MI; ++i) {
+          if constexpr (AM == A_I8)
+            acc[i][j] = __builtin_bit_cast(f4, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i4, ah[i]), __builtin_bit_cast(i4, bf[j]),
+                                                                                      __builtin_bit_cast(i4, acc[i][j]), 0, 0, 0));
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bf[j], acc[i][j], 0, 0, 0);
+        }
         if constexpr (PAIRS) {
           const h8v bs = bf[j] * (_Float16)0.00048828125f;  // 2^-11: exact on the 8-bit integers
 #pragma unroll
@@ -262,6 +271,12 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
         const FqP f = g.f;
         const float alpha = g.alpha;
         const float bia = biav[j];
+        int iadd = 0;  // int8 form: the accumulator is an int32 sum of centred indices; + (128 - zero_point) * column sum of w = the sum over idx - zp
+        if constexpr (AM == A_I8) iadd = g.acc_add != nullptr ? g.acc_add[(n - sg * P.E) + l15] : 0;
+        auto accv = [&](int i, int r) -> float {
+          if constexpr (AM == A_I8) return (float)((int)f32_bits(acc[i][j][r]) + iadd);  // (f32_bits: not __builtin_bit_cast of a vector element - oeh_common.h)
+          else return acc[i][j][r];
+        };
         // values: wave-uniform row base (scalar registers) + one lane offset for the whole tile column: no vector address arithmetic per store
         const long y_ld = g.y_ld;
         const char* ybase = g.y != nullptr ? reinterpret_cast<const char*>(g.y + (long)(m0 + 16 * MI * wm) * y_ld + (n - sg * P.E)) : nullptr;
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
             const bool rows_in = m0 + 16 * MI * wm + 16 * i < P.M && !(P.dbg & 16);  // (M % 16 == 0: a 16-row tile is inside or outside as a whole)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float rel = fq_rel(__builtin_fmaf(acc[i][j][r], alpha, bia), f);
+              const float rel = fq_rel(__builtin_fmaf(accv(i, r), alpha, bia), f);
               word = __builtin_amdgcn_cvt_pk_u8_f32(rel + f.zp, r, word);
               if (rows_in) store_wt4_s(ybase + (long)(16 * i + r) * y_ld * 4, y_voff, f.scale * rel);
             }
@@ -283,7 +298,7 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
             // (no values wanted: the conversion's saturation to [0, 255] is the clamp)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              word = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fq_quot(__builtin_fmaf(acc[i][j][r], alpha, bia), f)) + f.zp, r, word);
+              word = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fq_quot(__builtin_fmaf(accv(i, r), alpha, bia), f)) + f.zp, r, word);
           }
           word ^= 0x80808080u;
           if (idx_c) *reinterpret_cast<unsigned*>(img_c + (nl + l15) * G_PITCH_C + rl) = word;
@@ -362,10 +377,10 @@ int launch_gemm(const GemmParams& P0, hipStream_t st) {
   const bool big = force ? force == 1 : (t0 >= 512 && waste0 <= 1.06);
   if (big) {
     P.MT = (P.M + 127) / 128; P.NT = (P.N + 287) / 288;
-    return P.pairs == 2 ? launch_gemm_t<A_F32, 4, 9>(P, st) : P.pairs ? launch_gemm_t<A_PAIRS, 4, 9>(P, st) : launch_gemm_t<A_F16, 4, 9>(P, st);
+    return P.pairs == 3 ? launch_gemm_t<A_I8, 4, 9>(P, st) : P.pairs == 2 ? launch_gemm_t<A_F32, 4, 9>(P, st) : P.pairs ? launch_gemm_t<A_PAIRS, 4, 9>(P, st) : launch_gemm_t<A_F16, 4, 9>(P, st);
   }
   P.MT = (P.M + 63) / 64; P.NT = (P.N + 191) / 192;
-  return P.pairs == 2 ? launch_gemm_t<A_F32, 2, 6>(P, st) : P.pairs ? launch_gemm_t<A_PAIRS, 2, 6>(P, st) : launch_gemm_t<A_F16, 2, 6>(P, st);
+  return P.pairs == 3 ? launch_gemm_t<A_I8, 2, 6>(P, st) : P.pairs == 2 ? launch_gemm_t<A_F32, 2, 6>(P, st) : P.pairs ? launch_gemm_t<A_PAIRS, 2, 6>(P, st) : launch_gemm_t<A_F16, 2, 6>(P, st);
 }
 
 }  // namespace oeh

@@ -417,14 +417,21 @@ def proj_quant_i8(a: torch.Tensor, w_int: torch.Tensor, bias: torch.Tensor, B: i
     return res
 
 
-def proj_quant_values(a: torch.Tensor, w_int: torch.Tensor, bias: torch.Tensor, alpha: float, spec: "FakeQuantSpec", *, pairs: bool) -> torch.Tensor:
+def proj_quant_values(a: torch.Tensor, w_int: torch.Tensor, bias: torch.Tensor, alpha: float, spec: "FakeQuantSpec", *, pairs: bool,
+                      acc_add: Optional[torch.Tensor] = None) -> torch.Tensor:
     """A whole QuantLinear in one kernel (`oeh_proj_quant_i8`, values only): fake_quant(alpha * (a @ w_int^T) + bias) as fp32 (rows, N) -
     a (rows, K) fp16 (e.g. the integers of the producer's quantiser: exact products) or (rows, 2K) operand pairs, w_int (N, K) fp16 the
     weight's integers, `spec` the frozen 8-bit output quantiser.  rows % 16 == 0, K % 32 == 0, N % 64 == 0."""
-    dev = _need_gpu(a, w_int, bias)
+    dev = _need_gpu(a, w_int, bias, acc_add)
     N, K = w_int.shape
     rows = a.shape[0]
-    if a.dtype != torch.float16 or w_int.dtype != torch.float16 or bias.dtype != torch.float32 or a.dim() != 2 or a.shape[1] != (2 if pairs else 1) * K:
+    i8 = a.dtype == torch.int8  # int8 activations (e.g. centred indices) against int8 weights on the integer matrix cores; acc_add: int32 (N)
+    if i8:
+        if w_int.dtype != torch.int8 or pairs or a.dim() != 2 or a.shape[1] != K or bias.dtype != torch.float32:
+            raise ValueError("int8 form: a (rows, K) int8, w_int (N, K) int8, bias (N) fp32")
+        if acc_add is not None and (acc_add.dtype != torch.int32 or acc_add.numel() != N or not acc_add.is_contiguous()):
+            raise ValueError("acc_add must be a contiguous int32 vector of N")
+    elif a.dtype != torch.float16 or w_int.dtype != torch.float16 or bias.dtype != torch.float32 or a.dim() != 2 or a.shape[1] != (2 if pairs else 1) * K:
         raise ValueError("a (rows, K or 2K) fp16, w_int (N, K) fp16, bias (N) fp32")
     if a.stride(1) != 1 or w_int.stride(1) != 1 or not bias.is_contiguous() or bias.numel() != N or spec.qmax != 255.0:
         raise ValueError("contiguous rows, a bias of N and an 8-bit grid")
@@ -433,9 +440,9 @@ def proj_quant_values(a: torch.Tensor, w_int: torch.Tensor, bias: torch.Tensor, 
     y = torch.empty((rows, N), dtype=torch.float32, device=a.device)
     seg = (_lib.oeh_proj_seg * 1)()
     seg[0].alpha, seg[0].scale, seg[0].zero_point = float(alpha), float(spec.scale), float(spec.zero_point)
-    seg[0].out, seg[0].y, seg[0].y_stride_row, seg[0].transpose = None, _ptr(y), N, 0
+    seg[0].out, seg[0].y, seg[0].y_stride_row, seg[0].transpose, seg[0].acc_add = None, _ptr(y), N, 0, (_ptr(acc_add) if i8 else None)
     with _on_device(dev):
-        rc = _lib.load().oeh_proj_quant_i8(_ptr(a), int(bool(pairs)), _ptr(w_int), _ptr(bias), rows // 16, 16, K, N, 1, seg, a.stride(0), w_int.stride(0), _stream())
+        rc = _lib.load().oeh_proj_quant_i8(_ptr(a), 3 if i8 else int(bool(pairs)), _ptr(w_int), _ptr(bias), rows // 16, 16, K, N, 1, seg, a.stride(0), w_int.stride(0), _stream())
     _lib.check(rc, "oeh_proj_quant_i8")
     return y
 
@@ -464,7 +471,7 @@ def attn_fwd_i8(q: torch.Tensor, k: torch.Tensor, v_t: torch.Tensor, grids, *, f
     elif out.shape != (B, H, Sq, D) or out.dtype != out_dtype or out.stride(3) != 1:
         raise ValueError("out must be a (B,H,Sq,D) view with unit head-dim stride and dtype out_dtype")
     d = oeh_attn_desc()
-    d.B, d.H, d.Sq, d.Sk, d.D, d.dtype, d.o_dtype = B, H, Sq, Sk, D, _lib.OEH_I8, _DT[out_dtype]
+    d.B, d.H, d.Sq, d.Sk, d.D, d.dtype, d.o_dtype = B, H, Sq, Sk, D, _lib.OEH_I8, (_lib.OEH_I8 if out_dtype == torch.int8 else _DT[out_dtype])
     for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v_t), ("o_stride", out)):
         getattr(d, name)[:] = [t.stride(0), t.stride(1), t.stride(2)]
     for name, gr in zip(("q_grid", "k_grid", "v_grid"), grids):

@@ -599,7 +599,28 @@ class QuantLinear(QuantizedModule, nn.Linear):
         """`linear_index` applies: what `pair_gemm_ok` asks of the weights, for an fp32 model on the GPU."""
         return self.pair_gemm_ok(like) and self.bias is not None and self.activation_function is None
 
-    def linear_index(self, rel, xscale: float, out_dtype=torch.float32):
+    def int8_index_ok(self, rows: int) -> bool:
+        """`linear_index` on int8 centred indices applies: frozen 8-bit asymmetric output quantiser, K % 64 == 0, whole 16-row groups."""
+        aq = self.activation_quantizer
+        return (FUSED_PROJ and self._qa and self.out_features % 64 == 0 and aq.is_fixed and type(aq.quantizer) is AsymmetricUniformQuantizer
+                and aq.quantizer.n_bits == 8 and self.in_features % 64 == 0 and rows % 16 == 0 and self.bias is not None)
+
+    def _int8_weights(self, xzero: float):
+        """The weight's integers as int8 (N, K), (128 - xzero) * their row sums as int32 (N) and the fp32 weight scale, cached."""
+        qz = self.weight_quantizer.quantizer
+        key = (self.weight.data_ptr(), self.weight._version, qz._delta.data_ptr(), qz._delta._version, float(xzero))
+        hit = self.__dict__.get("_int8_cache")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                iw = qz.to_integer_forward(self.weight.detach())
+                iw8 = iw.to(torch.int8).contiguous()
+                add = (int(128 - int(xzero)) * iw.to(torch.int64).sum(dim=1)).to(torch.int32).contiguous()
+                s32 = float(np.float32(float(qz.scale)))
+            hit = (key, iw8, add, s32)
+            self.__dict__["_int8_cache"] = hit
+        return hit[1], hit[2], hit[3]
+
+    def linear_index(self, rel, xscale: float, out_dtype=torch.float32, xzero: float = 0.0):
         """This projection of x = xscale * rel, `rel` the INTEGERS idx - zp of the producer's 8-bit quantiser as a 16-bit float
         tensor (`ops.attn_fwd_i8(..., fq.ctx_emit_index)`): x W_q^T = (xscale * w_scale) * (rel . Iw), ONE fp16 GEMM of integers
         with exact products and fp32 accumulation - half the operand-pair GEMM and no split pass - then scale, bias and the
@@ -610,6 +631,13 @@ class QuantLinear(QuantizedModule, nn.Linear):
         aq = self.activation_quantizer
         fixed8 = (self._qa and self.out_features % 64 == 0 and aq.is_fixed and type(aq.quantizer) is AsymmetricUniformQuantizer and aq.quantizer.n_bits == 8)
         rel2 = rel.reshape(-1, K)
+        if rel2.dtype == torch.int8:
+            # the producer's CENTRED indices idx - 128 (`ops.attn_fwd_i8(..., out_dtype=torch.int8)`): both sides int8 on the integer matrix
+            # cores, exact int32 sums; the per-column integer (128 - zp) * sum_k Iw turns them into the sums over idx - zp
+            iw8, add, s32 = self._int8_weights(xzero)
+            self.__dict__["_int8_index_calls"] = self.__dict__.get("_int8_index_calls", 0) + 1  # (tests: which form ran)
+            y = ops.proj_quant_values(rel2, iw8, self.bias.detach(), float(np.float32(xscale) * np.float32(s32)), aq.quantizer.spec(), pairs=False, acc_add=add)
+            return y.view(shape).to(out_dtype)
         if (FUSED_PROJ and fixed8 and K % 32 == 0 and rel2.shape[0] % 16 == 0 and rel2.dtype == torch.float16 and rel2.stride(1) == 1
                 and self.bias is not None):
             # ONE kernel: the GEMM of integers, scale, bias and the output quantiser in its epilogue (`oeh_proj_quant_i8`, values only)
@@ -884,8 +912,11 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
         as_index = (INDEX_GEMM and consumer is not None and fq.ctx is not None and fq.ctx.qmax == 255.0 and (gate is None or not fq.ctx_before_gate)
                     and isinstance(consumer, QuantLinear) and consumer.in_features == E and consumer.index_gemm_ok(hidden_states))
         fq_call = dataclasses.replace(fq, ctx_emit_index=True) if as_index else fq
+        # ... as int8 centred indices when the consumer takes them on the integer matrix cores (K % 64 == 0, a whole zero point), else as
+        # the integers idx - zp in fp16
+        as_int8 = as_index and consumer.int8_index_ok(bsz * tgt_len) and float(fq.ctx.zero_point) == float(int(fq.ctx.zero_point))
         try:
-            out = ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq_call, out_dtype=torch.float16 if as_index else hidden_states.dtype, softmax=spec, scale=scale,
+            out = ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq_call, out_dtype=(torch.int8 if as_int8 else torch.float16) if as_index else hidden_states.dtype, softmax=spec, scale=scale,
                                   scale_div=scale_div, causal=causal, clamp_min=causal or padvec is not None, mask_min=mask_min, gate=gate,
                                   key_pad_mask=padvec)
         except _OehError as e:
@@ -896,7 +927,7 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
         merged = out.permute(0, 2, 1, 3).reshape(bsz, tgt_len, E)
         if as_index:
             self.__dict__["_index_gemm_calls"] = self.__dict__.get("_index_gemm_calls", 0) + 1
-            return consumer.linear_index(merged, fq.ctx.scale, out_dtype=hidden_states.dtype), (yk, yv), True
+            return consumer.linear_index(merged, fq.ctx.scale, out_dtype=hidden_states.dtype, xzero=fq.ctx.zero_point), (yk, yv), True
         return merged, (yk, yv), False
 
 

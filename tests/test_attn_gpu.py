@@ -1480,6 +1480,18 @@ def test_context_quantiser_emits_its_integers(ops):
     val = ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, out_dtype=torch.float32, **kw)
     rel = ops.attn_fwd_i8(qc, kc, vt, grids, fq=fqi, out_dtype=torch.float16, **kw)
     assert torch.equal(rel, rel.round()) and torch.equal(rel.float() * np.float32(0.021), val)
+    # (round 4) ... and as int8 CENTRED indices idx - 128 (o_dtype OEH_I8: what an int8 consumer GEMM takes, oeh_proj_quant_i8 pairs == 3),
+    # with and without a key-padding vector, on row lengths of all three kernel variants; refused without ctx_emit_index
+    for S_ in (128, 48, 512):
+        qs, ks = [torch.randint(-128, 128, (B, S_, H * D), device=dev, dtype=torch.int8).view(B, S_, H, D).permute(0, 2, 1, 3) for _ in range(2)]
+        vs = torch.randint(-128, 128, (B, H, D, S_), device=dev, dtype=torch.int8)
+        for pad in (None, torch.tensor([[0.0] * (S_ - 7) + [float(np.finfo(np.float32).min)] * 7] * B, device=dev)):
+            kw_ = dict(kw, key_pad_mask=pad)
+            r16 = ops.attn_fwd_i8(qs, ks, vs, grids, fq=fqi, out_dtype=torch.float16, **kw_)
+            c8 = ops.attn_fwd_i8(qs, ks, vs, grids, fq=fqi, out_dtype=torch.int8, **kw_)
+            assert c8.dtype == torch.int8 and c8.shape == r16.shape and torch.equal(c8.float() + (128.0 - 121.0), r16.float())
+    with pytest.raises(_lib.OehError):
+        ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, out_dtype=torch.int8, **kw)
     gate = torch.rand(B, H, S, 1, device=dev)
     with pytest.raises(_lib.OehError):
         ops.attn_fwd(q, k, v, fq=fqi, gate=gate, **kw)

@@ -533,6 +533,16 @@ def test_quantised_opt_uses_the_int8_storage_core(oa, monkeypatch):
         # ... and out_proj ran on the context quantiser's integers (one 16-bit GEMM of integers, QuantLinear.linear_index); with
         # the float hand-over instead (split pass + operand-pair GEMM) the outputs agree up to rare single steps of the output grid
         assert qm.__dict__.get("_index_gemm_calls", 0) == 2
+        # (round 4) ... as int8 centred indices against the int8 weights on the integer matrix cores (E % 64 == 0): exact int32 sums, so
+        # the same outputs bit for bit as with the integers idx - zp carried in fp16
+        assert qm.out_proj.__dict__.get("_int8_index_calls", 0) == 2
+        monkeypatch.setattr(Q.QuantLinear, "int8_index_ok", lambda self, rows: False)
+        out8h, _, _ = qm(x, attention_mask=mask)
+        monkeypatch.undo()
+        monkeypatch.setattr(ops, "attn_fwd_i8", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        assert qm.out_proj.__dict__["_int8_index_calls"] == 2 and torch.equal(out8h, out8)
+        calls.pop()
+        qm.__dict__["_index_gemm_calls"] -= 1
         monkeypatch.setattr(Q, "INDEX_GEMM", False)
         out8v, _, _ = qm(x, attention_mask=mask)
         monkeypatch.setattr(Q, "INDEX_GEMM", True)

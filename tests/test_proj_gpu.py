@@ -154,3 +154,25 @@ def test_fp32_activations_split_inside_the_kernel_equal_the_operand_pairs(B, S, 
     a = flat(ops.proj_quant_i8(ops.split_pairs(x), wi, bias, B, S, segs, pairs=True))
     b = flat(ops.proj_quant_i8(x, wi, bias, B, S, segs, pairs=True))
     assert len(a) == len(b) == 5 and all(torch.equal(p_, q_) for p_, q_ in zip(a, b))
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (400, 128, 64), (4096, 768, 768), (48, 64, 128)])
+def test_int8_activations_on_the_integer_matrix_cores_equal_the_fp16_integer_form(M, N, K):
+    """out_proj on the context quantiser's indices: int8 centred indices c = idx - 128 against the int8 weights (v_mfma_i32_16x16x64_i8,
+    exact int32 sums) with acc_add = (128 - zp) * column sums, against the same projection on the integers idx - zp carried as fp16
+    (exact products, fp32 sums exact below 2^24): the same fake-quantised values bit for bit."""
+    from outeffhop_amd import ops
+
+    torch.manual_seed(M + N)
+    zp = 117
+    idx = torch.randint(90, 150, (M, K), device="cuda")           # (sums of (idx - zp) * w stay below 2^24 for K = 768)
+    wi = torch.randint(-128, 128, (N, K), device="cuda")
+    bias = torch.randn(N, device="cuda") * 0.1
+    spec = ops.FakeQuantSpec(0.02, 131.0)
+    alpha = 3.1e-5
+    y16 = ops.proj_quant_values((idx - zp).to(torch.float16), wi.to(torch.float16), bias, alpha, spec, pairs=False)
+    add = ((128 - zp) * wi.sum(dim=1)).to(torch.int32).contiguous()
+    y8 = ops.proj_quant_values((idx - 128).to(torch.int8), wi.to(torch.int8), bias, alpha, spec, pairs=False, acc_add=add)
+    exact = (idx - zp).double() @ wi.double().t()
+    assert float(exact.abs().max()) < 2 ** 24
+    assert torch.equal(y8, y16)

@@ -63,6 +63,10 @@ def main():
                 acc = torch.mm(rel, wot, out_dtype=torch.float32)
                 return ops.quantize_heads_i8(acc.view(1, -1, E), sp, H, want_values=True, alpha=1e-4, bias=bias[:E].contiguous(), want_indices=False)
             line += f" (library GEMM + pass {gtime(oldo):.1f})"
+        rel8, wo8 = rel.to(torch.int8), wo.to(torch.int8)
+        add = torch.zeros(E, dtype=torch.int32, device="cuda")
+        t = gtime(lambda: ops.proj_quant_values(rel8, wo8, bias[:E].contiguous(), 1e-4, sp, pairs=False, acc_add=add))
+        line += f" | out_proj int8 {t:.1f} us"
         t = gtime(lambda: ops.split_pairs(x.view(M, K)))
         line += f" | split_pairs {t:.1f} us"
         x2 = x.view(M, K)

@@ -6,7 +6,7 @@ torch.mm) + one `oeh_quantize_heads_i8` pass per projection, in ONE process; one
 A step = the projection launches of `layers` layers on distinct buffers (inputs resident in HBM), timed with HIP events on the launch
 stream around a captured HIP graph of the step (so that host time stays out: these launches are 20-75 us).  roofline: bound mfma;
 `achieved` = algorithmic flops (2 M N K: ONE fp32-grade product per term - the operand-pair form executes two fp16 MFMA products per
-term, reported as mfma_flops_executed) / the kernel's mean duration; peak = 2500 TFLOP/s (fp16 dense, MI355X_MICROARCH.md)."""
+term, reported as mfma_flops_executed) / the kernel's mean duration; peak = 2500 TFLOP/s (fp16 dense, MI355X_MICROARCH.md; 5000 for the int8 x int8 out_proj)."""
 import argparse
 import json
 import os
@@ -24,7 +24,7 @@ WORKLOADS = {
     "opt_qkv_novalues": dict(B=16, S=512, H=12, K=768, kind="qkv", values=False,
                              desc="OPT-125m layer B=16 S=512 E=768 fp32: q/k/v QuantLinear projections from the fp32 activations (operand pairs formed inside) -> int8 indices (v transposed)"),
     "opt_out_proj": dict(B=16, S=512, H=12, K=768, kind="out", values=True,
-                         desc="OPT-125m layer B=16 S=512 E=768: out_proj QuantLinear on the context quantiser's integers -> fake-quantised fp32 values"),
+                         desc="OPT-125m layer B=16 S=512 E=768: out_proj QuantLinear on the context quantiser's int8 centred indices (v_mfma_i32_16x16x64_i8) -> fake-quantised fp32 values"),
     "bert_qkv": dict(B=32, S=128, H=12, K=768, kind="qkv", values=False,
                      desc="BERT-base layer B=32 S=128 E=768 fp32: query/key/value QuantLinear projections from the fp32 activations (operand pairs formed inside) -> int8 indices (v transposed)"),
 }
@@ -86,11 +86,14 @@ def main():
                 old.append(lib)
                 N, mult = 3 * E, 2
             else:
-                rel = torch.randint(-128, 128, (M, E), device="cuda").to(torch.float16)
-                wo = torch.randint(-128, 128, (E, K), device="cuda").to(torch.float16)
+                c8 = torch.randint(-128, 128, (M, E), device="cuda", dtype=torch.int8)       # centred indices idx - 128 (zero point 121)
+                rel = (c8.to(torch.float16) + 7.0)                                             # idx - zp, what the library path multiplies
+                wo8 = torch.randint(-128, 128, (E, K), device="cuda", dtype=torch.int8)
+                wo = wo8.to(torch.float16)
                 wot = wo.t().contiguous()
                 b1 = bias[:E].contiguous()
-                new.append(lambda rel=rel, wo=wo, b1=b1: ops.proj_quant_values(rel, wo, b1, 1e-4, sp[2], pairs=False))
+                add = (7 * wo8.to(torch.int64).sum(dim=1)).to(torch.int32).contiguous()
+                new.append(lambda c8=c8, wo8=wo8, b1=b1, add=add: ops.proj_quant_values(c8, wo8, b1, 1e-4, sp[2], pairs=False, acc_add=add))
 
                 def lib(rel=rel, wot=wot, b1=b1):
                     acc = torch.mm(rel, wot, out_dtype=torch.float32)
@@ -103,11 +106,11 @@ def main():
         kern_us = t_new / L
         line = {
             "metric": "projection_tokens_per_s", "value": B * S * L / (t_new * 1e-6), "unit": "tokens/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": t_new * 1e-3, "higher_is_better": True, "dtype": "f16 operand pairs, f32 accumulate" if mult == 2 else "f16 integers, f32 accumulate",
+            "ms_per_step": t_new * 1e-3, "higher_is_better": True, "dtype": "f16 operand pairs, f32 accumulate" if mult == 2 else "int8 x int8, int32 accumulate",
             "data": "synthetic", "config": {"workload": w["desc"], "layers_per_step": L, "M": M, "N": N, "K": K},
             "kernel_us": kern_us,
-            "roofline": {"bound": "mfma", "achieved": flops / kern_us * 1e-6, "peak": 2500.0, "unit": "TFLOP/s", "frac": flops / kern_us * 1e-6 / 2500.0,
-                         "mfma_flops_executed": mult * flops, "executed_frac": mult * flops / kern_us * 1e-6 / 2500.0, "traffic": None},
+            "roofline": {"bound": "mfma", "achieved": flops / kern_us * 1e-6, "peak": 2500.0 if mult == 2 else 5000.0, "unit": "TFLOP/s", "frac": flops / kern_us * 1e-6 / (2500.0 if mult == 2 else 5000.0),
+                         "mfma_flops_executed": mult * flops, "executed_frac": mult * flops / kern_us * 1e-6 / (2500.0 if mult == 2 else 5000.0), "traffic": None},
             "replaces": None if t_old is None else {"what": ("oeh_split_pairs + " if w["kind"] == "qkv" else "") + "library GEMM (torch.mm, hipBLASLt) + one oeh_quantize_heads_i8 pass per projection, same process",
                                                     "us_per_layer": t_old / L, "speedup": t_old / t_new},
         }
