@@ -60,7 +60,11 @@ for line in out.splitlines():
     elif fam == "oeh_attn_mfma_kernel":      # <NT, D, IN, FQ>
         key = (fam, "FQ=%d" % (a[3] if len(a) > 3 else 0), "general kernel: (B,1,Sq,Sk) masks, true score division, gamma > 0, any subset of the quantisers, the test-only index dumps; Sk <= 512")
     elif fam == "oeh_attn_i8_kernel":        # <NT, OUT, DUMP, CQ2, PAD>
-        key = (fam, "DUMP=%d CQ2=%d PAD=%d" % tuple(a[2:5]), "INT8 storage on v_mfma_i32_16x16x64_i8; DUMP: index dumps for the reference-capture tests; CQ2: q grid with zero point 0; PAD: key padding")
+        key = (fam, "DUMP=%d CQ2=%d PAD=%d" % tuple(a[2:5]), "INT8 storage on v_mfma_i32_16x16x64_i8 (NT in {8, 16, 32} x output f16 / bf16 / f32 / int8 indices); DUMP: index dumps for the reference-capture tests; CQ2: q grid with zero point 0; PAD: key padding")
+    elif fam == "oeh_gemm_kernel":           # <AM, MI, NJ>
+        form = {0: "fp16 activations", 1: "fp16 operand pairs of fp32 activations", 2: "fp32 activations, split at fragment-read time",
+                3: "int8 x int8 on v_mfma_i32_16x16x64_i8 (out_proj on the context quantiser's indices)"}.get(a[0], "?")
+        key = (fam, "AM=%d" % a[0], "projection GEMM with the quantisers in its epilogue (oeh_proj_quant_i8): " + form + "; tiles 128 x 288 and 64 x 192")
     elif fam == "oeh_attn_small_kernel":
         key = (fam, "", "STanHop Association: one wave per (batch, head), exact fp32 products; d in {16, 32, 64} x dtype x rows <= 32 / 64")
     groups[key] = groups.get(key, 0) + 1
