@@ -136,6 +136,37 @@ def quantised():
             print("capture of the quantised module failed:", type(e).__name__, str(e)[:200])
         t_lin = timeit(lambda: qm.q_proj(x), n=50)
         print(f"   parts: one QuantLinear (fp32 GEMM + output fake-quant) {t_lin:.1f} us")
+        # BERT-base layer (quantized_bert.py:221-440): B = 32, S = 128, key-padding mask, query / key / value QuantLinear + the integer core
+        from types import SimpleNamespace
+        bcfg = SimpleNamespace(hidden_size=768, num_attention_heads=12, attention_probs_dropout_prob=0.0, max_position_embeddings=512,
+                               is_decoder=False, position_embedding_type="absolute")
+        Bb, Sb = 32, 128
+        borg = BertSelfAttentionWithExtras(bcfg, softmax_fn=SOFTMAX_MAPPING["softmax1"]).to(dev).eval()
+        bq = oa.QuantizedBertSelfAttentionWithExtras(borg, **{**oa.val_qparams(cfg), "quant_dict": {}}).to(dev).eval()
+        bq.set_quant_state(weight_quant=True, act_quant=True)
+        lens = torch.randint(Sb // 2, Sb + 1, (Bb,))
+        bmask = torch.zeros(Bb, 1, 1, Sb, device=dev)
+        for b_, n_ in enumerate(lens.tolist()):
+            bmask[b_, :, :, n_:] = fmin
+        for _ in range(2):
+            bq(torch.randn(Bb, Sb, E, device=dev), attention_mask=bmask)
+        bq.fix_ranges()
+        xb = torch.randn(Bb, Sb, E, device=dev)
+        for i8 in (False, True):
+            Q.INT8_STORAGE = i8
+            t_mod = timeit(lambda: bq(xb, attention_mask=bmask), n=50)
+            print(f"QuantizedBert module fp32, INT8 storage core={i8}: {t_mod:8.1f} us  {Bb * Sb / t_mod:8.1f} M tokens/s")
+        try:
+            bq(xb, attention_mask=bmask)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                out_b = bq(xb, attention_mask=bmask)
+            t_g = timeit(gr.replay, n=50)
+            print(f"QuantizedBert module fp32, INT8 storage core, captured HIP graph: {t_g:8.1f} us  {Bb * Sb / t_g:8.1f} M tokens/s  "
+                  f"(replay equals eager: {torch.equal(out_b[0], bq(xb, attention_mask=bmask)[0])})")
+        except Exception as e:  # noqa: BLE001
+            print("capture of the quantised BERT module failed:", type(e).__name__, str(e)[:200])
 
 
 if __name__ == "__main__":
