@@ -878,8 +878,10 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
             # (the fp32 activations go in as they are: the (hi, lo) operand split happens when a wave reads its fragments - the same
             # values as `ops.split_pairs` would write, without the pass)
             x2 = hidden_states.reshape(-1, K_in)
-            if x2.stride(1) != 1 or (x2.stride(0) * 4) % 16 != 0 or x2.data_ptr() % 16 != 0:
+            if x2.stride(1) != 1 or (x2.stride(0) * 4) % 16 != 0:
                 x2 = x2.contiguous()
+            if x2.data_ptr() % 16 != 0:   # (a view at an odd storage offset: the kernel's 16-byte row loads need an aligned copy)
+                x2 = x2.clone(memory_format=torch.contiguous_format)
             w3, b3, scales3 = self._qkv_int_weights(lins)
             specs = [z.spec() for z in qzs]
             outs = ops.proj_quant_i8(x2, w3, b3, bsz, tgt_len, [(scales3[n_], specs[n_], n_ == 2, n_ > 0 and want_values) for n_ in range(3)], pairs=True)
