@@ -607,6 +607,13 @@ def test_quantised_modules_fuse_the_projections_into_one_gemm_with_quantiser_epi
         monkeypatch.setattr(ops, "proj_quant_i8", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
         out1, _, past1 = qm(x, attention_mask=mask)
         assert len(calls) == 1 and qm.__dict__.get("_fused_proj_calls", 0) == 1 and qm.__dict__.get("_i8_calls", 0) >= 1
+        # activations at an odd storage offset (a view 12 bytes into its buffer): the path takes an aligned copy, same outputs
+        big = torch.empty(x.numel() + 3, device=dev)
+        xo = big[3:].view_as(x).copy_(x)
+        assert xo.data_ptr() % 16 != 0
+        outo, _, _ = qm(xo, attention_mask=mask)
+        assert len(calls) == 2 and torch.equal(outo, out1)
+        calls.pop()
         monkeypatch.setattr(Q, "FUSED_PROJ", False)
         out0, _, past0 = qm(x, attention_mask=mask)
         assert len(calls) == 1
