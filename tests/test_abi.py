@@ -131,3 +131,32 @@ def test_debug_hooks_are_inert_unless_enabled():
     hdr = open(os.path.join(ROOT, "include", "oeh_debug.h")).read()
     assert "oeh_debug_set_variant" in hdr and "oeh_debug_set_stamps" in hdr
     assert "oeh_debug" not in open(os.path.join(ROOT, "include", "oeh.h")).read()
+
+
+def test_ctypes_structures_have_the_headers_layout(tmp_path):
+    """The ctypes mirrors in outeffhop_amd/_lib.py against include/oeh.h as a C compiler lays it out: size of every structure and
+    offset of every field (a field added on one side only, or a type that pads differently, would shift everything behind it)."""
+    import shutil
+
+    from outeffhop_amd import _lib
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    # (the (scale, zero_point) pairs q_grid / k_grid / v_grid are an anonymous struct in the header: covered through oeh_attn_desc's offsets)
+    structs = {"oeh_fq": _lib.oeh_fq, "oeh_fq_desc": _lib.oeh_fq_desc, "oeh_attn_desc": _lib.oeh_attn_desc, "oeh_proj_seg": _lib.oeh_proj_seg}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{HDR}"', "int main(void) {"]
+    for name, st in structs.items():
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for fname, _ in st._fields_:
+            lines.append(f'  printf("{name}.{fname} %zu\\n", offsetof({name}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-std=c99", "-o", str(exe), str(src)], check=True, capture_output=True)
+    out = dict(ln.split() for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, st in structs.items():
+        assert int(out[name]) == C.sizeof(st), (name, out[name], C.sizeof(st))
+        for fname, _ in st._fields_:
+            assert int(out[f"{name}.{fname}"]) == getattr(st, fname).offset, (name, fname, out[f"{name}.{fname}"], getattr(st, fname).offset)
