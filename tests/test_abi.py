@@ -160,3 +160,33 @@ def test_ctypes_structures_have_the_headers_layout(tmp_path):
         assert int(out[name]) == C.sizeof(st), (name, out[name], C.sizeof(st))
         for fname, _ in st._fields_:
             assert int(out[f"{name}.{fname}"]) == getattr(st, fname).offset, (name, fname, out[f"{name}.{fname}"], getattr(st, fname).offset)
+
+
+def test_a_plain_c_host_links_the_library(tmp_path):
+    """include/oeh.h is C99 and the exports have C linkage: a C program compiled with gcc against the header links liboeh_hip.so and
+    calls the host-only entry points (and gets EINVAL, not a crash, from the device entry points on NULL arguments)."""
+    import shutil
+
+    from outeffhop_amd import _lib
+
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("no C compiler or library not built")
+    src = tmp_path / "host.c"
+    src.write_text(f'''#include <stdio.h>
+#include <string.h>
+#include "{HDR}"
+int main(void) {{
+  oeh_attn_desc d;
+  memset(&d, 0, sizeof d);
+  printf("%d %s %d %d\\n", oeh_abi_version(), oeh_strerror(-95), oeh_attn_fwd(NULL, NULL, NULL, NULL, NULL, NULL, NULL),
+         oeh_proj_quant_i8(NULL, 0, NULL, NULL, 1, 16, 32, 64, 1, NULL, 32, 32, NULL));
+  return 0;
+}}
+''')
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run([gcc, "-std=c99", "-o", str(exe), str(src), "-L" + libdir, "-loeh_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+                    "-Wl,--allow-shlib-undefined"], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out[0] == "6" and out[-2:] == ["-22", "-22"], out
