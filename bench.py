@@ -83,39 +83,46 @@ def parse():
     ap.add_argument("--layers", type=int, default=None, help="launches (distinct buffer sets) per step; default 12 = OPT-125m's / BERT-base's "
                     "attention layers (stanhop: 48, so that a step's buffers exceed the 256 MB Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="(unused since round 5: the CPU leg is 3 warm-up + 10 timed full-batch passes)")
     ap.add_argument("--no-check", action="store_true", help="N > 1: skip the shard-parity check (all_gather of the ranks' layer-0 outputs "
                     "over RCCL, each compared bit for bit with rank 0's own run of that shard)")
     return ap.parse_args()
 
 
-def cpu_baseline(w, seconds):
-    """Reference op chain (eager torch, fp32, all host threads) on a bounded sample of the same workload."""
+def cpu_baseline(w, layer0, pad, gate_w):
+    """Reference op chain (eager torch, fp32, host threads) on the FULL batch of one layer - the very tensors the GPU leg's layer 0 holds
+    (`gen_layers(0, 1)`: same generator, same seed), BASELINE.md section 4: 3 warm-up + 10 timed passes; the thread count is the best of
+    8 ... all logical CPUs (eager torch on a many-core host is fastest well below the core count), stated in `sample`."""
     import torch
 
     from oracle import eager_torch as E
 
     cores = os.cpu_count() or 1
-    Bs = max(1, w["B"] // 4)
-    H, S, d = w["H"], w["S"], w["d"]
-    g = torch.Generator().manual_seed(1235)
-    q = torch.randn(Bs, H, S, d, generator=g).half().float()
-    k = torch.randn(Bs, H, S, d, generator=g).half().float()
-    v = torch.randn(Bs, H, S, d, generator=g).half().float()
+    B, H, S, d = w["B"], w["H"], w["S"], w["d"]
+    heads = lambda t: t.float().view(B, S, H, d).permute(0, 2, 1, 3).contiguous()  # noqa: E731  (B,H,S,d) fp32 of the fp16 values
+    q, k, v = (heads(t) for t in layer0[:3])
     base, clip, gamma, eta = w["sm"]
     if w["order"] == "opt":
-        q = (q * d ** -0.5).half().float()
-        mask = E.causal_mask(Bs, S)
+        mask = E.causal_mask(B, S)          # (q arrives scaled by head_dim^-0.5, as in the GPU leg)
     elif w["order"] == "none":
         q = q * d ** -0.5  # Association scales the scores by 1/sqrt(E): the same multiply count, done on q here
         mask = None
     else:
-        mask = torch.zeros(Bs, 1, 1, S)
+        mask = pad.float().view(B, 1, 1, S) if pad is not None else torch.zeros(B, 1, 1, S)
     fq = dict(scores=(0.08, 128.0, 255.0), probs=(1 / 255.0, 0.0, 255.0), ctx=(0.02, 128.0, 255.0)) if w["int8"] else None
-    gate = torch.rand(Bs, H, S, 1, generator=g) if w["gate"] else None
-    run = lambda: E.attn_core_eager(q, k, v, order=("opt" if w["order"] == "none" else w["order"]), base=base, clip=clip, gamma=gamma, eta=eta, mask=mask, fq=fq, gate=gate)  # noqa: E731
+    gate = None
+    if w["gate"]:  # the per-token gate from the per-head MLPs 64 -> 16 -> 1 on the layer input (bert_attention.py:301-327): inside the timed pass
+        gw1, gb1, gw2, gb2 = (t.float().cpu() for t in gate_w)
+        hid = heads(layer0[3])
+    def run():
+        g_ = None
+        if w["gate"]:
+            h1 = torch.relu(torch.einsum("bhsd,hud->bhsu", hid, gw1) + gb1[None, :, None, :])
+            g_ = torch.sigmoid((h1 * gw2[None, :, None, :]).sum(-1, keepdim=True) + gb2[None, :, None, None])
+        return E.attn_core_eager(q, k, v, order=("opt" if w["order"] == "none" else w["order"]), base=base, clip=clip, gamma=gamma, eta=eta,
+                                 mask=mask, fq=fq, gate=g_)
+    WARM, TIMED = 3, 10
     with torch.no_grad():
-        # eager torch on many-core hosts is fastest well below the core count: pick the best thread count first
         best_t, best_dt = cores, float("inf")
         for t in sorted({c for c in (8, 16, 32, 64, 128, cores) if c <= cores}):
             torch.set_num_threads(t)
@@ -126,19 +133,16 @@ def cpu_baseline(w, seconds):
             if dt1 < best_dt:
                 best_t, best_dt = t, dt1
         torch.set_num_threads(best_t)
-        run()
-        t0 = time.perf_counter()
-        n = 0
-        while True:
+        for _ in range(WARM):
             run()
-            n += 1
-            dt = time.perf_counter() - t0
-            if dt >= seconds or n >= 400:
-                break
-    cores_used = best_t
-    return dict(value=Bs * S * n / dt, unit="attention-layer tokens/s", cores=cores_used, kind="port",
-                sample=f"oracle/eager_torch.py (reference eager op chain, fp32, best of 8..{cores} torch threads = {cores_used}; host: "
-                       f"{_cpu_model()}, {cores} logical CPUs), B={Bs} of {w['B']} H={H} S={S} d={d}, {n} layer passes in {dt:.1f} s")
+        t0 = time.perf_counter()
+        for _ in range(TIMED):
+            run()
+        dt = time.perf_counter() - t0
+    return dict(value=B * S * TIMED / dt, unit="attention-layer tokens/s", cores=best_t, kind="port",
+                sample=f"oracle/eager_torch.py (reference eager op chain, fp32, best of 8..{cores} torch threads = {best_t}; host: "
+                       f"{_cpu_model()}, {cores} logical CPUs), B={B} of {B} H={H} S={S} d={d}: the GPU leg's own layer-0 tensors (seed 1235), "
+                       f"{WARM} warm-up + {TIMED} timed layer passes in {dt:.2f} s ({dt / TIMED * 1e3:.1f} ms per pass)")
 
 
 def int8_check(storage="f16"):
@@ -653,7 +657,7 @@ def main():
             },
         }
         if world == 1 and not a.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(w, a.cpu_seconds)
+            rec["cpu_baseline"] = cpu_baseline(w, gen_layers(0, 1)[0], gen_pad(0), (gw1, gb1, gw2, gb2) if w["gate"] else None)
             rec["config"]["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
             rec["cpu_baseline"]["int8_vs_reference"] = int8_check("f16")
             rec["cpu_baseline"]["int8_vs_reference_fp32_storage"] = int8_check("f32")

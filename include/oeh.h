@@ -160,9 +160,11 @@ typedef struct oeh_attn_desc {
   int32_t o_dtype;               /* dtype == OEH_I8: the output's dtype.  dtype OEH_F16 / OEH_BF16 (ABI 5): OEH_F32 here asks for the
                                     output straight from the kernel's fp32 accumulators (o is then fp32, strides in fp32 elements) - the
                                     arithmetic of the kernel that ships before its output rounding, for the "within 1e-3" checks: sibling
-                                    instantiations of the one-pass kernel's plain form (masks none / causal) and of the full-row
-                                    kernel's plain / clipped forms (+ key padding) at head dim 64 that differ in the epilogue's store
-                                    only; OEH_ENOTSUP elsewhere.  Any other value: o has `dtype`. */
+                                    instantiations that differ in the epilogue's store only.  Head dim 64: the one-pass kernel's plain
+                                    form (masks none / causal / key padding / a (B,1,Sq,Sk) mask; or with the in-kernel gate predictor,
+                                    unmasked / causal) and the full-row kernel's plain / clipped forms (+ key padding; the plain form also
+                                    with the in-kernel gate predictor).  Head dim 128 (round 5): the plain forms of both (the one-pass
+                                    kernel with one block per wave, unmasked / causal).  OEH_ENOTSUP elsewhere.  Any other value: o has `dtype`. */
 
   /* (appended in ABI 4: fields are only ever added at the end of a descriptor) */
   int32_t key_pad_boolean;       /* key_pad_mask: the caller's promise that every entry is 0 or <= -1e4 (HF's extended masks: 0 / finfo.min):
@@ -308,7 +310,8 @@ int oeh_split_triples(const float* x, void* out_f16, int64_t rows, int32_t K, in
  *           contiguous] - the layouts oeh_attn_fwd takes with dtype OEH_I8; 16-byte aligned;
  *      y    (optional): the dequantised values scale * (c + 128 - zero_point) as fp32, (B*S, E) with row stride y_stride_row
  *           elements - a decoder's (k, v) cache.
- * K % 32 == 0, E % 64 == 0, S % 16 == 0, n_seg in 1..3: OEH_ENOTSUP otherwise.  Same formulas as oeh_quantize_heads_i8; the
+ * K % 32 == 0, E % 64 == 0, S % 16 == 0 (and every 32-bit lane offset of a, w and y below 4 GiB): OEH_ENOTSUP otherwise; n_seg outside
+ * 1..3: OEH_EINVAL.  Same formulas as oeh_quantize_heads_i8; the
  * accumulation order differs from a library GEMM's, so an index may differ by one step where the value sits on a rounding
  * boundary to within the fp32 accumulation error (both are fp32-grade: |acc - exact| <~ 1e-6 of the row's scale). */
 typedef struct {

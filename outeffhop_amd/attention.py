@@ -100,6 +100,53 @@ def _note_gate(mod: nn.Module, gate: torch.Tensor, num_heads: int) -> None:
         mod.last_gate_avg_prob = gate.mean(dim=0).view(num_heads, -1).mean(dim=1)
 
 
+_warned_autograd = []
+
+
+def autograd_needed(mod: nn.Module, *ts) -> bool:
+    """True when this forward has to be differentiable: autograd is recording and an input or a parameter of the module requires
+    grad (training under the reference's swap-in: run_clm.py:214-233, run_mlm.py:200-219).  The modules then take the observable
+    torch-op path (`unfused_core`, `softmax.softmax_autograd`, `gate_autograd`) - slower, on the GPU - because the HIP kernels are
+    forward-only; under torch.no_grad() / inference_mode() nothing changes.  Says so once."""
+    if not torch.is_grad_enabled():
+        return False
+    if not (any(t is not None and t.requires_grad for t in ts) or any(p.requires_grad for p in mod.parameters())):
+        return False
+    if not _warned_autograd:
+        import warnings
+
+        _warned_autograd.append(True)
+        warnings.warn("outeffhop_amd: autograd is recording - this forward runs the differentiable torch-op path, not the fused HIP "
+                      "kernels (forward-only); wrap inference in torch.no_grad()", RuntimeWarning, stacklevel=3)
+    return True
+
+
+def gate_autograd(mod: nn.Module, hidden_states: torch.Tensor, num_heads: int) -> Optional[torch.Tensor]:
+    """The gate as the reference's torch ops (bert_attention.py:294-331 = opt_attention.py:265-304, vit_attention.py:241-262), so
+    that gradients reach `alpha`: probabilities broadcastable to (B,H,T,1) WITHOUT the scaling factor, bookkeeping attributes set."""
+    gt = mod.attn_gate_type
+    if gt == AttentionGateType.unconditional_per_head:
+        gate = torch.sigmoid(mod.alpha)
+        mod.last_gate_avg_prob = gate.view(-1)
+        return gate.view(1, -1, 1, 1)
+    if gt not in _CONDITIONAL:
+        return None
+    if mod.attn_gate_linear_all_features:
+        gate = torch.sigmoid(mod.alpha(hidden_states)).permute(0, 2, 1).contiguous().unsqueeze(3)
+    else:
+        x = hidden_states.view(hidden_states.shape[:-1] + (num_heads, -1)).permute(0, 2, 1, 3)  # (B,H,T,d)
+        logits = []
+        for h in range(num_heads):
+            a = mod.alpha[h](x[:, h, ...])  # (B,T,1)
+            if gt == AttentionGateType.conditional_per_head:
+                a = a.mean(dim=1, keepdim=True)  # (B,1,1)
+            logits.append(a)
+        gate = torch.sigmoid(torch.stack(logits, dim=1))  # (B,H,*,1)
+    mod.last_gate_all_probs = gate
+    mod.last_gate_avg_prob = gate.mean(dim=0).view(num_heads, -1).mean(dim=1)
+    return gate
+
+
 class GateState:
     """Evaluates the gate with HIP kernels and keeps the reference's bookkeeping attributes."""
 
@@ -146,6 +193,9 @@ class GateState:
         """Gate probabilities, broadcastable to (B,H,T,1), fp32, WITHOUT the scaling factor; sets
         last_gate_avg_prob / last_gate_all_probs like bert_attention.py:299,329-331."""
         gt = mod.attn_gate_type
+        if gt != AttentionGateType.none and ops.grad_recording(hidden_states, *(mod.alpha.parameters() if isinstance(mod.alpha, nn.Module) else (mod.alpha,))):
+            ops._need_gpu(hidden_states, allow_grad=True)
+            return gate_autograd(mod, hidden_states, num_heads)
         if gt == AttentionGateType.unconditional_per_head:
             gate = torch.sigmoid(mod.alpha.float())
             mod.last_gate_avg_prob = gate.view(-1)
@@ -382,7 +432,7 @@ def unfused_core(
     contractions are rocBLAS batched GEMMs and the softmax is the HIP row kernel behind SOFTMAX_MAPPING.
     Op order of bert_attention.py:222-292 / opt_attention.py:204-263.
     Returns (context (B,H,Sq,d), probs before dropout/head-mask, probs actually multiplied with V)."""
-    ops._need_gpu(q, k, v)  # GPU only, like the fused path: this package has no CPU implementation
+    ops._need_gpu(q, k, v, allow_grad=True)  # GPU only, like the fused path: this package has no CPU implementation; differentiable
     scores = torch.matmul(q, k.transpose(-1, -2))
     if extra_scores is not None:
         scores = scores + extra_scores

@@ -14,7 +14,7 @@ from typing import Optional, Tuple
 import torch
 from torch import nn
 
-from .attention import AttentionGateType, GateBookkeeping, GateState, attention_core, build_gate, fused_qkv, has_hooks, unfused_core
+from .attention import AttentionGateType, GateBookkeeping, GateState, attention_core, autograd_needed, build_gate, fused_qkv, has_hooks, unfused_core
 from .softmax import clipped_softmax, spec_of
 
 
@@ -105,8 +105,8 @@ class BertSelfAttentionWithExtras(GateBookkeeping, nn.Module):
             rel = rel + torch.einsum("bhrd,lrd->bhlr", k, emb)
         return rel
 
-    def _fusable(self, head_mask, output_attentions) -> bool:
-        return (spec_of(self.softmax_fn) is not None and head_mask is None and not output_attentions
+    def _fusable(self, head_mask, output_attentions, *inputs) -> bool:
+        return (spec_of(self.softmax_fn) is not None and head_mask is None and not output_attentions and not autograd_needed(self, *inputs)
                 and not (self.training and self.dropout.p > 0.0) and self.position_embedding_type == "absolute"
                 and not has_hooks(self.attn_scores, self.attn_probs_before_dropout, self.attn_probs_after_dropout))
 
@@ -120,7 +120,7 @@ class BertSelfAttentionWithExtras(GateBookkeeping, nn.Module):
         use_cache = past_key_value is not None
         q, k, v, attention_mask = self._project(hidden_states, attention_mask, encoder_hidden_states, encoder_attention_mask, past_key_value)
         new_past = (k, v) if self.is_decoder else None
-        fusable = self._fusable(head_mask, output_attentions)
+        fusable = self._fusable(head_mask, output_attentions, hidden_states, encoder_hidden_states, q, k, v)
         # conditional per-token gate: evaluated inside the attention kernel when the fused path runs
         gp = GateState.predictor(self, hidden_states, self.num_attention_heads, self.gate_scaling_factor) if fusable else None
         gate = None

@@ -283,6 +283,9 @@ int flash_mq(const oeh_attn_desc* d) {
 // The 32x32x16 form of the one-pass kernel (oeh_attn_wide.hip): plain softmax / softmax_1, 16-bit storage, head dim 64, masks none |
 // causal, gate values only.  Behind the diagnostic hook (oeh_debug_set_variant bit 12) until it is measured ahead.
 bool wide_eligible(const oeh_attn_desc* d, const oeh_fq_desc* fq) {
+#ifndef OEH_WITH_WIDE
+  return false;  // the candidate is not part of the production library (csrc/Makefile: `make experiment` builds it in)
+#endif
   if (!g_wide || d->D != 64 || (d->dtype != OEH_F16 && d->dtype != OEH_BF16) || want_out32(d)) return false;
   if (d->clip || any_fq(fq) || d->key_pad_mask != nullptr || d->full_mask != nullptr || (d->gate == nullptr && d->gate_hidden != nullptr)) return false;
   return d->Sq > 64;
@@ -425,11 +428,22 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
   fill_params(P, desc, q, k, v, o, fq);
   P.src32 = (desc->dtype == OEH_F32 && (var == V_FLASH || var == V_FAST)) ? 1 : 0;  // fp32 storage read directly, fp32 output
   if (want_out32(desc)) {
-    // the accumulators themselves - sibling instantiations (O32) of what the 16-bit workloads of BASELINE.json run: the one-pass kernel's
-    // plain form (masks none / causal) and the full-row kernel's plain and clipped forms (+ key padding), head dim 64, gate values only
+    // the accumulators themselves - sibling instantiations (O32) of what the 16-bit workloads of BASELINE.json run.  Head dim 64: the one-pass
+    // kernel's plain form with masks none / causal / key padding / a (B,1,Sq,Sk) mask, or with the in-kernel gate predictor (not both);
+    // the full-row kernel's plain and clipped forms (+ key padding), the plain form with the in-kernel gate predictor.  Head dim 128
+    // (round 5): the plain forms of both (one block per wave in the one-pass kernel), gate values only.
     const bool gated_in_kernel = desc->gate == nullptr && desc->gate_hidden != nullptr;
-    const bool ok = desc->D == 64 && !any_fq(fq) && !gated_in_kernel &&
-                    ((var == V_FLASH && !desc->clip && desc->key_pad_mask == nullptr && desc->full_mask == nullptr) || var == V_FAST);
+    const bool masked = desc->key_pad_mask != nullptr || desc->full_mask != nullptr;
+    bool ok = !any_fq(fq);
+    if (desc->D == 64) {
+      if (var == V_FLASH) ok = ok && !desc->clip && !(masked && gated_in_kernel);
+      else if (var == V_FAST) ok = ok && !(desc->clip && gated_in_kernel);
+      else ok = false;
+    } else if (desc->D == 128) {
+      ok = ok && !desc->clip && !gated_in_kernel && ((var == V_FLASH && !masked && flash_mq(desc) == 1) || var == V_FAST);
+    } else {
+      ok = false;
+    }
     if (!ok) return OEH_ENOTSUP;
     P.out32 = 1;
   }
@@ -447,10 +461,12 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
   }
   if (var == V_FLASH) {
     if (desc->scale_div != 0.0f) { P.scale = 1.0f / desc->scale_div; P.scale_div = 0.0f; }  // (fast_eligible: exact for a power of two)
+#ifdef OEH_WITH_WIDE
     if (wide_eligible(desc, fq)) {
       P.nQT = (desc->Sq + 127) / 128;
       return oeh::launch_attn_wide(P, desc->dtype, st);
     }
+#endif
     const int mq = flash_mq(desc);
     P.nQT = (desc->Sq + 64 * mq - 1) / (64 * mq);
     switch (desc->D) {
@@ -603,6 +619,7 @@ int oeh_proj_quant_i8(const void* a, int32_t pairs, const void* w, const float* 
     if (!(g.scale > 0.0f) || g.zero_point < 0.0f || g.zero_point > 255.0f || g.zero_point != std::nearbyint(g.zero_point)) return OEH_EINVAL;
     if ((reinterpret_cast<uintptr_t>(g.out) & 15) != 0 || (reinterpret_cast<uintptr_t>(g.y) & 3) != 0) return OEH_EALIGN;
     if (g.y != nullptr && g.y_stride_row < E) return OEH_EINVAL;
+    if (g.y != nullptr && (12 * g.y_stride_row + 16) * 4 >= 0xffffffffLL) return OEH_ENOTSUP;  // (32-bit lane offsets of the value stores: oeh_gemm.hip y_voff)
     oeh::GemmSeg& t = P.seg[i];
     t.alpha = g.alpha; t.out = reinterpret_cast<signed char*>(g.out); t.y = g.y; t.y_ld = g.y_stride_row; t.transpose = g.transpose ? 1 : 0;
     t.acc_add = pairs == 3 ? g.acc_add : nullptr;

@@ -71,7 +71,7 @@ constexpr int fast_occupancy() {  // what the LDS rings allow (6 tiles of 64 x 2
 template <int NT, int D, int IN, bool CLIP, bool GATE, int FQ = 0, bool SRC32 = false, bool O32 = false>
 __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void oeh_attn_fast_kernel(const AttnParams P) {
   static_assert(!SRC32 || IN == IN_F16, "fp32 storage: fp16 operand pairs, fp32 output");
-  static_assert(!O32 || (!SRC32 && !GATE && FQ == 0), "fp32 output of 16-bit storage: the plain and clipped forms");
+  static_assert(!O32 || (!SRC32 && FQ == 0 && !(GATE && CLIP)), "fp32 output of 16-bit storage: the plain and clipped forms, the plain form + in-kernel gate");
   constexpr bool OUT32 = SRC32 || O32;
   static_assert(!FQ || !GATE, "the fake-quant variant has no in-kernel gate predictor");
   constexpr bool GRID = (FQ == 1 || FQ == 3), GRIDPAD = (FQ == 3);  // FQ == 3: the grid chain with a key-padding vector of 0 / <= -1e4 entries
@@ -899,10 +899,17 @@ static void launch_fast_nt_d_in(const AttnParams& P, unsigned grid, hipStream_t 
     else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 2>), dim3(grid), dim3(256), 0, st, P);
     return;
   }
-  if constexpr (D == 64) {  // (oeh_api.hip: out32_supported)
+  if constexpr (D == 64) {  // (oeh_api.hip: the out32 rule - head dim 64: plain, clipped, plain + the in-kernel gate predictor)
     if (P.out32) {
       if (P.clip) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, true, false, 0, false, true>), dim3(grid), dim3(256), 0, st, P);
+      else if (gate) hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, true, 0, false, true>), dim3(grid), dim3(256), 0, st, P);
       else hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 0, false, true>), dim3(grid), dim3(256), 0, st, P);
+      return;
+    }
+  }
+  if constexpr (D == 128) {  // (head dim 128: the plain form)
+    if (P.out32) {
+      hipLaunchKernelGGL((oeh_attn_fast_kernel<NT, D, IN, false, false, 0, false, true>), dim3(grid), dim3(256), 0, st, P);
       return;
     }
   }

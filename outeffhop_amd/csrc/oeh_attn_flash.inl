@@ -65,7 +65,7 @@ constexpr int flash_occupancy() { return D >= 128 ? 1 : (SRC32 ? 2 : 3); }  // f
 template <int D, int IN, int MQ, bool PAD, bool GATE, bool SRC32 = false, int TP = 0, bool O32 = false>
 __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_attn_flash_kernel(const AttnParams P) {
   static_assert(IN == IN_F16 || IN == IN_BF16, "16-bit matrix-core operands");
-  static_assert(!O32 || (!SRC32 && !GATE && !PAD && TP == 0), "fp32 output of 16-bit storage: the plain one-pass form");
+  static_assert(!O32 || (!SRC32 && TP == 0 && !(GATE && PAD)), "fp32 output of 16-bit storage: the plain one-pass form [+ key padding | + in-kernel gate]");
   constexpr bool CLIP = (TP == 1), FQ2 = (TP == 2);
   static_assert(TP == 0 || !GATE, "two-pass forms: no in-kernel gate predictor");
   static_assert(!SRC32 || (!GATE && IN == IN_F16), "fp32 storage: fp16 operands, fp32 output, no in-kernel gate predictor");
@@ -635,6 +635,14 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       // visible key).  lacc holds the row sum in every register of every lane of the row: the decision stays per row.
       float thr_j = thr;
       if constexpr (has_pad && MODE == 0) thr_j = (lacc[j][0] == 0.0f) ? -1.0e20f : thr;
+      if constexpr (has_pad && MODE == 1) {
+        // the statistics pass of the two-pass clipped form: the same rule.  Its row sum is dealt over the row's four lanes
+        // (c, c + 16, c + 32, c + 48): "nothing accumulated yet" = none of them holds a non-zero share - one ballot, folded to the row's bit
+        unsigned long long seen = __builtin_amdgcn_ballot_w64(lsum[j] != 0.0f);
+        seen |= seen >> 32;
+        seen |= seen >> 16;
+        thr_j = ((seen >> c) & 1ull) ? thr : -1.0e20f;
+      }
       if (__builtin_amdgcn_ballot_w64(mt > thr_j) != 0) {
         mt = row_allreduce_max(mt);
         const float delta = (mt > thr_j) ? mt : 0.0f;
@@ -645,7 +653,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
           for (int r = 0; r < 4; ++r) s[j][sub][r] -= delta;
         if (i != 0) {
           float alpha = __builtin_amdgcn_exp2f(-delta);
-          if constexpr (has_pad && MODE == 0) alpha = (thr_j < -1.0e19f) ? 1.0f : alpha;  // nothing accumulated yet (and exp2(-delta) may overflow)
+          if constexpr (has_pad && (MODE == 0 || MODE == 1)) alpha = (thr_j < -1.0e19f) ? 1.0f : alpha;  // nothing accumulated yet (and exp2(-delta) may overflow)
           if constexpr (MODE == 1) lsum[j] *= alpha;
 #pragma unroll
           for (int r = 0; r < 4; ++r) lacc[j][r] *= alpha;
@@ -978,7 +986,15 @@ static void launch_flash_d_mq_in(const AttnParams& P, unsigned grid, hipStream_t
     else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, false, 1>), dim3(grid), dim3(256), 0, st, P);
     return;
   }
-  if constexpr (D == 64) {  // (oeh_api.hip: out32_supported)
+  if constexpr (D == 64) {  // (oeh_api.hip: the out32 rule - head dim 64: plain, + key padding / a (B,1,Sq,Sk) mask, + the in-kernel gate predictor)
+    if (P.out32) {
+      if (pad) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, true, false, false, 0, true>), dim3(grid), dim3(256), 0, st, P);
+      else if (gate) hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, true, false, 0, true>), dim3(grid), dim3(256), 0, st, P);
+      else hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, false, 0, true>), dim3(grid), dim3(256), 0, st, P);
+      return;
+    }
+  }
+  if constexpr (D == 128 && MQ == 1) {  // (head dim 128: the plain form; flash_mq gives one block per wave there)
     if (P.out32) {
       hipLaunchKernelGGL((oeh_attn_flash_kernel<D, IN, MQ, false, false, false, 0, true>), dim3(grid), dim3(256), 0, st, P);
       return;

@@ -34,6 +34,7 @@
 #include "oeh_common.h"
 #include "oeh_gemm.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace oeh {
@@ -61,6 +62,15 @@ struct Geo {
   static constexpr int PITCH_C = BM + 16, IMG_C = BM * BN, IMGS = IMG_C + BN * PITCH_C;   // the epilogue's byte images
   static constexpr int LDS = 2 * SLOT > IMGS ? 2 * SLOT : IMGS;
 };
+
+// Diagnostic knock-outs (OEH_GEMM_DBG, tools/exp/proj_time.py) exist only in a build with -DOEH_GEMM_EXPERIMENT (`make experiment`): in the
+// production kernel they are the constant 0 and compile out (a leftover environment variable must not make the shipping
+// library return wrong numbers).
+#ifdef OEH_GEMM_EXPERIMENT
+#define GEMM_DBG(P) ((P).dbg)
+#else
+#define GEMM_DBG(P) 0
+#endif
 
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef int i4 __attribute__((ext_vector_type(4)));
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
     }
   }
   const int m0 = mi * GBM, n0 = ni * GBN;
-  const int T = (P.dbg & 2) ? 2 : P.K * EB / (GBK * 2);
+  const int T = (GEMM_DBG(P) & 2) ? 2 : P.K * EB / (GBK * 2);
 
   // ---- LDS-DMA: piece p (1 KB = 16 rows x 64 B); lane -> row p * 16 + (lane >> 2), stored chunk lane & 3 = logical chunk ^ (-(row >> 2) & 3)
   const unsigned lds_base = lds_offset(lds);
@@ -159,12 +169,12 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
 
   issue(0);
   for (int t = 0; t < T; ++t) {
-    if (!(P.dbg & 8)) {
+    if (!(GEMM_DBG(P) & 8)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       barrier_mem();
     }
-    const bool more = t + 1 < T && !((P.dbg & 4) && t >= 1);
-    if ((P.dbg & 64) && more) issue(t + 1);
+    const bool more = t + 1 < T && !((GEMM_DBG(P) & 4) && t >= 1);
+    if ((GEMM_DBG(P) & 64) && more) issue(t + 1);
     const unsigned char* sl = lds + (t & 1) * G_SLOT;
     h8v ah[MI], al[MI];
     f4 x32[AM == A_F32 ? MI : 1][2];
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bf[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(P.dbg & 64) && more) {
+        if (!(GEMM_DBG(P) & 64) && more) {
 #pragma unroll
           for (int u = 0; u < PI; ++u)
             if (PI * i + u < NQ) issue_q(t + 1, PI * i + u);
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
         // wave spends its issue slots on them, and every piece is under way before the middle of the step
         if (kPer * j < NQ) {
           __builtin_amdgcn_sched_barrier(0);
-          if (!(P.dbg & 64) && more) {
+          if (!(GEMM_DBG(P) & 64) && more) {
 #pragma unroll
             for (int u = 0; u < kPer; ++u)
               if (kPer * j + u < NQ) issue_q(t + 1, kPer * j + u);
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
   }
 
   // ---- epilogue.  C[row 16 i + 4 lq + r][col 16 j + l15]
-  if (P.dbg & 1) {
+  if (GEMM_DBG(P) & 1) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
           unsigned word = 0;
           const int rl = 16 * MI * wm + 16 * i + 4 * lq;  // tile-local first row of the lane's four
           if (ybase != nullptr) {
-            const bool rows_in = m0 + 16 * MI * wm + 16 * i < P.M && !(P.dbg & 16);  // (M % 16 == 0: a 16-row tile is inside or outside as a whole)
+            const bool rows_in = m0 + 16 * MI * wm + 16 * i < P.M && !(GEMM_DBG(P) & 16);  // (M % 16 == 0: a 16-row tile is inside or outside as a whole)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float rel = fq_rel(__builtin_fmaf(accv(i, r), alpha, bia), f);
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
       }
     }
     barrier_mem();
-    if (P.dbg & 32) return;
+    if (GEMM_DBG(P) & 32) return;
     // plain segments: BM rows x BN / 16 pieces, consecutive threads on consecutive pieces of a row
     for (int e = tid; e < GBM * (GBN / 16); e += 256) {
       const int row = e / (GBN / 16), c16 = e - row * (GBN / 16);
@@ -370,7 +380,15 @@ int launch_gemm(const GemmParams& P0, hipStream_t st) {
   static const bool hooks = [] { const char* e = getenv("OEH_DEBUG_HOOKS"); return e != nullptr && e[0] == '1'; }();
   static const int dbg = [] { const char* e = getenv("OEH_GEMM_DBG"); return e ? atoi(e) : 0; }() * (hooks ? 1 : 0);
   static const int force = [] { const char* e = getenv("OEH_GEMM_TILE"); return e ? atoi(e) : 0; }() * (hooks ? 1 : 0);
+#ifdef OEH_GEMM_EXPERIMENT
   P.dbg = dbg;
+#else
+  P.dbg = 0;
+  if (dbg != 0) {
+    static bool said = false;
+    if (!said) { said = true; fprintf(stderr, "liboeh_hip: OEH_GEMM_DBG is set but this build has no knock-outs (make experiment): ignored\n"); }
+  }
+#endif
   P.magic_s = P.S > 1 ? (unsigned)(0x100000000ULL / (unsigned long long)P.S) : 0xffffffffu;
   const long t0 = (long)((P.M + 127) / 128) * ((P.N + 287) / 288);
   const double waste0 = (double)t0 * 128.0 * 288.0 / ((double)P.M * (double)P.N);

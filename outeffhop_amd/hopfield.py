@@ -16,7 +16,7 @@ import torch
 from torch import nn
 
 from .attention import unfused_core
-from .ops import SoftmaxSpec, attn_fwd
+from .ops import SoftmaxSpec, attn_fwd, grad_recording
 from .softmax import SoftmaxFn
 from .sparse_activations import EntmaxAlpha, Sparsemax
 
@@ -50,7 +50,7 @@ class Association(nn.Module):
         if not isinstance(self.softmax, SoftmaxFn):  # sparse activations: scores materialised, torch ops (outside the HIP path)
             probs = self.dropout(self.softmax(scale * torch.matmul(q, k.transpose(-1, -2))))
             return torch.matmul(probs, v).permute(0, 2, 1, 3).contiguous()
-        if self.training and self.dropout.p > 0.0:
+        if (self.training and self.dropout.p > 0.0) or grad_recording(q, k, v):  # dropout / autograd: the observable torch-op path
             ctx, _, _ = unfused_core(q, k, v, softmax_fn=self.softmax, scale=scale, dropout=self.dropout)
             return ctx.permute(0, 2, 1, 3).contiguous()
         out = attn_fwd(q, k, v, softmax=self.softmax.spec, scale=scale)  # stored (B,L,H,D)-contiguous

@@ -55,10 +55,18 @@ class AttnFakeQuant:
     ctx_emit_index: bool = False  # the output holds the context quantiser's integers idx - zp (include/oeh.h: ctx_emit_index)
 
 
-def _need_gpu(*ts):
-    """Every tensor on ONE GPU, and none of them part of an autograd graph being recorded: the library is the only
-    implementation (no CPU path) and it is forward-only - its outputs carry no grad_fn, so running it under autograd
-    would drop the gradients of q / k / v / gate silently.  Raise instead (inference: `with torch.no_grad():`)."""
+def grad_recording(*ts) -> bool:
+    """True when autograd is recording and one of the tensors is part of the graph: the callers then take the differentiable
+    torch-op form of the same op chain (attention.unfused_core, softmax.softmax_autograd, attention.gate_autograd) - on the GPU, like
+    everything else here - instead of the forward-only HIP kernels."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+def _need_gpu(*ts, allow_grad: bool = False):
+    """Every tensor on ONE GPU, and (unless `allow_grad`: the torch-op path) none of them part of an autograd graph being
+    recorded: the library is the only implementation (no CPU path) and it is forward-only - its outputs carry no grad_fn, so
+    running it under autograd would drop the gradients of q / k / v / gate silently.  The modules route such calls to the torch-op
+    path before they get here (`grad_recording`); a direct op call raises (inference: `with torch.no_grad():`)."""
     dev = None
     for t in ts:
         if t is None:
@@ -69,7 +77,7 @@ def _need_gpu(*ts):
             dev = t.device
         elif t.device != dev:
             raise _lib.OehError(f"outeffhop_amd ops need all tensors on one GPU, got {dev} and {t.device}")
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
+    if not allow_grad and grad_recording(*ts):
         raise _lib.OehError("outeffhop_amd is forward-only (the backward pass is out of scope, DESIGN.md section 7): an input requires "
                             "grad while autograd is recording - run inference under torch.no_grad() / torch.inference_mode()")
     return dev

@@ -16,7 +16,7 @@ from typing import Optional, Tuple
 import torch
 from torch import nn
 
-from .attention import AttentionGateType, GateBookkeeping, GateState, attention_core, build_gate, fused_qkv, has_hooks, linear_fp32, unfused_core
+from .attention import AttentionGateType, GateBookkeeping, GateState, attention_core, autograd_needed, build_gate, fused_qkv, has_hooks, linear_fp32, unfused_core
 from .softmax import clipped_softmax, clipped_softmax1, spec_of
 
 
@@ -104,7 +104,7 @@ class OPTAttentionWithExtras(GateBookkeeping, nn.Module):
         if layer_head_mask is not None and layer_head_mask.size() != (self.num_heads,):
             raise ValueError(f"Head mask for a single layer should be of size {(self.num_heads,)}, but is {layer_head_mask.size()}")
         fusable = (spec_of(self.softmax_fn) is not None and layer_head_mask is None and not output_attentions
-                   and not (self.training and self.dropout > 0.0)
+                   and not (self.training and self.dropout > 0.0) and not autograd_needed(self, hidden_states, key_value_states, q, k, v)
                    and not has_hooks(self.attn_scores, self.attn_probs_before_dropout, self.attn_probs_after_dropout))
         # conditional per-token gate: evaluated inside the attention kernel when the fused path runs (self-attention only:
         # the predictor acts on the query-side layer input)

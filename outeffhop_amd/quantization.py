@@ -603,7 +603,22 @@ class QuantLinear(QuantizedModule, nn.Linear):
         """`linear_index` on int8 centred indices applies: frozen 8-bit asymmetric output quantiser, K % 64 == 0, whole 16-row groups."""
         aq = self.activation_quantizer
         return (FUSED_PROJ and self._qa and self.out_features % 64 == 0 and aq.is_fixed and type(aq.quantizer) is AsymmetricUniformQuantizer
-                and aq.quantizer.n_bits == 8 and self.in_features % 64 == 0 and rows % 16 == 0 and self.bias is not None)
+                and aq.quantizer.n_bits == 8 and self.in_features % 64 == 0 and rows % 16 == 0 and self.bias is not None
+                and self._int8_weights_fit())
+
+    def _int8_weights_fit(self) -> bool:
+        """The weight's integers fit a SIGNED byte.  A SymmetricUniformQuantizer whose weights are all >= 0 is unsigned: its integers
+        run to 255, exact in fp16 (the fp16-integer form of `linear_index` serves them) but not as int8 - 128 ... 255 would wrap
+        (ADVICE r4).  One host read per weight / weight-range version, cached."""
+        qz = self.weight_quantizer.quantizer
+        key = (self.weight.data_ptr(), self.weight._version, qz._delta.data_ptr(), qz._delta._version)
+        hit = self.__dict__.get("_int8_fit_cache")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                iw = qz.to_integer_forward(self.weight.detach())
+                hit = (key, bool(((iw >= -128) & (iw <= 127)).all()))
+            self.__dict__["_int8_fit_cache"] = hit
+        return hit[1]
 
     def _int8_weights(self, xzero: float):
         """The weight's integers as int8 (N, K), (128 - xzero) * their row sums as int32 (N) and the fp32 weight scale, cached."""
@@ -613,6 +628,8 @@ class QuantLinear(QuantizedModule, nn.Linear):
         if hit is None or hit[0] != key:
             with torch.no_grad():
                 iw = qz.to_integer_forward(self.weight.detach())
+                if not self._int8_weights_fit():
+                    raise ValueError("the weight's integers do not fit int8 (an unsigned grid): use the fp16 integer form (int8_index_ok)")
                 iw8 = iw.to(torch.int8).contiguous()
                 add = (int(128 - int(xzero)) * iw.to(torch.int64).sum(dim=1)).to(torch.int32).contiguous()
                 s32 = float(np.float32(float(qz.scale)))
@@ -884,9 +901,16 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
                 x2 = x2.clone(memory_format=torch.contiguous_format)
             w3, b3, scales3 = self._qkv_int_weights(lins)
             specs = [z.spec() for z in qzs]
-            outs = ops.proj_quant_i8(x2, w3, b3, bsz, tgt_len, [(scales3[n_], specs[n_], n_ == 2, n_ > 0 and want_values) for n_ in range(3)], pairs=True)
-            grids = [ops.QuantGrid.of(sp) for sp in specs]
-            self.__dict__["_fused_proj_calls"] = self.__dict__.get("_fused_proj_calls", 0) + 1  # (tests: which path ran)
+            try:
+                outs = ops.proj_quant_i8(x2, w3, b3, bsz, tgt_len, [(scales3[n_], specs[n_], n_ == 2, n_ > 0 and want_values) for n_ in range(3)], pairs=True)
+                grids = [ops.QuantGrid.of(sp) for sp in specs]
+                self.__dict__["_fused_proj_calls"] = self.__dict__.get("_fused_proj_calls", 0) + 1  # (tests: which path ran)
+            except _OehError as e:  # a size / alignment the fused kernel refuses (32-bit lane offsets ...): the library pair GEMM below
+                if e.code not in (-95, -14):
+                    raise
+                outs = []
+        if outs:
+            pass
         elif all_pairs:
             # fp32 model: the input as fp16 operand pairs, split once, and ONE fp16 GEMM against the three integer weight
             # matrices side by side; each projection's weight scale and bias are folded into its quantiser pass

@@ -21,6 +21,21 @@ from . import ops
 from .ops import SoftmaxSpec
 
 
+def softmax_autograd(data: torch.Tensor, spec: SoftmaxSpec, dim: int = -1) -> torch.Tensor:
+    """The registry entry as differentiable torch ops, in the reference's op order (vutils/softmax_1.py:11-21, models/softmax.py:10-19):
+    what a `SoftmaxFn` runs while autograd is recording its input - training under the reference's swap-in (run_clm.py:214-233,
+    run_mlm.py:200-219) - since the HIP row kernel is forward-only.  Still on the tensor's GPU: rocm ATen kernels, no CPU path."""
+    if spec.base == 1:
+        m = data.max(dim=dim, keepdim=True).values
+        e = torch.exp(torch.subtract(data, m))
+        p = torch.divide(e, torch.add(e.sum(dim=dim, keepdim=True), torch.exp(torch.multiply(m, -1))))
+    else:
+        p = torch.nn.functional.softmax(data, dim=dim)
+    if spec.clip:
+        p = torch.clip(p * (spec.eta - spec.gamma) + spec.gamma, 0, 1)
+    return p
+
+
 class SoftmaxFn:
     """Callable registry entry; `spec` is what the fused kernel consumes."""
 
@@ -37,6 +52,9 @@ class SoftmaxFn:
             raise TypeError(f"softmax() got an unexpected keyword argument '{next(iter(kw))}'")
         if dtype is not None:
             data = data.to(dtype)
+        if ops.grad_recording(data):  # autograd is recording: the differentiable torch-op form (the HIP kernel is forward-only)
+            ops._need_gpu(data, allow_grad=True)
+            return softmax_autograd(data, self.spec, dim)
         return ops.softmax_rows(data, self.spec, dim=dim)
 
     def __repr__(self):

@@ -12,7 +12,7 @@ from functools import partial
 import torch
 from torch import nn
 
-from .attention import AttentionGateType, GateBookkeeping, GateState, attention_core, build_gate, has_hooks, linear_fp32, unfused_core
+from .attention import AttentionGateType, GateBookkeeping, GateState, attention_core, autograd_needed, build_gate, has_hooks, linear_fp32, unfused_core
 from .softmax import spec_of
 
 
@@ -63,7 +63,7 @@ class ViTSelfAttentionWithExtras(GateBookkeeping, nn.Module):
         H, d = self.num_attention_heads, self.attention_head_size
         q, k, v = linear_fp32(self.qkv, x).reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4).unbind(0)  # (B,H,N,d) views, unit d stride
         q, k = self.q_norm(q), self.k_norm(k)
-        fusable = (spec_of(self.softmax_fn) is not None and not (self.training and self.attn_drop.p > 0.0)
+        fusable = (spec_of(self.softmax_fn) is not None and not (self.training and self.attn_drop.p > 0.0) and not autograd_needed(self, x, q, k, v)
                    and not has_hooks(self.attn_scores, self.attn_probs_before_dropout, self.attn_probs_after_dropout))
         gp = GateState.predictor(self, x, H, self.gate_scaling_factor) if fusable else None  # gate evaluated in the kernel
         gate = None

@@ -705,13 +705,66 @@ def gen_sparse_acts():
     save("sparse_acts.npz", **arrays)
 
 
+def gen_train_grads():
+    """Training through the reference's swap-in modules (run_clm.py:214-233, run_mlm.py:200-219): a two-layer toy
+    y = x + OPTAttentionWithExtras(x), z = BertSelfAttentionWithExtras(y), loss = sum(w * z), in train() mode with autograd on -
+    the forward value and the gradients of the input and of every parameter (attention dropout 0: deterministic)."""
+    from transformers_language.models.bert_attention import AttentionGateType, BertSelfAttentionWithExtras
+    from transformers_language.models.opt_attention import OPTAttentionWithExtras
+    from transformers_language.models.softmax import SOFTMAX_MAPPING
+
+    class Cfg0(_Cfg):
+        attention_probs_dropout_prob = 0.0
+
+    B, T, E, H = 2, 32, 128, 2
+    g = torch.Generator().manual_seed(1012)
+    x0 = torch.randn(B, T, E, generator=g)
+    w = torch.randn(B, T, E, generator=g)
+    omask = _opt_mask(B, T, [32, 23])
+    bmask = _bert_mask(B, T, [32, 20])
+    arrays = {"x": _np(x0), "w": _np(w), "opt_mask": _np(omask), "bert_mask": _np(bmask)}
+    toys = [("toy0", "softmax1", "tok_linear", "clippedsoftmax1(-.025:1)", "tok_mlp"),
+            ("toy1", "vanilla", "uncond_head", "clipped(-.025:1)", "head_linear"),
+            ("toy2", "clippedsoftmax1(-.0001:1)", "tok_allfeat", "softmax1", "nogate")]
+    names = []
+    for i, (name, sm_a, gate_a, sm_b, gate_b) in enumerate(toys):
+        def kw_of(gc):
+            kw = dict(GATE_CASES[gc])
+            if "attn_gate_type" in kw:
+                kw["attn_gate_type"] = AttentionGateType[kw["attn_gate_type"]]
+            return kw
+
+        torch.manual_seed(4100 + i)
+        la = OPTAttentionWithExtras(E, H, is_decoder=True, softmax_fn=SOFTMAX_MAPPING[sm_a], **kw_of(gate_a))
+        lb = BertSelfAttentionWithExtras(Cfg0(), softmax_fn=SOFTMAX_MAPPING[sm_b], **kw_of(gate_b))
+        _randomise_gate(la, g)
+        _randomise_gate(lb, g)
+        la.train()
+        lb.train()
+        x = x0.clone().requires_grad_(True)
+        y = x + la(x, attention_mask=omask)[0]
+        z = lb(y, attention_mask=bmask)[0]
+        (z * w).sum().backward()
+        arrays[f"{name}.z"] = _np(z)
+        arrays[f"{name}.dx"] = _np(x.grad)
+        for tag, mod in (("a", la), ("b", lb)):
+            for k, v in mod.state_dict().items():
+                arrays[f"{name}.{tag}.w.{k}"] = _np(v)
+            for k, p_ in mod.named_parameters():
+                arrays[f"{name}.{tag}.g.{k}"] = _np(p_.grad if p_.grad is not None else torch.zeros_like(p_))
+                arrays[f"{name}.{tag}.hasgrad.{k}"] = np.array(p_.grad is not None)
+        names.append(json.dumps(dict(name=name, softmax_a=sm_a, gate_a=gate_a, softmax_b=sm_b, gate_b=gate_b)))
+    arrays["cases_json"] = np.array(names)
+    save("train_grads.npz", **arrays)
+
+
 def main():
     only = set(sys.argv[1:])
     assert os.path.isdir(REF), "reference not mounted: golden fixtures can only be generated in the build container"
     torch.set_num_threads(1)  # deterministic reduction order for the captured outputs
     _shim()
     gens = [gen_softmax_rows, gen_fakequant, gen_range_estimators, gen_bert_fp, gen_opt_fp, gen_int8, gen_vit, gen_core_cases,
-            gen_stanhop, gen_theory_cfg1, gen_sparse_acts]
+            gen_stanhop, gen_theory_cfg1, gen_sparse_acts, gen_train_grads]
     sys.path.insert(0, os.path.join(REF, "OutEffHop"))
     for fn in gens:  # `make_golden.py gen_vit` regenerates one file
         if not only or fn.__name__ in only:

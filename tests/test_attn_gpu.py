@@ -14,6 +14,7 @@ Tolerances (written here once):
     flips must be +-1 and rarer than 2e-3 per tensor, and outside flipped elements outputs agree to 1e-3.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -24,6 +25,8 @@ from tests.conftest import load_golden
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
+FLIP_RATE = 1e-4   # share of a fused quantiser's indices that may sit one step from the oracle's (measured <= 4e-6 at full size; round 4: 2e-3)
+OUT_OFF = 2e-4     # share of outputs that may sit one context-grid step off (round 4: 4e-3)
 F16_TOL = None  # fp16 storage: the contract above (1e-3 + half an fp16 ulp of the reference), see `_check`
 BF16_TOL = dict(atol=2e-2, rtol=2e-2)
 
@@ -46,6 +49,23 @@ def _np32(t):
     return t.detach().float().cpu().numpy()
 
 
+def _le(value, limit, what):
+    """`value <= limit` with the margin on record: OEH_TEST_REPORT=<file> appends "what value limit" per call - how the shares below were
+    set in round 5 (bounds ~500x looser than what the kernels deliver let a 0.1 % regression pass): measured on the
+    GPU box, then a bound a small factor above the measurement, never below one element of the smallest tensor."""
+    rep = os.environ.get("OEH_TEST_REPORT")
+    if rep:
+        with open(rep, "a") as f:
+            f.write(f"{what}\t{float(value):.3e}\t{float(limit):.3e}\n")
+    return float(value) <= float(limit)
+
+
+def _lib_of(ops):
+    from outeffhop_amd import _lib
+
+    return _lib.load()
+
+
 def _f16_limit(want, arith=1e-3):
     """arith + half an fp16 ulp of the reference value (the rounding of the stored output)"""
     return np.float32(arith) + 0.5 * np.spacing(np.abs(want).astype(np.float16)).astype(np.float32)
@@ -59,6 +79,7 @@ def _check(got, want, tol=F16_TOL, msg="", arith=1e-3):
     lim = _f16_limit(want, arith) if tol is None else tol["atol"] + tol["rtol"] * np.abs(want)
     assert np.isfinite(got).all(), f"{msg}: non-finite output"
     worst = float((err - lim).max())
+    _le(float((err / lim).max()), 1.0, f"_check[{msg}]")
     assert worst <= 0, f"{msg}: max abs err {err.max():.3e} (limit exceeded by {worst:.3e}) at {np.unravel_index((err - lim).argmax(), err.shape)}"
 
 
@@ -255,11 +276,11 @@ def test_int8_fused(ops, order, sm, S):
     got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=fq, **args)
     for name, dump in (("scores", dump_s), ("probs", dump_p), ("ctx", dump_c)):
         mx, rate = _flip_stats(dump.cpu().numpy(), ex[f"{name}_idx"])
-        assert mx <= 1 and rate < 2e-3, f"{name}: max index diff {mx}, flip rate {rate:.2e}"
+        assert mx <= 1 and _le(rate, FLIP_RATE, f"int8_fused[{order},{sm},{S}] {name} flip rate"), f"{name}: max index diff {mx}, flip rate {rate:.2e}"
     step = float(np.float32(d_c[0])) * float(gate.max())
     err = np.abs(_np32(got) - want)
     flipped = err > 1e-3 + 1e-3 * np.abs(want)
-    assert flipped.mean() < 4e-3 and err.max() <= 1.05 * step + 2e-3, f"out: {flipped.mean():.2e} elements off, max err {err.max():.3e} (step {step:.3e})"
+    assert _le(flipped.mean(), OUT_OFF, f"int8_fused[{order},{sm},{S}] outputs off") and err.max() <= 1.05 * step + 2e-3, f"out: {flipped.mean():.2e} elements off, max err {err.max():.3e} (step {step:.3e})"
     # production form (no dumps -> causal tile skipping allowed) gives the same bits
     fq2 = ops.AttnFakeQuant(FQ(*d_s), FQ(*d_p), FQ(*d_c), ctx_before_gate=before)
     got2 = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=fq2, **args)
@@ -309,7 +330,7 @@ def test_full_size_properties(ops):
     v2 = _rand((B, H, S, D), 104).cuda()
     lin = ops.attn_fwd(q, k, (v.float() + v2.float()).half(), **kw).float()
     sep = out.float() + ops.attn_fwd(q, k, v2, **kw).float()
-    assert float((lin - sep).abs().max()) < 8e-3
+    assert _le(float((lin - sep).abs().max()), 4e-3, "full_size linearity")
     k3, v3 = k.clone(), v.clone()
     k3[:, :, 300:] = 7.0
     v3[:, :, 300:] = -3.0
@@ -442,7 +463,7 @@ def test_int8_chain_on_long_rows_two_pass(ops, dt, order):
     step = float(np.float32(d_c[0])) * (float(gate.max()) if opt else 1.0)
     err = np.abs(_np32(got) - want)
     flipped = err > 1e-3 + 1e-3 * np.abs(want)
-    assert flipped.mean() < 4e-3 and err.max() <= 1.05 * step + 2e-3, f"out: {flipped.mean():.2e} elements off, max err {err.max():.3e} (step {step:.3e})"
+    assert _le(flipped.mean(), OUT_OFF, "fq2p outputs off") and err.max() <= 1.05 * step + 2e-3, f"out: {flipped.mean():.2e} elements off, max err {err.max():.3e} (step {step:.3e})"
     # 512 keys: the full-row kernel's result against the two-pass form forced over the same problem
     q5, k5, v5, g5 = q[:, :, :512].cuda(), k[:, :, :512].cuda(), v[:, :, :512].cuda(), gate[:, :, :512].cuda()
     a = ops.attn_fwd(q5, k5, v5, fq=fq, **{**args, "gate": g5})
@@ -452,7 +473,7 @@ def test_int8_chain_on_long_rows_two_pass(ops, dt, order):
     finally:
         lib.oeh_debug_set_variant(0, 0)
     d = (a.float() - b.float()).abs()
-    assert float(d.max()) <= 1.05 * step + 2e-3 and float((d > 1e-3).float().mean()) < 2e-3, (float(d.max()), float((d > 1e-3).float().mean()))
+    assert float(d.max()) <= 1.05 * step + 2e-3 and _le(float((d > 1e-3).float().mean()), OUT_OFF, "fq2p vs full-row outputs apart"), (float(d.max()), float((d > 1e-3).float().mean()))
 
 
 def test_snake_block_order_changes_nothing_but_the_placement(ops):
@@ -1402,7 +1423,7 @@ def test_int8_storage_randomised_sweep(ops):
         d = (got.float() - ref).abs()
         lim = tol + tol * ref.abs()
         frac_off = float((d > lim).float().mean())
-        assert float(d.max()) <= 1.05 * step + float(lim.max()) and frac_off <= 2e-3, \
+        assert float(d.max()) <= 1.05 * step + float(lim.max()) and _le(frac_off, OUT_OFF, f"i8 storage case {n} outputs off"), \
             f"case {n} {(B, H, Sq, Sk, causal, base, out_dtype)}: max diff {float(d.max()):.3e} (step {step:.3e}), {frac_off:.2e} off"
 
 
@@ -1567,9 +1588,9 @@ def test_int8_grid_chain_with_key_padding(ops, order, base, S, dt):
     for name, got in (("grid", grid), ("literal", literal)):
         err = np.abs(_np32(got) - want)
         off = float((err > 0.5 * step).mean())
-        assert np.isfinite(_np32(got)).all() and off < 4e-3 and err.max() <= 2.05 * step + 2e-3, f"{name}: {off:.2e} off, max {err.max() / step:.2f} steps"
+        assert np.isfinite(_np32(got)).all() and _le(off, OUT_OFF, f"grid-vs-literal {name} outputs off") and err.max() <= 2.05 * step + 2e-3, f"{name}: {off:.2e} off, max {err.max() / step:.2f} steps"
     d = (grid.float() - literal.float()).abs()
-    assert float((d > 0.5 * step).float().mean()) < 2e-3 and float(d.max()) <= 2.05 * step + 2e-3
+    assert _le(float((d > 0.5 * step).float().mean()), OUT_OFF, "grid vs literal apart") and float(d.max()) <= 2.05 * step + 2e-3
     if base == 1:
         assert float(grid[3].abs().max()) <= abs(float(np.float32(d_c[0])) * 0.51) + abs(want[3]).max()  # the sample without a visible key
 
@@ -1618,7 +1639,7 @@ def test_long_rows_with_key_padding_two_pass(ops, order, kind, dt):
     step = float(np.float32(d_c[0]))
     err = np.abs(_np32(got) - want)
     off = float((err > 0.5 * step).mean())
-    assert np.isfinite(_np32(got)).all() and off < 4e-3 and err.max() <= 2.05 * step + 2e-3, f"{off:.2e} off, max {err.max() / step:.2f} steps"
+    assert np.isfinite(_np32(got)).all() and _le(off, OUT_OFF, "fused chain outputs off") and err.max() <= 2.05 * step + 2e-3, f"{off:.2e} off, max {err.max() / step:.2f} steps"
 
 
 @pytest.mark.gpu
@@ -1750,7 +1771,7 @@ def test_clipped_int8_chain_on_the_quantiser_grid(ops, S, dt, pad):
     step = float(np.float32(d_c[0]))
     err = np.abs(_np32(got) - want)
     off = float((err > 0.5 * step).mean())
-    assert np.isfinite(_np32(got)).all() and off < 4e-3 and err.max() <= 2.05 * step + 2e-3, f"{off:.2e} off, max {err.max() / step:.2f} steps"
+    assert np.isfinite(_np32(got)).all() and _le(off, OUT_OFF, "fused chain outputs off") and err.max() <= 2.05 * step + 2e-3, f"{off:.2e} off, max {err.max() / step:.2f} steps"
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -1806,7 +1827,7 @@ def test_padding_masks_of_exactly_minus_1e4_hide_their_keys(ops, path):
     step = float(np.float32(d_c[0]))
     err = np.abs(_np32(got_hf) - want)
     off = float((err > 0.5 * step + 1e-3).mean())
-    assert err.max() <= 2.05 * step + 2e-3 and off < 4e-3, f"{path}: max {err.max() / step:.2f} steps, {off:.2e} off (padded keys attending?)"
+    assert err.max() <= 2.05 * step + 2e-3 and _le(off, OUT_OFF, f"{path} outputs off"), f"{path}: max {err.max() / step:.2f} steps, {off:.2e} off (padded keys attending?)"
 
 
 @pytest.mark.gpu
@@ -1869,6 +1890,73 @@ def test_fp32_output_of_the_16bit_kernels(ops, dt):
     assert ei.value.code == -95
     with pytest.raises(ValueError):
         ops.attn_fwd(q.float(), k.float(), v.float(), out_dtype=torch.float16)
+
+
+@pytest.mark.gpu
+def test_fp32_output_siblings_of_the_gated_padded_and_d128_kernels(ops):
+    """the `O32` equality - the stored fp16 output IS the fp32 accumulator rounded once, and the
+    accumulator is within 1e-3 of the reference - existed for the d = 64 plain / clipped forms only.  Now also: the in-kernel gate
+    predictor (full-row kernel, BERT cfg5's shape class; one-pass kernel on 320-key rows), key padding on the one-pass kernel, and
+    head dim 128 (both kernels).  Gated cases are held against the oracle run with the gate probabilities the kernel itself formed and
+    wrote out (their own error against the fp32 predictor is bounded in test_gate_predictor_fused_*): this isolates the attention
+    arithmetic, which is what the 1e-3 is about."""
+    fmin = float(np.finfo(np.float32).min)
+    dt = torch.float16
+
+    def run(name_prefix, q, k, v, want_kw, kw, gate_mlp=None, arith=1e-3, variant_kw=None):
+        B, H, Sq, D = q.shape
+        Sk = k.shape[2]
+        name = ops.attn_variant(B, H, Sq, Sk, D, dt, mask_min=fmin, **(variant_kw or {}))
+        assert name.startswith(name_prefix), name
+        mk = (lambda: dict(gate_mlp=ops.GatePredictor(gate_mlp.hidden, gate_mlp.w1, gate_mlp.b1, gate_mlp.w2, gate_mlp.b2, scaling=gate_mlp.scaling,
+                                                       out=torch.empty_like(gate_mlp.out)))) if gate_mlp is not None else (lambda: {})
+        a_kw = mk()
+        acc = ops.attn_fwd(q, k, v, out_dtype=torch.float32, mask_min=fmin, **kw, **a_kw)
+        o_kw = mk()
+        out = ops.attn_fwd(q, k, v, mask_min=fmin, **kw, **o_kw)
+        assert acc.dtype == torch.float32 and torch.equal(out, acc.to(dt)), f"{name}: the stored output is not the accumulator rounded once"
+        if gate_mlp is not None:
+            assert torch.equal(a_kw["gate_mlp"].out, o_kw["gate_mlp"].out)
+            want_kw = dict(want_kw, gate=(a_kw["gate_mlp"].out.cpu().numpy() * np.float32(gate_mlp.scaling))[..., None])
+        want = O.attn_core(_np32(q), _np32(k), _np32(v), **want_kw)
+        err = float(np.abs(_np32(acc) - want).max())
+        assert _le(err, arith, f"O32 arithmetic {name}"), f"{name}: arithmetic error {err:.3e} > {arith:.1e}"
+
+    # (1) BERT order, key padding, per-token gate from per-head MLPs 64 -> 16 -> 1 evaluated in the kernel: the full-row kernel (cfg5's class)
+    B, H, S, D = 4, 12, 128, 64
+    view = lambda t: t.cuda().view(B, S, H, D).permute(0, 2, 1, 3)  # noqa: E731
+    q, k, v = view(_rand((B, S, H * D), 6101)), view(_rand((B, S, H * D), 6102)), view(_rand((B, S, H * D), 6103))
+    hidden = _rand((B, S, H * D), 6104).cuda()
+    g = torch.Generator().manual_seed(6105)
+    w1, b1 = (torch.randn((H, 16, D), generator=g) * 0.2).cuda(), (torch.randn((H, 16), generator=g) * 0.2).cuda()
+    w2, b2 = (torch.randn((H, 16), generator=g) * 0.5).cuda(), torch.randn((H,), generator=g).cuda()
+    padm = _pad_mask(B, S, [128, 97, 64, 33], fmin)
+    gp = ops.GatePredictor(hidden, w1, b1, w2, b2, scaling=1.0, out=torch.empty((B, H, S), dtype=torch.float32, device="cuda"))
+    run("fast16/", q, k, v, dict(scale=8.0, scale_is_divisor=True, pad_mask=padm, **SPECS["softmax1"]),
+        dict(scale_div=8.0, key_pad_mask=torch.from_numpy(padm).cuda()), gate_mlp=gp, variant_kw=dict(scale_div=8.0, key_pad=True, gate_hidden=True))
+    # (2) the one-pass kernel with the in-kernel gate predictor (OPT order, causal, 512-key rows)
+    B, H, S = 2, 4, 512
+    view = lambda t: t.cuda().view(B, S, H, D).permute(0, 2, 1, 3)  # noqa: E731
+    q = view((_rand((B, S, H * D), 6111, dtype=torch.float32) * D ** -0.5).half())
+    k, v = view(_rand((B, S, H * D), 6112)), view(_rand((B, S, H * D), 6113))
+    hidden = _rand((B, S, H * D), 6114).cuda()
+    w1h, b1h, w2h, b2h = w1[:H].contiguous(), b1[:H].contiguous(), w2[:H].contiguous(), b2[:H].contiguous()
+    gp = ops.GatePredictor(hidden, w1h, b1h, w2h, b2h, scaling=1.0, out=torch.empty((B, H, S), dtype=torch.float32, device="cuda"))
+    run("flash16/", q, k, v, dict(causal=True, clamp_min=True, **SPECS["softmax1"]), dict(causal=True, clamp_min=True), gate_mlp=gp,
+        variant_kw=dict(causal=True, gate_hidden=True))
+    # (3) key padding on the one-pass kernel (softmax_1, left- and right-padded samples)
+    padm = np.zeros((B, S), dtype=np.float32)
+    padm[0, 400:] = fmin
+    padm[1, :70] = fmin
+    run("flash16/", q, k, v, dict(pad_mask=padm, **SPECS["softmax1"]), dict(key_pad_mask=torch.from_numpy(padm).cuda()), variant_kw=dict(key_pad=True))
+    # (4) head dim 128: the one-pass kernel ...
+    B2, H2, S2, D2 = 2, 2, 512, 128
+    q2 = (_rand((B2, H2, S2, D2), 6121, dtype=torch.float32) * D2 ** -0.5).half().cuda()
+    k2, v2 = _rand((B2, H2, S2, D2), 6122).cuda(), _rand((B2, H2, S2, D2), 6123).cuda()
+    run("flash16/", q2, k2, v2, dict(causal=True, clamp_min=True, **SPECS["softmax1"]), dict(causal=True, clamp_min=True), variant_kw=dict(causal=True))
+    # ... and the full-row kernel (short rows)
+    q3, k3, v3 = q2[:, :, :96].contiguous(), k2[:, :, :96].contiguous(), v2[:, :, :96].contiguous()
+    run("fast16/", q3, k3, v3, dict(**SPECS["vanilla"]), dict(softmax=_spec(ops, "vanilla")))
 
 
 @pytest.mark.gpu
@@ -1977,7 +2065,7 @@ def test_both_sides_of_every_dispatch_rule_meet_the_contract(ops, rule):
         if int8:
             step = float(np.float32(d_c[0]))
             err = np.abs(_np32(got) - want)
-            assert err.max() <= 2.05 * step + 2e-3 and float((err > 0.5 * step + 1e-3).mean()) < 4e-3, f"{rule} {name}: {err.max() / step:.2f} steps"
+            assert err.max() <= 2.05 * step + 2e-3 and _le(float((err > 0.5 * step + 1e-3).mean()), OUT_OFF, f"{rule} {name} outputs off"), f"{rule} {name}: {err.max() / step:.2f} steps"
         elif dt == torch.float32:
             _check(got, want, tol=dict(atol=5e-4, rtol=5e-4), msg=f"{rule} {name}")
         else:
@@ -2012,6 +2100,8 @@ def test_wide_mfma_form_of_the_one_pass_kernel(ops, dt):
             got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), **kw)
         finally:
             lib.oeh_debug_set_variant(0, 0)
+        if n == 0 and not name.startswith("flash16w/"):
+            pytest.skip("the 32x32x16 candidate is not in the production library since round 5 (csrc/Makefile: `make experiment`, OEH_LIB)")
         assert name.startswith("flash16w/"), name
         _check(got, want, tol=tol, msg=f"wide form {(B, H, Sq, Sk, causal, base)}")
     assert not ops.attn_variant(2, 3, 512, 512, 64, dt, causal=True, mask_min=fmin).startswith("flash16w/")  # (the hook is off again)
@@ -2052,3 +2142,35 @@ def test_clipped_softmax_on_long_rows_with_masks_two_pass(ops, kind, dt):
         got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), softmax=_spec(ops, sm_name), mask_min=fmin, **kw)
         assert np.isfinite(_np32(got)).all()
         _check(got, want, tol=tol, msg=f"{kind} {sm_name} {dt}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sm_name", ["clipped(-.003:1.003)", "clippedsoftmax1(-.025:1)", "vanilla"])
+def test_left_padded_rows_with_strongly_negative_scores_on_long_rows(ops, sm_name):
+    """a LEFT-padded sample whose visible scores are all below about -87.  The statistics pass of the two-pass clipped
+    form kept its initial reference 0 behind the fully masked first tile(s): every exponential underflowed, the row sum came out 0 and
+    under the vanilla clipped softmax the row was taken for one without a visible key (a uniform row times the clip) instead of the
+    real softmax.  It now moves the reference at a row's first VISIBLE tile, like the plain one-pass form (checked here too).  Rows of
+    704 keys (beyond the full-row kernels), the first 200 padded; q . k around -150 for the visible keys."""
+    B, H, S, D = 2, 2, 704, 64
+    fmin = float(np.finfo(np.float32).min)
+    rng = np.random.default_rng(77)
+    u = rng.standard_normal(D).astype(np.float32)
+    u /= np.linalg.norm(u)
+    q = (0.05 * rng.standard_normal((B, H, S, D)).astype(np.float32) + 12.5 * u).astype(np.float16)
+    k = (0.05 * rng.standard_normal((B, H, S, D)).astype(np.float32) - 12.0 * u).astype(np.float16)   # q . k ~ -150 +- 1
+    v = rng.standard_normal((B, H, S, D)).astype(np.float16)
+    padm = np.zeros((B, S), dtype=np.float32)
+    padm[0, :200] = fmin   # left padding over three whole 64-key tiles and a part of the fourth
+    padm[1, :64] = fmin
+    sp = SPECS[sm_name]
+    name = ops.attn_variant(B, H, S, S, D, torch.float16, clip=bool(sp["clip"]), base=sp["base"], key_pad=True, mask_min=fmin)
+    assert name.startswith("flash16/") and (name.endswith("clip2p") == bool(sp["clip"])), name
+    want = O.attn_core(q.astype(np.float32), k.astype(np.float32), v.astype(np.float32), pad_mask=padm, mask_min=fmin, **sp)
+    got = ops.attn_fwd(torch.from_numpy(q).cuda(), torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda(), softmax=_spec(ops, sm_name),
+                       key_pad_mask=torch.from_numpy(padm).cuda(), mask_min=fmin)
+    assert np.isfinite(_np32(got)).all()
+    if sp["base"] == 0:  # the reference's rows are real softmax rows over the visible keys, far from the uniform row the bug produced
+        uniform = v.astype(np.float32).mean(axis=2, keepdims=True)
+        assert np.abs(want - uniform).max() > 0.05
+    _check(got, want, tol=F16_TOL, msg=f"left padding, scores ~ -150, {sm_name}")

@@ -327,3 +327,103 @@ def test_percentile_pair_is_numpys_tuple_form():
         assert want.dtype == np.float64
         got = percentile_pair(torch.from_numpy(x), 100 - P, P)
         assert float(got[0]) == float(want[0]) and float(got[1]) == float(want[1]), (t, n, P, got, want)
+
+
+# ---- training under the reference's swap-in: with autograd recording the modules take the differentiable
+# torch-op path instead of raising.  tests/golden/train_grads.npz holds the REFERENCE's forward value and gradients (input + every
+# parameter) of a two-layer toy y = x + OPT(x), z = BERT(y), loss = sum(w z) in train() mode.
+class Cfg0(Cfg):
+    attention_probs_dropout_prob = 0.0
+
+
+def build_train_toy(g, case, device):
+    """The toy of tests/golden/make_golden.py:gen_train_grads out of this package's modules, with the reference's weights."""
+    la = oa.OPTAttentionWithExtras(128, 2, is_decoder=True, softmax_fn=oa.SOFTMAX_MAPPING[case["softmax_a"]], **gate_kwargs(case["gate_a"]))
+    lb = oa.BertSelfAttentionWithExtras(Cfg0(), softmax_fn=oa.SOFTMAX_MAPPING[case["softmax_b"]], **gate_kwargs(case["gate_b"]))
+    for tag, mod in (("a", la), ("b", lb)):
+        pre = f"{case['name']}.{tag}.w."
+        mod.load_state_dict({k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}, strict=True)
+        mod.to(device).train()
+    return la, lb
+
+
+def run_train_toy(g, case, device):
+    la, lb = build_train_toy(g, case, device)
+    x = torch.from_numpy(g["x"]).to(device).requires_grad_(True)
+    y = x + la(x, attention_mask=torch.from_numpy(g["opt_mask"]).to(device))[0]
+    z = lb(y, attention_mask=torch.from_numpy(g["bert_mask"]).to(device))[0]
+    assert z.grad_fn is not None
+    (z * torch.from_numpy(g["w"]).to(device)).sum().backward()
+    return la, lb, x, z
+
+
+def check_train_toy(g, case, la, lb, x, z, rtol, atol):
+    name = case["name"]
+
+    def close(got, want, what):
+        got = got.detach().float().cpu().numpy()
+        lim = atol * max(1.0, float(np.abs(want).max())) + rtol * np.abs(want)
+        err = np.abs(got - want)
+        assert np.isfinite(got).all() and (err <= lim).all(), f"{name} {what}: max err {err.max():.3e} (max |ref| {np.abs(want).max():.3e})"
+
+    close(z, g[f"{name}.z"], "forward")
+    close(x.grad, g[f"{name}.dx"], "d loss / d x")
+    n = 0
+    for tag, mod in (("a", la), ("b", lb)):
+        for k, p in mod.named_parameters():
+            if bool(g[f"{name}.{tag}.hasgrad.{k}"]):
+                assert p.grad is not None, f"{name}: no gradient reached {tag}.{k}"
+                close(p.grad, g[f"{name}.{tag}.g.{k}"], f"d loss / d {tag}.{k}")
+                n += 1
+            else:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0
+    assert n >= 12
+
+
+def test_autograd_routes_to_the_differentiable_torch_op_path(monkeypatch):
+    from outeffhop_amd import attention, ops
+    from outeffhop_amd._lib import OehError
+    from outeffhop_amd.softmax import softmax_autograd
+
+    g = load_golden("train_grads.npz")
+    case = json.loads(str(g["cases_json"][0]))
+    la, lb = build_train_toy(g, case, "cpu")
+    x = torch.from_numpy(g["x"])
+    # who takes the torch-op path: autograd recording AND something to differentiate; never under no_grad
+    attention._warned_autograd.clear()
+    with pytest.warns(RuntimeWarning, match="autograd is recording"):  # said once
+        assert attention.autograd_needed(la, x)
+    assert attention.autograd_needed(lb, x.clone().requires_grad_(True))
+    with torch.no_grad():
+        assert not attention.autograd_needed(la, x)
+    for p in la.parameters():
+        p.requires_grad_(False)
+    assert not attention.autograd_needed(la, x) and attention.autograd_needed(la, x.clone().requires_grad_(True))
+    # ... and it is NOT a CPU path: the package still refuses CPU tensors, in either mode
+    with pytest.raises(OehError, match="GPU"):
+        lb(x)
+    with torch.no_grad(), pytest.raises(OehError, match="GPU"):
+        lb(x)
+    with pytest.raises(OehError, match="GPU"):
+        oa.SOFTMAX_MAPPING["softmax1"](x.clone().requires_grad_(True))
+    # the registry entries as torch ops against the reference's captured rows (every numeric key), and their Jacobians in float64
+    r = load_golden("softmax_rows.npz")
+    for k in r["keys"]:
+        spec = oa.SOFTMAX_MAPPING[str(k)].spec
+        np.testing.assert_allclose(softmax_autograd(torch.from_numpy(r["x"]), spec).numpy(), r[f"y[{k}]"], rtol=3e-6, atol=1e-7, err_msg=str(k))
+        if f"ym[{k}]" in r.files:  # masked rows, the fully masked one, the exp-range edges
+            np.testing.assert_allclose(softmax_autograd(torch.from_numpy(r["xm"]), spec).numpy(), r[f"ym[{k}]"], rtol=3e-6, atol=1e-7, err_msg=str(k))
+            for e in ("allmasked", "below_exp_range", "big", "single"):
+                np.testing.assert_allclose(softmax_autograd(torch.from_numpy(r[f"edge_x[{e}]"]), spec).numpy(), r[f"edge_y[{e}][{k}]"], rtol=3e-6, atol=1e-7)
+    x64 = torch.randn(3, 7, dtype=torch.float64, requires_grad=True)
+    for key in ("softmax1", "clippedsoftmax1(-.025:1)", "clipped(-.03:1.03)"):
+        assert torch.autograd.gradcheck(lambda t: softmax_autograd(t, oa.SOFTMAX_MAPPING[key].spec), (x64,), atol=1e-7)
+    # the host logic of the route (module -> unfused_core -> SoftmaxFn -> gate_autograd) against the REFERENCE's gradients, with the
+    # device check lifted for this test only (the torch ops are device-agnostic; on the GPU box tests/test_modules_gpu.py runs it for real)
+    real = ops._need_gpu
+    monkeypatch.setattr(ops, "_need_gpu", lambda *ts, allow_grad=False: real(*ts, allow_grad=allow_grad) if not allow_grad else None)
+    for cj in g["cases_json"]:
+        case = json.loads(str(cj))
+        la, lb, x, z = run_train_toy(g, case, "cpu")
+        check_train_toy(g, case, la, lb, x, z, rtol=2e-4, atol=2e-6)
+

@@ -390,13 +390,20 @@ def test_fused_qkv_projection_matches_three_linears(oa):
         finally:
             attention.FUSE_QKV = True
         assert torch.allclose(a, b, atol=2e-3, rtol=2e-3) and not torch.allclose(a, outs[True], atol=1e-4)
-    # with autograd recording, the forward-only library refuses instead of silently dropping the gradients of q/k/v
-    # (the fused path returned a tensor without grad_fn in train mode whenever attention dropout was 0)
+    # with autograd recording the module takes the differentiable torch-op path (round 5; it raised before) - never the forward-only
+    # kernels, whose output would carry no grad_fn - and a DIRECT op call with such inputs still refuses
     from outeffhop_amd._lib import OehError
 
     m.train()
+    for p_ in m.parameters():
+        p_.requires_grad_(True)
+    with torch.no_grad():
+        want = m(x, attention_mask=mask)[0].float()
+    got = m(x, attention_mask=mask)[0]
+    assert got.grad_fn is not None and torch.allclose(got.float(), want, atol=2e-3, rtol=2e-3)
+    q = torch.randn(1, 2, 32, 64, device="cuda", dtype=torch.float16, requires_grad=True)
     with pytest.raises(OehError, match="forward-only"):
-        m(x, attention_mask=mask)
+        oa.ops.attn_fwd(q, q, q)
     with torch.no_grad():
         assert torch.isfinite(m(x, attention_mask=mask)[0]).all()
 
@@ -822,3 +829,23 @@ def test_int8_storage_core_yields_to_forward_hooks(oa):
     assert fired, "the hook on `key` never fired: the fast path bypassed the module forward"
     step = float(qm.context_act_quantizer.activation_quantizer.quantizer.delta)
     assert float((plain - hooked).abs().max()) <= 1.05 * step
+
+
+def test_training_backpropagates_through_the_torch_op_path(oa):
+    """under the reference's training swap-in (run_clm.py:214-233, run_mlm.py:200-219: modules in train() mode,
+    autograd recording) the forward falls back to differentiable torch ops on the GPU instead of raising.  A two-layer toy
+    y = x + OPT(x), z = BERT(y), loss = sum(w z) against the forward value and the gradients (input and EVERY parameter: projections,
+    gate predictors, the unconditional gate's alpha) captured from the reference (tests/golden/train_grads.npz); inference on the same
+    modules keeps the HIP kernels."""
+    from tests.test_host_cpu import check_train_toy, run_train_toy
+
+    g = load_golden("train_grads.npz")
+    for cj in g["cases_json"]:
+        case = json.loads(str(cj))
+        la, lb, x, z = run_train_toy(g, case, "cuda")
+        check_train_toy(g, case, la, lb, x, z, rtol=1e-3, atol=2e-5)  # fp32 rocBLAS / ATen against the reference's CPU fp32
+        la.eval(), lb.eval()
+        with torch.no_grad():  # the same modules in inference: the fused kernels (fp32 storage: operand pairs, 5e-4)
+            y = x.detach() + la(x.detach(), attention_mask=torch.from_numpy(g["opt_mask"]).cuda())[0]
+            z2 = lb(y, attention_mask=torch.from_numpy(g["bert_mask"]).cuda())[0]
+        _close(z2, g[f"{case['name']}.z"], case["name"] + " inference after training", dict(atol=2e-3, rtol=2e-3))
