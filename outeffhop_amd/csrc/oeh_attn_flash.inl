@@ -25,6 +25,14 @@
 #pragma once
 #include "oeh_attn_fast.inl"
 
+// Knock-out ladder of the one-pass kernel (diagnostic builds only: make -C outeffhop_amd/csrc knockout KO=n; profiles/r05_headline_floor.txt).
+// 0 (production): everything.  1: return at entry.  2: + the prologue and the whole LDS-DMA stream with its waits and barriers, nothing else.
+// 3: + both products' MFMAs and their LDS fragment reads (the second product on the raw bits of the scores).  4: + the softmax arithmetic (the full
+// tile).  2 - 4 skip the epilogue (its stores sit behind a never-true test of an accumulator, so that nothing above is dead code).
+#ifndef OEH_KO
+#define OEH_KO 0
+#endif
+
 #include <type_traits>
 
 namespace oeh {
@@ -102,6 +110,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   if (SRC32 && P.head_major) block_to_tile(bid, P.nBHpad, P.nQT, P.head_major, qt_rev, bh);
   else div_magic((unsigned)bid, (unsigned)P.nBHpad, P.magic_nbh, qt_rev, bh);
   if (bh >= P.nBH) return;
+#if OEH_KO == 1
+  return;
+#endif
   int b, h;
   div_magic((unsigned)bh, (unsigned)P.H, P.magic_h, b, h);
 
@@ -444,6 +455,16 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     constexpr int J0 = decltype(j0c)::value;
     constexpr bool FIRST = decltype(firstc)::value;  // tile 0: V tile 0 is awaited between the two products
     constexpr int MODE = decltype(modec)::value;
+#if OEH_KO == 2
+    if constexpr (FIRST) {
+      if (!GATE && 1 < n_kt) wait_vm(std::integral_constant<int, 2>{});
+      else wait_vm(std::integral_constant<int, 0>{});
+      barrier_mem();
+      if (GATE && 1 < n_kt) issue_next();
+      if (2 < n_kt) issue_next();
+    }
+    return;
+#endif
     // S^T = K Q^T; every K fragment is read once and used by all active blocks
     __builtin_amdgcn_s_setprio(1);  // matrix-core phases at a higher issue priority than the other waves' softmax arithmetic (dense S=512: -2.7 %)
     f4 s[MQ][4];
@@ -472,6 +493,13 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       }
     }
     __builtin_amdgcn_s_setprio(0);
+    u4 pb[MQ][2];
+#if OEH_KO == 3
+#pragma unroll
+    for (int j = J0; j < MQ; ++j)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) pb[j][u] = u4{f32_bits(s[j][2 * u][0]), f32_bits(s[j][2 * u][1]), f32_bits(s[j][2 * u + 1][0]), f32_bits(s[j][2 * u + 1][1])};
+#else
     // exponent arguments t = (s - reference) * log2e  [key padding: BERT order scale*s + pad first]
     f4 padflag[(has_pad && MODE >= 3) ? 4 : 1];  // the grid chain with key padding (key_pad_boolean): +big for a visible key, the sentinel for a padded one
     if constexpr (has_pad) {
@@ -549,7 +577,6 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     }
     // online softmax per block, P^T packed for the second product
     const float thr = (i == 0) ? -1.0e20f : kThr;
-    u4 pb[MQ][2];
 #pragma unroll
     for (int j = J0; j < MQ; ++j) {
       if constexpr (MODE == 3) {  // statistics of the grid chain, per lane
@@ -685,6 +712,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
         else pb[j][u] = u4{pack2_f16(a[0], a[1]), pack2_f16(a[2], a[3]), pack2_f16(bb[0], bb[1]), pack2_f16(bb[2], bb[3])};
       }
     }
+#endif  // OEH_KO == 3
     if constexpr (FIRST) {
       // V tile 0 landed for every wave (stage 1 may still be in flight); every wave has its Q operands, so the Q stage
       // can now be refilled with stage 2
@@ -839,6 +867,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   // last reader was tile n_kt - 3 and no DMA is in flight.  Each wave owns 16*MQ rows of it: no workgroup barrier.
   // (lane-derived addresses come from an opaque copy of the lane id: formed here, not kept live across the loop where
   // the MQ=2 variant has no register to spare)
+#if OEH_KO >= 2 && OEH_KO <= 4
+  if (!(o[0][0][0] == 1.2345e-31f && lacc[0][1] == 5.4321e-30f)) return;  // (never true: the accumulators stay live, the epilogue does not run)
+#endif
   constexpr int XM = (CPR < 8 ? CPR : 8) - 1;
   unsigned char* ebase = lds + (n_kt % R) * STAGEB + wave * (16 * MQ * ROWB);
   int lane_e = lane;

@@ -1,11 +1,8 @@
-// Instantiates the fused attention kernels for head dim 64: the general kernel (oeh_attn_mfma.inl: NT in {8,16,32} x
-// {f16,bf16,f32 storage} x {plain, fake-quant}) the full-row 16-bit kernel (oeh_attn_fast.inl: NT x {f16,bf16} x {clip}) and the
-// one-pass 16-bit kernel (oeh_attn_flash.inl: {f16,bf16} x MQ).
-// One translation unit per head dim keeps the build parallel.
-#include "oeh_attn_flash.inl"
+// Head dim 64, the GENERAL kernel (oeh_attn_mfma.inl: NT in {8,16,32} x {f16, bf16, f32 storage} x {plain, fake-quant}).
+// One translation unit per head dim AND kernel family (round 5; one per head dim before): nine units of similar weight build in parallel,
+// and an edit to one family's .inl no longer recompiles the other two.
+#include "oeh_attn_mfma.inl"
 
 namespace oeh {
 int launch_attn_mfma_d64(const AttnParams& P, int in, bool fq, hipStream_t st) { return launch_d<64>(P, in, fq, st); }
-int launch_attn_fast_d64(const AttnParams& P, int in, hipStream_t st) { return launch_fast_d<64>(P, in, st); }
-int launch_attn_flash_d64(const AttnParams& P, int in, int mq, hipStream_t st) { return launch_flash_d<64>(P, in, mq, st); }
 }  // namespace oeh

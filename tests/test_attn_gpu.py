@@ -49,10 +49,12 @@ def _np32(t):
     return t.detach().float().cpu().numpy()
 
 
-def _le(value, limit, what):
+def _le(value, limit, what, n=None):
     """`value <= limit` with the margin on record: OEH_TEST_REPORT=<file> appends "what value limit" per call - how the shares below were
     set in round 5 (bounds ~500x looser than what the kernels deliver let a 0.1 % regression pass): measured on the
     GPU box, then a bound a small factor above the measurement, never below one element of the smallest tensor."""
+    if n is not None:  # a share of n elements: two of them may always differ (a tensor of 1 152 outputs has no share below 8.7e-4)
+        limit = max(float(limit), 2.0 / float(n))
     rep = os.environ.get("OEH_TEST_REPORT")
     if rep:
         with open(rep, "a") as f:
@@ -276,11 +278,11 @@ def test_int8_fused(ops, order, sm, S):
     got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=fq, **args)
     for name, dump in (("scores", dump_s), ("probs", dump_p), ("ctx", dump_c)):
         mx, rate = _flip_stats(dump.cpu().numpy(), ex[f"{name}_idx"])
-        assert mx <= 1 and _le(rate, FLIP_RATE, f"int8_fused[{order},{sm},{S}] {name} flip rate"), f"{name}: max index diff {mx}, flip rate {rate:.2e}"
+        assert mx <= 1 and _le(rate, FLIP_RATE, f"int8_fused[{order},{sm},{S}] {name} flip rate", n=dump.numel()), f"{name}: max index diff {mx}, flip rate {rate:.2e}"
     step = float(np.float32(d_c[0])) * float(gate.max())
     err = np.abs(_np32(got) - want)
     flipped = err > 1e-3 + 1e-3 * np.abs(want)
-    assert _le(flipped.mean(), OUT_OFF, f"int8_fused[{order},{sm},{S}] outputs off") and err.max() <= 1.05 * step + 2e-3, f"out: {flipped.mean():.2e} elements off, max err {err.max():.3e} (step {step:.3e})"
+    assert _le(flipped.mean(), OUT_OFF, f"int8_fused[{order},{sm},{S}] outputs off", n=flipped.size) and err.max() <= 1.05 * step + 2e-3, f"out: {flipped.mean():.2e} elements off, max err {err.max():.3e} (step {step:.3e})"
     # production form (no dumps -> causal tile skipping allowed) gives the same bits
     fq2 = ops.AttnFakeQuant(FQ(*d_s), FQ(*d_p), FQ(*d_c), ctx_before_gate=before)
     got2 = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=fq2, **args)
@@ -463,7 +465,7 @@ def test_int8_chain_on_long_rows_two_pass(ops, dt, order):
     step = float(np.float32(d_c[0])) * (float(gate.max()) if opt else 1.0)
     err = np.abs(_np32(got) - want)
     flipped = err > 1e-3 + 1e-3 * np.abs(want)
-    assert _le(flipped.mean(), OUT_OFF, "fq2p outputs off") and err.max() <= 1.05 * step + 2e-3, f"out: {flipped.mean():.2e} elements off, max err {err.max():.3e} (step {step:.3e})"
+    assert _le(flipped.mean(), OUT_OFF, "fq2p outputs off", n=flipped.size) and err.max() <= 1.05 * step + 2e-3, f"out: {flipped.mean():.2e} elements off, max err {err.max():.3e} (step {step:.3e})"
     # 512 keys: the full-row kernel's result against the two-pass form forced over the same problem
     q5, k5, v5, g5 = q[:, :, :512].cuda(), k[:, :, :512].cuda(), v[:, :, :512].cuda(), gate[:, :, :512].cuda()
     a = ops.attn_fwd(q5, k5, v5, fq=fq, **{**args, "gate": g5})
@@ -473,7 +475,7 @@ def test_int8_chain_on_long_rows_two_pass(ops, dt, order):
     finally:
         lib.oeh_debug_set_variant(0, 0)
     d = (a.float() - b.float()).abs()
-    assert float(d.max()) <= 1.05 * step + 2e-3 and _le(float((d > 1e-3).float().mean()), OUT_OFF, "fq2p vs full-row outputs apart"), (float(d.max()), float((d > 1e-3).float().mean()))
+    assert float(d.max()) <= 1.05 * step + 2e-3 and _le(float((d > 1e-3).float().mean()), OUT_OFF, "fq2p vs full-row outputs apart", n=d.numel()), (float(d.max()), float((d > 1e-3).float().mean()))
 
 
 def test_snake_block_order_changes_nothing_but_the_placement(ops):
@@ -1423,7 +1425,7 @@ def test_int8_storage_randomised_sweep(ops):
         d = (got.float() - ref).abs()
         lim = tol + tol * ref.abs()
         frac_off = float((d > lim).float().mean())
-        assert float(d.max()) <= 1.05 * step + float(lim.max()) and _le(frac_off, OUT_OFF, f"i8 storage case {n} outputs off"), \
+        assert float(d.max()) <= 1.05 * step + float(lim.max()) and _le(frac_off, OUT_OFF, f"i8 storage case {n} outputs off", n=d.numel()), \
             f"case {n} {(B, H, Sq, Sk, causal, base, out_dtype)}: max diff {float(d.max()):.3e} (step {step:.3e}), {frac_off:.2e} off"
 
 
@@ -1588,9 +1590,9 @@ def test_int8_grid_chain_with_key_padding(ops, order, base, S, dt):
     for name, got in (("grid", grid), ("literal", literal)):
         err = np.abs(_np32(got) - want)
         off = float((err > 0.5 * step).mean())
-        assert np.isfinite(_np32(got)).all() and _le(off, OUT_OFF, f"grid-vs-literal {name} outputs off") and err.max() <= 2.05 * step + 2e-3, f"{name}: {off:.2e} off, max {err.max() / step:.2f} steps"
+        assert np.isfinite(_np32(got)).all() and _le(off, OUT_OFF, f"grid-vs-literal {name} outputs off", n=err.size) and err.max() <= 2.05 * step + 2e-3, f"{name}: {off:.2e} off, max {err.max() / step:.2f} steps"
     d = (grid.float() - literal.float()).abs()
-    assert _le(float((d > 0.5 * step).float().mean()), OUT_OFF, "grid vs literal apart") and float(d.max()) <= 2.05 * step + 2e-3
+    assert _le(float((d > 0.5 * step).float().mean()), OUT_OFF, "grid vs literal apart", n=d.numel()) and float(d.max()) <= 2.05 * step + 2e-3
     if base == 1:
         assert float(grid[3].abs().max()) <= abs(float(np.float32(d_c[0])) * 0.51) + abs(want[3]).max()  # the sample without a visible key
 
@@ -1639,7 +1641,7 @@ def test_long_rows_with_key_padding_two_pass(ops, order, kind, dt):
     step = float(np.float32(d_c[0]))
     err = np.abs(_np32(got) - want)
     off = float((err > 0.5 * step).mean())
-    assert np.isfinite(_np32(got)).all() and _le(off, OUT_OFF, "fused chain outputs off") and err.max() <= 2.05 * step + 2e-3, f"{off:.2e} off, max {err.max() / step:.2f} steps"
+    assert np.isfinite(_np32(got)).all() and _le(off, OUT_OFF, "fused chain outputs off", n=err.size) and err.max() <= 2.05 * step + 2e-3, f"{off:.2e} off, max {err.max() / step:.2f} steps"
 
 
 @pytest.mark.gpu
@@ -1771,7 +1773,7 @@ def test_clipped_int8_chain_on_the_quantiser_grid(ops, S, dt, pad):
     step = float(np.float32(d_c[0]))
     err = np.abs(_np32(got) - want)
     off = float((err > 0.5 * step).mean())
-    assert np.isfinite(_np32(got)).all() and _le(off, OUT_OFF, "fused chain outputs off") and err.max() <= 2.05 * step + 2e-3, f"{off:.2e} off, max {err.max() / step:.2f} steps"
+    assert np.isfinite(_np32(got)).all() and _le(off, OUT_OFF, "fused chain outputs off", n=err.size) and err.max() <= 2.05 * step + 2e-3, f"{off:.2e} off, max {err.max() / step:.2f} steps"
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -1827,7 +1829,7 @@ def test_padding_masks_of_exactly_minus_1e4_hide_their_keys(ops, path):
     step = float(np.float32(d_c[0]))
     err = np.abs(_np32(got_hf) - want)
     off = float((err > 0.5 * step + 1e-3).mean())
-    assert err.max() <= 2.05 * step + 2e-3 and _le(off, OUT_OFF, f"{path} outputs off"), f"{path}: max {err.max() / step:.2f} steps, {off:.2e} off (padded keys attending?)"
+    assert err.max() <= 2.05 * step + 2e-3 and _le(off, OUT_OFF, f"{path} outputs off", n=err.size), f"{path}: max {err.max() / step:.2f} steps, {off:.2e} off (padded keys attending?)"
 
 
 @pytest.mark.gpu
@@ -2065,7 +2067,7 @@ def test_both_sides_of_every_dispatch_rule_meet_the_contract(ops, rule):
         if int8:
             step = float(np.float32(d_c[0]))
             err = np.abs(_np32(got) - want)
-            assert err.max() <= 2.05 * step + 2e-3 and _le(float((err > 0.5 * step + 1e-3).mean()), OUT_OFF, f"{rule} {name} outputs off"), f"{rule} {name}: {err.max() / step:.2f} steps"
+            assert err.max() <= 2.05 * step + 2e-3 and _le(float((err > 0.5 * step + 1e-3).mean()), OUT_OFF, f"{rule} {name} outputs off", n=err.size), f"{rule} {name}: {err.max() / step:.2f} steps"
         elif dt == torch.float32:
             _check(got, want, tol=dict(atol=5e-4, rtol=5e-4), msg=f"{rule} {name}")
         else:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Registers / spills / LDS of every kernel in the built objects (code-object metadata):
     python tools/kernel_resources.py [substring ...]   # e.g. fast_kernelILi32ELi64
-Reads outeffhop_amd/lib/liboeh_hip.so (make -C outeffhop_amd/csrc)."""
+Reads outeffhop_amd/lib/liboeh_hip.so (make -C outeffhop_amd/csrc), or the build named by OEH_LIB (an experiment build: make ... alt NAME=...)."""
 import glob
 import os
 import re
@@ -19,7 +19,7 @@ def main():
     tmp = tempfile.mkdtemp()
     try:
         lib = os.path.join(tmp, "lib.so")
-        shutil.copy(os.path.join(ROOT, "outeffhop_amd", "lib", "liboeh_hip.so"), lib)
+        shutil.copy(os.environ.get("OEH_LIB") or os.path.join(ROOT, "outeffhop_amd", "lib", "liboeh_hip.so"), lib)
         subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", lib], check=True, capture_output=True, cwd=tmp)  # writes lib.so.N.hipv4-...gfx950
         for co in sorted(glob.glob(lib + ".*gfx950")):
             txt = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
