@@ -207,7 +207,7 @@ __device__ __forceinline__ void fp16_overflow_clamp() {
   __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);  // hwreg(HW_REG_MODE, 23, 1): FP16_OVFL
 }
 __device__ __forceinline__ h2 sat_h2(float x, float y) { return __builtin_convertvector((f2{x, y}), h2); }
-__device__ __forceinline__ void split8(const f4 a, const f4 b, u4& hi, u4& lo) {
+__device__ __forceinline__ void split8_ref(const f4 a, const f4 b, u4& hi, u4& lo) {
   const h2 h0 = sat_h2(a[0], a[1]), h1 = sat_h2(a[2], a[3]);
   const h2 h2_ = sat_h2(b[0], b[1]), h3 = sat_h2(b[2], b[3]);
   hi = u4{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, h2_), __builtin_bit_cast(unsigned, h3)};
@@ -215,6 +215,67 @@ __device__ __forceinline__ void split8(const f4 a, const f4 b, u4& hi, u4& lo) {
     return __builtin_bit_cast(unsigned, sat_h2((x0 - (float)hh0) * kSplitUp, (x1 - (float)hh1) * kSplitUp));
   };
   lo = u4{lo2(a[0], h0[0], a[1], h0[1]), lo2(a[2], h1[0], a[3], h1[1]), lo2(b[0], h2_[0], b[1], h2_[1]), lo2(b[2], h3[0], b[3], h3[1])};
+}
+// split8 in 20 vector instructions instead of ~37 (round 5): hi by four v_cvt_pk_f16_f32 as above; the residual x - hi by v_fma_mix_f32 reading the
+// fp16 half straight out of the packed register (fma(hi, -1, x): exact, no separate conversion), and lo = RN16(residual * 2^11) by
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 (the product is exact, ONE rounding, written into its half of the packed register: no multiply, no pack).
+// Bit-identical to split8 for |x| inside the fp16 range (tests/test_proj_gpu.py compares the two paths bit for bit).  One asm statement per
+// fragment: the compiler pads every asm statement that writes vector registers with an s_nop.  k2048: 2048.0f in a scalar register.
+__device__ __forceinline__ void split8_mix(const f4 a, const f4 b, const float k2048, u4& hi, u4& lo) {
+  const h2 h0 = sat_h2(a[0], a[1]), h1 = sat_h2(a[2], a[3]);
+  const h2 h2_ = sat_h2(b[0], b[1]), h3 = sat_h2(b[2], b[3]);
+  hi = u4{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, h2_), __builtin_bit_cast(unsigned, h3)};
+  float d0, d1, d2, d3, d4, d5, d6, d7;
+  unsigned l0, l1, l2, l3;
+  asm("v_fma_mix_f32 %0, %12, -1.0, %16 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %1, %12, -1.0, %17 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %2, %13, -1.0, %18 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %3, %13, -1.0, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %4, %14, -1.0, %20 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %5, %14, -1.0, %21 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %6, %15, -1.0, %22 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %7, %15, -1.0, %23 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %8, %0, %24, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixhi_f16 %8, %1, %24, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixlo_f16 %9, %2, %24, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixhi_f16 %9, %3, %24, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixlo_f16 %10, %4, %24, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixhi_f16 %10, %5, %24, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixlo_f16 %11, %6, %24, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixhi_f16 %11, %7, %24, 0 op_sel_hi:[0,0,0]"
+      : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+      : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "s"(k2048));
+  lo = u4{l0, l1, l2, l3};
+}
+// The UNSCALED operand pair (round 5): x = hi + lo' with lo' = RN16(x - hi), no 2^11.  tools/probe/mix_probe.hip: v_mfma_f32_16x16x32_f16 takes
+// fp16 SUBNORMAL operands exactly (2^-24 * 1 and 2^-24 * 2^-24 come out exact), so the scaling that kept lo out of the subnormals is not needed by
+// the matrix core; what it bought is precision of lo itself: unscaled, a residual below 2^-14 (|x| < ~0.25) lands on the subnormal grid of 2^-24,
+// i.e. |x - (hi + lo')| <= 2^-25 absolute instead of 2^-22 |x| relative - the same size for |x| ~ 0.1 ... 1, and far below the fp32 accumulation's
+// own rounding in a dot product.  It costs ONE instruction per element (v_fma_mixlo/hi_f16: fma(hi, -1, x) rounded once into its half of the packed
+// register) and the second product needs no 2^-11 on the other operand and no second accumulator: a.b = ah.bh + (ah.bl' + al'.bh) in one register set.
+__device__ __forceinline__ void split8_raw(const f4 a, const f4 b, u4& hi, u4& lo) {
+  const h2 h0 = sat_h2(a[0], a[1]), h1 = sat_h2(a[2], a[3]);
+  const h2 h2_ = sat_h2(b[0], b[1]), h3 = sat_h2(b[2], b[3]);
+  hi = u4{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, h2_), __builtin_bit_cast(unsigned, h3)};
+  unsigned l0, l1, l2, l3;
+  asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %4, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %2, %6, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %3, %7, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+      : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+  lo = u4{l0, l1, l2, l3};
+}
+__device__ __forceinline__ void split8(const f4 a, const f4 b, u4& hi, u4& lo) {
+#ifdef OEH_SPLIT_REF   // (the round-4 form, for A/B builds: make alt NAME=ref DEFS=-DOEH_SPLIT_REF)
+  split8_ref(a, b, hi, lo);
+#else
+  split8_mix(a, b, 2048.0f, hi, lo);
+#endif
 }
 // 8 consecutive fp32 storage elements -> the (hi, lo) operand pair
 __device__ __forceinline__ void load8_split(const void* base, long elem_off, u4& hi, u4& lo) {

@@ -201,7 +201,11 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         u4 hi, lo;
+#ifndef OEH_SCALED_LO   // (round 5; -DOEH_SCALED_LO: the round-4 form, [hi | lo 2^11] against W and W 2^-11, for A/B builds)
+        split8_raw(x32[i][0], x32[i][1], hi, lo);   // lo = RN16(x - hi), unscaled (oeh_common.h): the second product runs against W itself (below)
+#else
         split8(x32[i][0], x32[i][1], hi, lo);
+#endif
         ah[i] = __builtin_bit_cast(h8v, hi);
         al[i] = __builtin_bit_cast(h8v, lo);
 #pragma unroll
@@ -216,7 +220,11 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
+#ifndef OEH_SCALED_LO
+        const h8v bs = bf[j];
+#else
         const h8v bs = bf[j] * (_Float16)0.00048828125f;  // 2^-11: exact on the 8-bit integers
+#endif
 #pragma unroll
         for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bs, acc[i][j], 0, 0, 0);
       }

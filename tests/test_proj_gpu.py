@@ -40,6 +40,7 @@ def test_pair_gemm_with_quantiser_epilogue_vs_exact_arithmetic(B, S, H, K, want)
     vals = [ref64[:, n * E:(n + 1) * E] * alphas[n] + bias[n * E:(n + 1) * E].double() for n in range(3)]
     specs = [ops.FakeQuantSpec(*_grid(v)) for v in vals]
     new = ops.proj_quant_i8(pairs, wi, bias, B, S, [(alphas[n], specs[n], n == 2, n > 0 and want) for n in range(3)], pairs=True)
+    new32 = ops.proj_quant_i8(x.view(M, K), wi, bias, B, S, [(alphas[n], specs[n], n == 2, n > 0 and want) for n in range(3)], pairs=True)
     ww3 = torch.cat([wi, wi * 2.0 ** -11], dim=1).t().contiguous()
     acc3 = torch.mm(pairs, ww3, out_dtype=torch.float32).view(B, S, 3 * E)
     for n in range(3):
@@ -53,6 +54,12 @@ def test_pair_gemm_with_quantiser_epilogue_vs_exact_arithmetic(B, S, H, K, want)
         rate, rate_old = float((d != 0).float().mean()), float((d_old != 0).float().mean())
         print(f"B={B} S={S} H={H} K={K} [{'qkv'[n]}]: index != exact {rate:.1e} (library GEMM + quantiser pass: {rate_old:.1e}), max {int(d.max())} step")
         assert int(d.max()) <= 1 and rate <= max(3e-5, 3.0 * rate_old)
+        # ... and from the fp32 activations themselves (the modules' path; round 5: the residual operand unscaled, oeh_common.h: split8_raw): the same bar
+        got32 = (new32[n][0] if (n > 0 and want) else new32[n]).contiguous().to(torch.int32)
+        d32 = (got32 - ex).abs()
+        rate32 = float((d32 != 0).float().mean())
+        print(f"   from the fp32 activations: index != exact {rate32:.1e}, max {int(d32.max())} step")
+        assert int(d32.max()) <= 1 and rate32 <= max(3e-5, 3.0 * rate_old)
         if y is not None:
             rows = got.permute(0, 1, 3, 2) if n == 2 else got          # (B, H, S, 64)
             want_y = np.float32(specs[n].scale) * (rows.permute(0, 2, 1, 3).reshape(B, S, E).float() + 128.0 - specs[n].zero_point)
@@ -136,9 +143,12 @@ def test_projection_gemm_random_shapes_against_the_library_path():
 
 @pytest.mark.parametrize("B,S,H,K", [(16, 512, 12, 768), (4, 128, 12, 768), (3, 48, 2, 64), (5, 80, 12, 768)])
 def test_fp32_activations_split_inside_the_kernel_equal_the_operand_pairs(B, S, H, K):
-    """`a` as the fp32 activation matrix (the (hi, lo) split at fragment-read time, oeh_common.h: split8) against the same call on
-    `oeh_split_pairs`' output: the same operands in the same accumulation order - bit-identical indices and values, values beyond the
-    fp16 range included (both saturate)."""
+    """`a` as the fp32 activation matrix (split into fp16 operands when a wave reads its fragments) against the same call on `oeh_split_pairs`'
+    output.  Round 5: the in-kernel split keeps the residual UNSCALED (oeh_common.h: split8_raw - the matrix core takes fp16 subnormals exactly,
+    tools/probe/mix_probe.hip), `oeh_split_pairs` keeps its documented [hi | lo 2^11] format: the two represent x to 2^-25 absolute / 2^-22 relative
+    respectively, so an index may differ where a value sits on a rounding boundary to within that - never by more than one step, in at most 2e-5 of
+    the outputs (measured ~1e-6; rounds 1-4: bit-identical, with both paths on the scaled pair).  Values beyond the fp16 range: the pair format
+    saturates at 65504 (+ 32), the unscaled residual carries them exactly up to twice that - both finite; those rows are compared for finiteness only."""
     from outeffhop_amd import ops
 
     torch.manual_seed(11 + S)
@@ -153,7 +163,26 @@ def test_fp32_activations_split_inside_the_kernel_equal_the_operand_pairs(B, S, 
     flat = lambda r: [t_ for o in r for t_ in (o if isinstance(o, tuple) else (o,))]  # noqa: E731
     a = flat(ops.proj_quant_i8(ops.split_pairs(x), wi, bias, B, S, segs, pairs=True))
     b = flat(ops.proj_quant_i8(x, wi, bias, B, S, segs, pairs=True))
-    assert len(a) == len(b) == 5 and all(torch.equal(p_, q_) for p_, q_ in zip(a, b))
+    assert len(a) == len(b) == 5
+    steps = [1.0, 1.0, 0.035, 1.0, 0.03]   # q idx | k idx, k values | v idx (transposed), v values
+    for n, (p_, q_) in enumerate(zip(a, b)):
+        assert p_.shape == q_.shape and p_.dtype == q_.dtype
+        if p_.dtype != torch.int8:
+            assert torch.isfinite(q_).all()
+        if n == 3:   # v indices, (B, H, 64, S): token rows 0 and 1 of batch 0 are columns 0 and 1 of every head's tile
+            pm, qm = p_[0, :, :, 2:].float(), q_[0, :, :, 2:].float()
+            rest = (p_[1:].float(), q_[1:].float()) if B > 1 else None
+        else:        # (B, S, E) row-major views: drop rows 0 and 1 of batch 0
+            pv = p_.permute(0, 2, 1, 3).reshape(B, S, E) if p_.dim() == 4 else p_.reshape(B, S, E)
+            qv = q_.permute(0, 2, 1, 3).reshape(B, S, E) if q_.dim() == 4 else q_.reshape(B, S, E)
+            pm, qm = pv[0, 2:].float(), qv[0, 2:].float()
+            rest = (pv[1:].float(), qv[1:].float()) if B > 1 else None
+        d = (pm - qm).abs()
+        cnt, tot, worst = int((d > 0).sum()), d.numel(), float(d.max()) if d.numel() else 0.0
+        if rest is not None:
+            d2 = (rest[0] - rest[1]).abs()
+            cnt, tot, worst = cnt + int((d2 > 0).sum()), tot + d2.numel(), max(worst, float(d2.max()))
+        assert worst <= steps[n] * 1.0001 and cnt <= max(2, 2e-5 * tot), f"output {n}: {cnt} of {tot} differ, max {worst / steps[n]:.2f} steps"
 
 
 @pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (400, 128, 64), (4096, 768, 768), (48, 64, 128)])
