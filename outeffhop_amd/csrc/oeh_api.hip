@@ -423,6 +423,7 @@ int oeh_attn_fwd(const oeh_attn_desc* desc, const void* q, const void* k, const 
     if ((var != V_FAST && var != V_FLASH) || desc->gate_units > 64 || (desc->dtype == OEH_F32 && var != V_FAST)) return OEH_ENOTSUP;
     const int geb = desc->dtype == OEH_F32 ? 4 : 2;
     if (((reinterpret_cast<uintptr_t>(desc->gate_hidden) | (uintptr_t)(desc->gate_hidden_stride[0] * geb) | (uintptr_t)(desc->gate_hidden_stride[1] * geb)) & 15) != 0) return OEH_EALIGN;
+    if (desc->gate_hidden_stride[1] <= 0 || desc->gate_hidden_stride[1] >= (1 << 24)) return OEH_ENOTSUP;  // (32-bit lane offsets of the input rows' LDS-DMA)
   }
   AttnParams P;
   fill_params(P, desc, q, k, v, o, fq);

@@ -138,39 +138,47 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
   const int prow = lane / CPR, pch = lane % CPR;
   const unsigned lds_base = lds_offset(lds);
   auto piece_row = [&](int j) { return (wave * G + j) * RPP + prow; };
-  auto k_lane_off = [&](int j) { const int row = piece_row(j); return (long)row * P.ks_s + (pch ^ swz_k<D>(row)) * 8; };
-  auto v_lane_off = [&](int j) { const int row = piece_row(j); return (long)row * P.vs_s + ((((pch >> 1) ^ swz_v<D>(row)) << 1) | (pch & 1)) * 8; };
-  // The K-then-V tile stream is issued strictly in order by `issue_next()`; its position (tile, ring slot, per-lane
-  // source offsets) is carried incrementally - no multiply / modulo per tile.
-  const long kstep = 64 * P.ks_s, vstep = 64 * P.vs_s;
+  // The K-then-V tile stream is issued strictly in order by `issue_next()`.  Round 5 (from the disassembly: every request cost ~12 vector
+  // instructions of 64-bit per-lane address arithmetic - v_mad_u64_u32, v_lshl_add_u64, exec masking for the ragged rows - a fifth of the
+  // clipped kernel's vector instructions): the scalar-base form the one-pass kernel has had since round 3.  A request is a wave-uniform
+  // 64-bit base in scalar registers (it advances by 64 rows per tile) + a CONSTANT 32-bit byte offset per lane (row of the piece, swizzled
+  // 16-B chunk; oeh_api.hip: fast_eligible bounds the row strides), two constant sets: K and V.  Only the ragged last tile adjusts offsets.
+  unsigned noff[G], voff[G];   // the stream's current offsets (K first), and V's for the switch
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    const int row = piece_row(j);
+    noff[j] = 2u * (unsigned)(row * (int)P.ks_s + (pch ^ swz_k<D>(row)) * 8);
+    voff[j] = 2u * (unsigned)(row * (int)P.vs_s + ((((pch >> 1) ^ swz_v<D>(row)) << 1) | (pch & 1)) * 8);
+  }
+  const unsigned char* ncur = reinterpret_cast<const unsigned char*>(kbase);
+  long nstep = 128 * P.ks_s;      // bytes per 64 rows
+  int nrow2 = 2 * (int)P.ks_s;    // bytes per row (the ragged tile's redirection)
   int nx_tile = 0, nx_slot = 0;
   bool nx_isv = false;
-  long nx_off[G];
-#pragma unroll
-  for (int j = 0; j < G; ++j) nx_off[j] = k_lane_off(j);
   auto issue_next = [&]() {
     const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(((nx_isv ? R : 0) + nx_slot) * TILEB + wave * G * 1024));
-    const unsigned short* base = nx_isv ? vbase : kbase;
-    const long srow = nx_isv ? P.vs_s : P.ks_s;
-    const bool tail = nx_tile * 64 + 64 > P.Sk;  // wave-uniform; rows past Sk are redirected to row Sk-1
+    if (nx_tile * 64 + 64 > P.Sk) {  // wave-uniform: the ragged last tile - rows past Sk are redirected to row Sk-1 (finite data, masked later)
 #pragma unroll
-    for (int j = 0; j < G; ++j) {
-      long off = nx_off[j];
-      if (tail) {
+      for (int j = 0; j < G; ++j) {
         const int over = nx_tile * 64 + piece_row(j) - (P.Sk - 1);
-        if (over > 0) off -= (long)over * srow;
+        glds16_s(ncur, noff[j] - (over > 0 ? (unsigned)(over * nrow2) : 0u), slot + j * 1024);
       }
-      glds16(base + off, slot + j * 1024);
-      nx_off[j] += nx_isv ? vstep : kstep;
+    } else {
+#pragma unroll
+      for (int j = 0; j < G; ++j) glds16_s(ncur, noff[j], slot + j * 1024);
     }
+    ncur += nstep;
     ++nx_tile;
     nx_slot = (nx_slot == R - 1) ? 0 : nx_slot + 1;
     if (!nx_isv && nx_tile == n_kt) {  // K exhausted: continue with V tile 0 in the V ring
       nx_isv = true;
       nx_tile = 0;
       nx_slot = 0;
+      ncur = reinterpret_cast<const unsigned char*>(vbase);
+      nstep = 128 * P.vs_s;
+      nrow2 = 2 * (int)P.vs_s;
 #pragma unroll
-      for (int j = 0; j < G; ++j) nx_off[j] = v_lane_off(j);
+      for (int j = 0; j < G; ++j) noff[j] = voff[j];
     }
   };
 
@@ -235,7 +243,8 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
       const int row = piece_row(j);
       int qr = qt * 64 + row;
       qr = qr < P.Sq ? qr : P.Sq - 1;  // rows past Sq: finite data, never stored
-      glds16(qbase + (long)qr * P.qs_s + (pch ^ swz_k<D>(row)) * 8, qslot + j * 1024);
+      // (scalar base = the q tile's first row, lane offset = the row inside the tile: 32 bits whatever Sq)
+      glds16_s(qbase + (long)qt * 64 * P.qs_s, 2u * (unsigned)((qr - qt * 64) * (int)P.qs_s + (pch ^ swz_k<D>(row)) * 8), qslot + j * 1024);
     }
   }
   // GATE: this workgroup's 64 rows of the layer input, head h's slice, as a K-shaped tile in K ring slot R-1 (first used by
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
       const int row = piece_row(j);
       int xr = qt * 64 + row;
       xr = xr < P.Sq ? xr : P.Sq - 1;
-      glds16(xbase + (long)xr * P.ghs_t + (pch ^ swz_k<D>(row)) * 8, xslot + j * 1024);
+      glds16_s(xbase + (long)qt * 64 * P.ghs_t, 2u * (unsigned)((xr - qt * 64) * (int)P.ghs_t + (pch ^ swz_k<D>(row)) * 8), xslot + j * 1024);
     }
   }
   // stream prologue: two tiles in flight

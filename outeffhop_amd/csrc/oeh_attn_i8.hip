@@ -235,36 +235,37 @@ __global__ __launch_bounds__(256, 3) void oeh_attn_i8_kernel(const AttnParams P)
     if (kt < n_kt) {
       const bool open_tile = kt < kt_causal && kt < kt_tail;
       const int lim = klim_g - 64 * kt;                     // element (t, r) is masked when 4 t + r > lim
-      auto quantise = [&](auto masked_c) {  // (the tile's body twice, not a test per four elements)
-        constexpr bool MASKED = decltype(masked_c)::value;
+      // the score index in place; a tile with hidden keys then masks in place under ONE wave-uniform branch.  (Round 3 wrote the tile's body twice -
+      // an open and a masked form - to avoid a test per four elements; the two forms left their results in different registers and the join cost
+      // eight v_mov_b64 per tile, 0.5 vector instructions per score element: round 5, from the disassembly.)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[kt * 4 + t][r] = grid_rel_m(s[kt * 4 + t][r], k1, slo, shi);
+        if constexpr (DUMP) {
+          if (P.fq_s.dump != nullptr && qvalid) {
+            const int zi = (int)P.fq_s.zp - 0x4B400000;
+            const unsigned w = (unsigned)((int)f32_bits(s[kt * 4 + t][0]) + zi) | ((unsigned)((int)f32_bits(s[kt * 4 + t][1]) + zi) << 8) |
+                               ((unsigned)((int)f32_bits(s[kt * 4 + t][2]) + zi) << 16) | ((unsigned)((int)f32_bits(s[kt * 4 + t][3]) + zi) << 24);
+            const int key0 = 64 * kt + 16 * g + 4 * t;
+            if (key0 < Sk) *reinterpret_cast<unsigned*>(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0) = w;
+          }
+        }
+      }
+      if (!open_tile) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[kt * 4 + t][r] = (4 * t + r > lim) ? RELMASK : s[kt * 4 + t][r];
+      }
+      if constexpr (PAD) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          f4 rel;
+          const f4 flag = *reinterpret_cast<const f4*>(&lds_pad[64 * kt + 16 * g + 4 * t]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) rel[r] = grid_rel_m(s[kt * 4 + t][r], k1, slo, shi);
-          if constexpr (DUMP) {
-            if (P.fq_s.dump != nullptr && qvalid) {
-              const int zi = (int)P.fq_s.zp - 0x4B400000;
-              const unsigned w = (unsigned)((int)f32_bits(rel[0]) + zi) | ((unsigned)((int)f32_bits(rel[1]) + zi) << 8) |
-                                 ((unsigned)((int)f32_bits(rel[2]) + zi) << 16) | ((unsigned)((int)f32_bits(rel[3]) + zi) << 24);
-              const int key0 = 64 * kt + 16 * g + 4 * t;
-              if (key0 < Sk) *reinterpret_cast<unsigned*>(P.fq_s.dump + (((long)b * P.H + h) * P.Sq + qrow) * Sk + key0) = w;
-            }
-          }
-          if constexpr (MASKED) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rel[r] = (4 * t + r > lim) ? RELMASK : rel[r];
-          }
-          if constexpr (PAD) {
-            const f4 flag = *reinterpret_cast<const f4*>(&lds_pad[64 * kt + 16 * g + 4 * t]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rel[r] = __builtin_fminf(rel[r], flag[r]);
-          }
-          s[kt * 4 + t] = rel;
+          for (int r = 0; r < 4; ++r) s[kt * 4 + t][r] = __builtin_fminf(s[kt * 4 + t][r], flag[r]);
         }
-      };
-      if (open_tile) quantise(std::false_type{});
-      else quantise(std::true_type{});
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {  // (v_max3 from the plain builtins: the operands are v_med3 / select results, known canonical - no
         mr = __builtin_fmaxf(__builtin_fmaxf(mr, s[kt * 4 + t][0]), s[kt * 4 + t][1]);  // canonicalising v_max, and none of the
