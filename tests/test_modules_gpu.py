@@ -531,6 +531,7 @@ def test_quantised_opt_uses_the_int8_storage_core(oa, monkeypatch):
             qm(torch.randn(B, T, E, device=dev), attention_mask=mask)
         qm.fix_ranges()
         x = torch.randn(B, T, E, device=dev)
+        monkeypatch.setattr(Q, "I8_PLAN", False)  # (this test counts the ops calls of EVERY forward: the prebuilt plan of a repeated forward bypasses them)
         calls = []
         real = ops.attn_fwd_i8
         monkeypatch.setattr(ops, "attn_fwd_i8", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
@@ -546,6 +547,7 @@ def test_quantised_opt_uses_the_int8_storage_core(oa, monkeypatch):
         monkeypatch.setattr(Q.QuantLinear, "int8_index_ok", lambda self, rows: False)
         out8h, _, _ = qm(x, attention_mask=mask)
         monkeypatch.undo()
+        monkeypatch.setattr(Q, "I8_PLAN", False)
         monkeypatch.setattr(ops, "attn_fwd_i8", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
         assert qm.out_proj.__dict__["_int8_index_calls"] == 2 and torch.equal(out8h, out8)
         calls.pop()
@@ -609,6 +611,7 @@ def test_quantised_modules_fuse_the_projections_into_one_gemm_with_quantiser_epi
             qm(torch.randn(B, T, E, device=dev), attention_mask=mask)
         qm.fix_ranges()
         x = torch.randn(B, T, E, device=dev)
+        monkeypatch.setattr(Q, "I8_PLAN", False)  # (this test counts the ops calls of EVERY forward: the prebuilt plan of a repeated forward bypasses them)
         calls = []
         real = ops.proj_quant_i8
         monkeypatch.setattr(ops, "proj_quant_i8", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
@@ -663,6 +666,7 @@ def test_quantised_bert_uses_the_int8_storage_core(oa, monkeypatch):
                 qm(torch.randn(B, T, 256, device=dev), attention_mask=mask)
             qm.fix_ranges()
             x = torch.randn(B, T, 256, device=dev)
+            monkeypatch.setattr(Q, "I8_PLAN", False)  # (this test counts the ops calls of EVERY forward: the prebuilt plan of a repeated forward bypasses them)
             calls = []
             real = ops.attn_fwd_i8
             monkeypatch.setattr(ops, "attn_fwd_i8", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
@@ -849,3 +853,100 @@ def test_training_backpropagates_through_the_torch_op_path(oa):
             y = x.detach() + la(x.detach(), attention_mask=torch.from_numpy(g["opt_mask"]).cuda())[0]
             z2 = lb(y, attention_mask=torch.from_numpy(g["bert_mask"]).cuda())[0]
         _close(z2, g[f"{case['name']}.z"], case["name"] + " inference after training", dict(atol=2e-3, rtol=2e-3))
+
+
+def test_frozen_int8_layers_replay_a_prebuilt_plan(oa):
+    """Round 5 (the eager quantised modules were host-bound).  Once the ranges are frozen, a repeated forward of
+    QuantizedOPT / QuantizedBert runs three PREBUILT launches (quantization._I8LayerPlan) instead of the ~80 Python statements of
+    `_int8_storage_core`.  Same bits as the full path; and the plan must notice everything that was baked into it: an in-place weight update,
+    a re-fitted range, another input geometry, a padding mask of another batch (pointer patched), a forward hook (bypass forbidden), the feature
+    switches - each checked against the full path (I8_PLAN off) on the same module."""
+    from outeffhop_amd import quantization as Q
+
+    torch.manual_seed(31)
+    dev = torch.device("cuda:0")
+    B, T, E, H = 3, 128, 256, 4
+
+    def both(mod, *a, **k):
+        """(output through the plan machinery, output of the full path, plan runs during the first)"""
+        before = mod.__dict__.get("_i8_plan_runs", 0)
+        o1 = mod(*a, **k)
+        n = mod.__dict__.get("_i8_plan_runs", 0) - before
+        Q.I8_PLAN = False
+        try:
+            o2 = mod(*a, **k)
+        finally:
+            Q.I8_PLAN = True
+        return o1, o2, n
+
+    # ---- OPT (decoder: int8 core -> out_proj on the int8 context, (k, v) cache values)
+    org = oa.OPTAttentionWithExtras(E, H, is_decoder=True, softmax_fn=oa.SOFTMAX_MAPPING["softmax1"]).to(dev).eval()
+    qm = oa.QuantizedOPTAttentionWithExtras(org, **_qparams(oa)).to(dev).eval()
+    qm.set_quant_state(weight_quant=True, act_quant=True)
+    mask = _decoder_mask(B, T, [T] * B, torch.float32, dev)
+    with torch.no_grad():
+        for _ in range(3):
+            qm(torch.randn(B, T, E, device=dev), attention_mask=mask)
+        qm.fix_ranges()
+        x, x2 = torch.randn(B, T, E, device=dev), torch.randn(B, T, E, device=dev)
+        first = qm(x, attention_mask=mask)                       # full path, builds the plan
+        assert qm.__dict__.get("_oeh_i8_plan") is not None and qm.__dict__.get("_i8_plan_runs", 0) == 0
+        (o1, _, p1), (o2, _, p2), n = both(qm, x, attention_mask=mask)
+        assert n == 1 and torch.equal(o1, o2) and torch.equal(o1, first[0]) and torch.equal(p1[0], p2[0]) and torch.equal(p1[1], p2[1])
+        (o1, _, p1), (o2, _, p2), n = both(qm, x2, attention_mask=mask)     # other data, same geometry: the plan again; fresh outputs
+        assert n == 1 and torch.equal(o1, o2) and not torch.equal(o1, first[0]) and o1.data_ptr() != first[0].data_ptr()
+        assert torch.equal(first[0], qm(x, attention_mask=mask)[0])        # (the earlier result was not overwritten by later forwards)
+        # an in-place weight update / a re-fitted range: noticed (version counters, buffer identity), same result as the full path
+        qm.q_proj.weight.mul_(1.01)
+        (o1, _, _), (o2, _, _), n = both(qm, x, attention_mask=mask)
+        assert n == 0 and torch.equal(o1, o2) and not torch.equal(o1, first[0])
+        qz = qm.attn_probs_act_quantizer.activation_quantizer.quantizer
+        qz._delta.mul_(1.25)
+        (o1, _, _), (o2, _, _), n = both(qm, x, attention_mask=mask)
+        assert n == 0 and torch.equal(o1, o2)
+        assert both(qm, x, attention_mask=mask)[2] == 1                     # (rebuilt: the next forward replays again)
+        # another geometry
+        xs = torch.randn(2, 64, E, device=dev)
+        (o1, _, _), (o2, _, _), n = both(qm, xs, attention_mask=_decoder_mask(2, 64, [64, 64], torch.float32, dev))
+        assert n == 0 and torch.equal(o1, o2)
+        # a forward hook on a bypassed module: the module path must run (the hook fires)
+        fired = []
+        hnd = qm.k_proj.register_forward_hook(lambda m_, i_, o_: fired.append(1))
+        qm(xs, attention_mask=_decoder_mask(2, 64, [64, 64], torch.float32, dev))
+        hnd.remove()
+        assert fired
+        # a feature switch
+        qm(x, attention_mask=mask)
+        Q.INDEX_GEMM = False
+        try:
+            before = qm.__dict__.get("_i8_plan_runs", 0)
+            qm(x, attention_mask=mask)
+            assert qm.__dict__.get("_i8_plan_runs", 0) == before
+        finally:
+            Q.INDEX_GEMM = True
+
+    # ---- BERT (key padding: the mask's pointer is patched per call)
+    bq = oa.QuantizedBertSelfAttentionWithExtras(oa.BertSelfAttentionWithExtras(Cfg(), softmax_fn=oa.SOFTMAX_MAPPING["softmax1"]).to(dev).eval(),
+                                                 **_qparams(oa)).to(dev).eval()
+    bq.set_quant_state(weight_quant=True, act_quant=True)
+    fmin = torch.finfo(torch.float32).min
+
+    def bmask(lens):
+        m = torch.zeros(len(lens), 1, 1, T, device=dev)
+        for b_, n_ in enumerate(lens):
+            m[b_, ..., n_:] = fmin
+        return m
+
+    with torch.no_grad():
+        for _ in range(3):
+            bq(torch.randn(B, T, 128, device=dev), attention_mask=bmask([T, 90, 40]))
+        bq.fix_ranges()
+        xb = torch.randn(B, T, 128, device=dev)
+        m1, m2 = bmask([T, 90, 40]), bmask([17, T, 64])
+        bq(xb, attention_mask=m1)
+        (o1,), (o2,), n = both(bq, xb, attention_mask=m1)
+        assert n == 1 and torch.equal(o1, o2)
+        (o1b,), (o2b,), n = both(bq, xb, attention_mask=m2)                 # another batch's padding through the same plan
+        assert n == 1 and torch.equal(o1b, o2b) and not torch.equal(o1b, o1)
+        (o1c,), (o2c,), n = both(bq, xb)                                    # no mask: another plan
+        assert torch.equal(o1c, o2c)
