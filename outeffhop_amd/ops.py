@@ -5,6 +5,7 @@ liboeh_hip.so; tensors that are not on a GPU are an error (there is no CPU path 
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass
 from typing import Optional
 
@@ -154,6 +155,27 @@ def attn_fwd(
     out_dtype=torch.float32 with fp16 / bf16 inputs: the output straight from the kernel's fp32 accumulators (include/oeh.h: o_dtype) -
     the kernel's arithmetic before the output rounding, which is how tests / smoke / bench check the "within 1e-3" contract on the
     kernel that ships; the one-pass and full-row kernels only (OehError -95 otherwise)."""
+    # ---- the repeated call (round 5): same geometry and options as an earlier call -> that call's prebuilt descriptor, pointers patched.
+    # The Python below this block is ~13 us per call (checks, a 40-field ctypes descriptor, mask / gate views) against ~3 us for the launch of a
+    # prebuilt one, and the fp16 BERT-base layer is host-bound in eager mode.  Only the plain forms (no fused quantisers, no in-kernel gate predictor,
+    # no (B,1,Sq,Sk) mask, no caller's `out`, inference).
+    fkey = None
+    if (FAST_CALLS and out is None and gate_mlp is None and fq is None and full_mask is None and _prepared is None and out_dtype is None
+            and q.is_cuda and q.dim() == 4 and q.device.index == torch.cuda.current_device()
+            and not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad or (gate is not None and gate.requires_grad)))):
+        fkey = _fast_key(q, k, v, softmax, scale, scale_div, key_pad_mask, key_pad_boolean, causal, clamp_min, mask_min, gate)
+        hit = _fast_tls.table.get(fkey) if fkey is not None else None
+        if hit is not None:
+            fn, d, oshape, odt = hit
+            o = torch.empty(oshape, dtype=odt, device=q.device).permute(0, 2, 1, 3)
+            if key_pad_mask is not None:
+                d.key_pad_mask = key_pad_mask.data_ptr()
+            if gate is not None:
+                d.gate = gate.data_ptr()
+            rc = fn(C.byref(d), C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(o.data_ptr()), None, _stream())
+            if rc != 0:
+                _lib.check(rc, "oeh_attn_fwd")
+            return o
     dev = _need_gpu(q, k, v, key_pad_mask, full_mask, gate, out)
     if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
         raise ValueError("q, k, v must be 4-D (B,H,S,D) views")
@@ -262,7 +284,49 @@ def attn_fwd(
         rc = lib.oeh_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), None if fqd is None else C.byref(fqd), _stream())
     _lib.check(rc, "oeh_attn_fwd")
     _warn_if_any_shape_kernel(lib, d, fqd, softmax)  # (after the launch: a call the library refuses raises above and has run nothing)
+    if fkey is not None and fqd is None and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1 and out.shape == (B, H, Sq, D):
+        # remember the descriptor for the next call of this geometry (its mask / gate pointers are patched per call; the views `keep` holds
+        # were only needed for THIS call's pointers)
+        if len(_fast_tls.table) >= 256:
+            _fast_tls.table.clear()
+        _fast_tls.table[fkey] = (lib.oeh_attn_fwd, d, (B, Sq, H, D), odt)
     return out
+
+
+FAST_CALLS = True
+
+
+class _FastCalls(threading.local):
+    """geometry + options -> (C function, descriptor, output shape, output dtype): see attn_fwd.  Per THREAD: a cached descriptor's mask / gate
+    pointers are patched right before the call, and ctypes releases the GIL inside it."""
+
+    def __init__(self):
+        self.table = {}
+
+
+_fast_tls = _FastCalls()
+
+
+def _fast_key(q, k, v, softmax, scale, scale_div, key_pad_mask, key_pad_boolean, causal, clamp_min, mask_min, gate):
+    """What a prebuilt `oeh_attn_desc` depends on besides the four data pointers and the mask / gate pointers; None: not a plain call."""
+    if k.dim() != 4 or v.dim() != 4 or k.device != q.device or v.device != q.device or not (q.dtype == k.dtype == v.dtype):
+        return None
+    if q.stride(3) != 1 or k.stride(3) != 1 or v.stride(3) != 1 or q.shape[3] not in (32, 64, 128):
+        return None
+    pk = None
+    if key_pad_mask is not None:
+        # (the vector as the slow path would hand it over unchanged: (B, Sk), fp16 / fp32, contiguous rows, on the same GPU)
+        if (key_pad_mask.dim() != 2 or key_pad_mask.dtype not in (torch.float16, torch.float32) or key_pad_mask.stride(1) != 1 or key_pad_mask.stride(0) != key_pad_mask.shape[1]
+                or key_pad_mask.device != q.device or key_pad_mask.shape != (q.shape[0], k.shape[2])):
+            return None
+        pk = key_pad_mask.dtype
+    gk = None
+    if gate is not None:
+        if gate.dim() != 4 or gate.dtype != torch.float32 or gate.device != q.device:
+            return None
+        gk = (gate.shape, gate.stride())
+    return (q.shape, q.stride(), k.shape, k.stride(), v.shape, v.stride(), q.dtype, q.device, softmax, float(scale), float(scale_div), pk, bool(key_pad_boolean), bool(causal),
+            bool(clamp_min), mask_min, gk)
 
 
 def _matrix_core_head_dim(D: int, Sq: int, Sk: int, plain: bool) -> int:
