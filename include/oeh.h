@@ -298,12 +298,13 @@ int oeh_split_triples(const float* x, void* out_f16, int64_t rows, int32_t K, in
  * oeh_quantize_heads_i8 passes computes, without the (B*S, n_seg*E) accumulator ever reaching memory.
  *   a: the activations (B*S rows, row stride lda elements, 16-byte aligned rows) - pairs == 0: fp16 (rows, K); pairs == 1: fp16
  *      (rows, 2K), the operand pairs [hi | lo] that oeh_split_pairs writes for an fp32 model; pairs == 2: the fp32 activations (rows, K)
- *      themselves - the kernel forms the same (hi, lo) pairs when a wave reads its operand fragments: same result as pairs == 1,
- *      bit for bit, without the split pass; pairs == 3: int8 (rows, K) - e.g. the centred indices idx - 128 of the producer's 8-bit
+ *      themselves - the kernel forms a (hi, lo) pair when a wave reads its operand fragments, without the split pass: 64 x = hi + lo with the
+ *      residual unscaled (|x - pair| <= 2^-31: 22 bits down to |x| = 2^-9, as pairs == 1 above that; |x| <= 2 047, saturating beyond), so an index
+ *      differs from the pairs == 1 call's only where the value sits on a rounding boundary to within the fp32 accumulation error; pairs == 3: int8 (rows, K) - e.g. the centred indices idx - 128 of the producer's 8-bit
  *      quantiser (oeh_attn_fwd, dtype OEH_I8, o_dtype OEH_I8) - against int8 weights on the integer matrix cores (K % 64 == 0): exact
  *      int32 sums; with acc_add[n] = (128 - zero_point) * sum_k w[n][k] the accumulator is the sum over idx - zero_point;
  *   w: (n_seg*E, K) fp16 (int8 with pairs == 3), row stride ldw: the QuantLinear weights' INTEGERS (w / weight scale: exact in fp16), the segments' rows
- *      one after the other; pairs != 0 multiplies the lo half against w * 2^-11, formed in registers (exact on integers);
+ *      one after the other; pairs == 1 multiplies the lo half against w * 2^-11, formed in registers (exact on integers);
  *   bias: (n_seg*E) fp32; segment i covers output columns [i*E, (i+1)*E) and turns the fp32 accumulator into
  *      value = alpha * acc + bias[column],  c = clamp(rint(value / scale) + zero_point, 0, 255) - 128:
  *      out  (may be NULL when y is given): int8, (B, S, E) [transpose == 0: q, k] or (B, E/64, 64, S) [transpose == 1: v, keys

@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256) void split_pairs_kernel(const float* __restric
     const int c0 = (int)(i - r * chunks) * 8;
     const f4* p = reinterpret_cast<const f4*>(x + r * x_sr + c0);
     u4 hi, lo;
-    split8(p[0], p[1], hi, lo);
+    split8_scaled(p[0], p[1], hi, lo);   // the documented [hi | lo 2^11] format (include/oeh.h: oeh_split_pairs)
     *reinterpret_cast<u4*>(out + r * 2 * K + c0) = hi;
     *reinterpret_cast<u4*>(out + r * 2 * K + K + c0) = lo;
   }
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void split_triples_kernel(const float* __restr
     const f4* p = reinterpret_cast<const f4*>(x + r * x_sr + c0);
     const f4 a = p[0], b = p[1];
     u4 hi, lo;
-    split8(a, b, hi, lo);
+    split8_scaled(a, b, hi, lo);
     // hi 2^-5 and lo 2^-5 (lo = (x - hi) 2^11): exact scalings of fp16 values unless they leave the normal range
     const h2* hh = reinterpret_cast<const h2*>(&hi);
     const h2* ll = reinterpret_cast<const h2*>(&lo);

@@ -202,7 +202,13 @@ __device__ __forceinline__ u4 load8_as16(const void* base, long elem_off) {
 // far inside).  Kernels that split call fp16_overflow_clamp() first: with MODE.FP16_OVFL set the conversions SATURATE at the
 // fp16 range instead of producing inf, so that a stray larger value costs accuracy (the excess is dropped) and never turns a
 // whole row into NaN - at no instruction cost (two v_med3 per element in the load path measured +15 % on the fp32 kernels).
+// OEH_PAIR_RAW (round 5 experiment -> see profiles/r05_pair_raw_ab.txt): the attention kernels' operand pairs with the UNSCALED residual (split8_raw below) -
+// the factor that brings the lo products back is then 1.
+#ifdef OEH_PAIR_RAW
+constexpr float kSplitUp = 1.0f, kSplitDown = 1.0f;
+#else
 constexpr float kSplitUp = 2048.0f, kSplitDown = 1.0f / 2048.0f;
+#endif
 __device__ __forceinline__ void fp16_overflow_clamp() {
   __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);  // hwreg(HW_REG_MODE, 23, 1): FP16_OVFL
 }
@@ -270,11 +276,48 @@ __device__ __forceinline__ void split8_raw(const f4 a, const f4 b, u4& hi, u4& l
       : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
   lo = u4{l0, l1, l2, l3};
 }
-__device__ __forceinline__ void split8(const f4 a, const f4 b, u4& hi, u4& lo) {
+// split8_raw with a power-of-two PRE-SCALE k of the values (k in a scalar register): k x = hi + lo', hi = RN16(k x), lo' = RN16(k x - hi), both by
+// v_fma_mixlo/hi_f16 (16 instructions per 8 values, no conversion, no pack).  Why: the unscaled residual is a fp16 subnormal once |k x| < ~2^-3, i.e. the pair's
+// RELATIVE precision falls below 2^-22 for small values (2^-15 at |k x| = 2^-10) - harmless in a dot product dominated by O(1) elements, a real loss if a
+// whole tensor is tiny.  With k = 64 the 22 bits hold down to |x| = 2^-9 and degrade gracefully below; the range is |x| <= 2 047 (hi saturates at 65 504 under
+// MODE.FP16_OVFL and lo' carries the excess up to another 65 504; beyond that the value saturates).  The caller folds 1 / k into its output scale (exact).
+__device__ __forceinline__ void split8_raw_scaled(const f4 a, const f4 b, const float k, u4& hi, u4& lo) {
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  asm("v_fma_mixlo_f16 %0, %8, %16, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %9, %16, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixlo_f16 %1, %10, %16, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %11, %16, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixlo_f16 %2, %12, %16, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixhi_f16 %2, %13, %16, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixlo_f16 %3, %14, %16, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixhi_f16 %3, %15, %16, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixlo_f16 %4, %8, %16, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %4, %9, %16, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %5, %10, %16, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %5, %11, %16, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %6, %12, %16, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %6, %13, %16, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %7, %14, %16, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %7, %15, %16, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "s"(k));
+  hi = u4{h0, h1, h2, h3};
+  lo = u4{l0, l1, l2, l3};
+}
+// the documented [hi | lo 2^11] pair (oeh_split_pairs' output format, the projection GEMM's `pairs` = 1 input)
+__device__ __forceinline__ void split8_scaled(const f4 a, const f4 b, u4& hi, u4& lo) {
 #ifdef OEH_SPLIT_REF   // (the round-4 form, for A/B builds: make alt NAME=ref DEFS=-DOEH_SPLIT_REF)
   split8_ref(a, b, hi, lo);
 #else
   split8_mix(a, b, 2048.0f, hi, lo);
+#endif
+}
+// the kernels' own operand pairs (never leave a kernel)
+__device__ __forceinline__ void split8(const f4 a, const f4 b, u4& hi, u4& lo) {
+#ifdef OEH_PAIR_RAW
+  split8_raw(a, b, hi, lo);
+#else
+  split8_scaled(a, b, hi, lo);
 #endif
 }
 // 8 consecutive fp32 storage elements -> the (hi, lo) operand pair

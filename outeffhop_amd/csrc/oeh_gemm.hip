@@ -85,6 +85,14 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
   typedef Geo<MI, NJ> G;
   constexpr bool PAIRS = AM == A_PAIRS || AM == A_F32;   // two MFMA products per term: (hi, lo) of fp32 activations
   constexpr int EB = AM == A_I8 ? 1 : 2;               // bytes per element of a and w (a K step is 64 bytes of a row either way)
+#ifndef OEH_GEMM_KPRE
+#define OEH_GEMM_KPRE 32   // (A/B builds: 0 = the plain unscaled residual of x itself, split8_raw)
+#endif
+#if !defined(OEH_SCALED_LO) && OEH_GEMM_KPRE
+  constexpr float kApre = (float)OEH_GEMM_KPRE, kApreInv = AM == A_F32 ? 1.0f / kApre : 1.0f;   // fp32 activations are split as kApre x (below)
+#else
+  constexpr float kApreInv = 1.0f;
+#endif
   constexpr int GBM = G::BM, GBN = G::BN, G_AHI = G::AHI, G_ALO = G::ALO, G_W = G::W, G_SLOT = G::SLOT, G_PITCH_C = G::PITCH_C, G_IMG_C = G::IMG_C;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -202,9 +210,15 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
       for (int i = 0; i < MI; ++i) {
         u4 hi, lo;
 #ifndef OEH_SCALED_LO   // (round 5; -DOEH_SCALED_LO: the round-4 form, [hi | lo 2^11] against W and W 2^-11, for A/B builds)
-        split8_raw(x32[i][0], x32[i][1], hi, lo);   // lo = RN16(x - hi), unscaled (oeh_common.h): the second product runs against W itself (below)
+        // 32 x = hi + lo', lo' = RN16(32 x - hi) unscaled (oeh_common.h: why the pre-scale): the second product runs against W itself (below), and the
+        // epilogue folds the 2^-5 into the segment's alpha (exact).  22 bits of x for 2^-8 <= |x| <= 2 047 (an absolute 2^-30 below, 11 bits up to 4 094)
+#if OEH_GEMM_KPRE
+        split8_raw_scaled(x32[i][0], x32[i][1], kApre, hi, lo);
 #else
-        split8(x32[i][0], x32[i][1], hi, lo);
+        split8_raw(x32[i][0], x32[i][1], hi, lo);
+#endif
+#else
+        split8_scaled(x32[i][0], x32[i][1], hi, lo);
 #endif
         ah[i] = __builtin_bit_cast(h8v, hi);
         al[i] = __builtin_bit_cast(h8v, lo);
@@ -287,7 +301,7 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
         const int sg = (n >= P.E) + (n >= 2 * P.E);
         const GemmSeg& g = P.seg[sg];
         const FqP f = g.f;
-        const float alpha = g.alpha;
+        const float alpha = g.alpha * kApreInv;
         const float bia = biav[j];
         int iadd = 0;  // int8 form: the accumulator is an int32 sum of centred indices; + (128 - zero_point) * column sum of w = the sum over idx - zp
         if constexpr (AM == A_I8) iadd = g.acc_add != nullptr ? g.acc_add[(n - sg * P.E) + l15] : 0;

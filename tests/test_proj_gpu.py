@@ -54,7 +54,7 @@ def test_pair_gemm_with_quantiser_epilogue_vs_exact_arithmetic(B, S, H, K, want)
         rate, rate_old = float((d != 0).float().mean()), float((d_old != 0).float().mean())
         print(f"B={B} S={S} H={H} K={K} [{'qkv'[n]}]: index != exact {rate:.1e} (library GEMM + quantiser pass: {rate_old:.1e}), max {int(d.max())} step")
         assert int(d.max()) <= 1 and rate <= max(3e-5, 3.0 * rate_old)
-        # ... and from the fp32 activations themselves (the modules' path; round 5: the residual operand unscaled, oeh_common.h: split8_raw): the same bar
+        # ... and from the fp32 activations themselves (the modules' path; round 5: the residual operand unscaled, oeh_common.h: split8_raw_scaled): the same bar
         got32 = (new32[n][0] if (n > 0 and want) else new32[n]).contiguous().to(torch.int32)
         d32 = (got32 - ex).abs()
         rate32 = float((d32 != 0).float().mean())
@@ -141,14 +141,40 @@ def test_projection_gemm_random_shapes_against_the_library_path():
                 assert torch.equal(yn, want_y)
 
 
+@pytest.mark.parametrize("mag", [1.0e-4, 1.0e-3, 0.05, 1.0, 450.0])
+def test_fp32_activations_of_any_magnitude_vs_exact_arithmetic(mag):
+    """The in-kernel split of fp32 activations (pairs == 2) keeps the residual unscaled, on 32 x (oeh_common.h: split8_raw_scaled): 22 bits of every
+    value down to |x| = 2^-8, an absolute 2^-30 below, range |x| <= 2 047 (11 bits up to 4 094).  A whole tensor of tiny values (the case an unscaled residual WITHOUT the
+    pre-scale would lose: fp16 subnormals) and one that fills the range: the indices against float64 arithmetic, the same bar as at magnitude 1."""
+    from outeffhop_amd import ops
+
+    torch.manual_seed(int(mag * 1e4) + 3)
+    B, S, H, K = 4, 256, 12, 768
+    E, M = H * 64, B * S
+    x = (torch.randn(M, K, device="cuda") * mag).clamp_(-2040.0, 2040.0)
+    wi = torch.randint(-128, 128, (3 * E, K), device="cuda").to(torch.float16)
+    bias = torch.randn(3 * E, device="cuda") * 0.1
+    alphas = [0.003 / mag, 0.0025 / mag, 0.002 / mag]
+    ref64 = x.double() @ wi.double().t()
+    vals = [ref64[:, n * E:(n + 1) * E] * alphas[n] + bias[n * E:(n + 1) * E].double() for n in range(3)]
+    specs = [ops.FakeQuantSpec(*_grid(v)) for v in vals]
+    got = ops.proj_quant_i8(x, wi, bias, B, S, [(alphas[n], specs[n], n == 2, False) for n in range(3)], pairs=True)
+    for n in range(3):
+        ex = _exact_indices(vals[n], specs[n], B, S, H, n == 2)
+        d = (got[n].contiguous().to(torch.int32) - ex).abs()
+        rate = float((d != 0).float().mean())
+        print(f"|x| ~ {mag:g} [{'qkv'[n]}]: index != exact {rate:.1e}, max {int(d.max())} step")
+        assert int(d.max()) <= 1 and rate <= (3e-5 if mag >= 1e-3 else 3e-4)   # (|x| ~ 1e-4 is 5 bits below 2^-8: 17 bits)
+
+
 @pytest.mark.parametrize("B,S,H,K", [(16, 512, 12, 768), (4, 128, 12, 768), (3, 48, 2, 64), (5, 80, 12, 768)])
 def test_fp32_activations_split_inside_the_kernel_equal_the_operand_pairs(B, S, H, K):
     """`a` as the fp32 activation matrix (split into fp16 operands when a wave reads its fragments) against the same call on `oeh_split_pairs`'
-    output.  Round 5: the in-kernel split keeps the residual UNSCALED (oeh_common.h: split8_raw - the matrix core takes fp16 subnormals exactly,
-    tools/probe/mix_probe.hip), `oeh_split_pairs` keeps its documented [hi | lo 2^11] format: the two represent x to 2^-25 absolute / 2^-22 relative
-    respectively, so an index may differ where a value sits on a rounding boundary to within that - never by more than one step, in at most 2e-5 of
-    the outputs (measured ~1e-6; rounds 1-4: bit-identical, with both paths on the scaled pair).  Values beyond the fp16 range: the pair format
-    saturates at 65504 (+ 32), the unscaled residual carries them exactly up to twice that - both finite; those rows are compared for finiteness only."""
+    output.  Round 5: the in-kernel split keeps the residual UNSCALED, on 32 x (oeh_common.h: split8_raw_scaled - the matrix core takes fp16 subnormals
+    exactly, tools/probe/mix_probe.hip), `oeh_split_pairs` keeps its documented [hi | lo 2^11] format: the two represent x to 2^-30 absolute / 2^-22
+    relative respectively, so an index may differ where a value sits on a rounding boundary to within that - never by more than one step, in at most 2e-5
+    of the outputs (measured ~1e-6; rounds 1-4: bit-identical, with both paths on the scaled pair).  Values beyond the range: the pair format saturates
+    at 65504 (+ 32), the in-kernel one at 4 094 - both finite; those rows are compared for finiteness only."""
     from outeffhop_amd import ops
 
     torch.manual_seed(11 + S)

@@ -10,6 +10,20 @@
 #include <vector>
 using namespace oeh;
 
+__global__ void k_split_scaled(const float* x, unsigned* out, float k, int clampmode) {   // split8_raw_scaled against its definition in plain C
+  if (clampmode) fp16_overflow_clamp();
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  f4 a = *reinterpret_cast<const f4*>(x + t * 8), b = *reinterpret_cast<const f4*>(x + t * 8 + 4);
+  u4 hi, lo;
+  split8_raw_scaled(a, b, k, hi, lo);
+  const float xs[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  for (int i = 0; i < 4; ++i) {
+    const h2 h = sat_h2(xs[2 * i] * k, xs[2 * i + 1] * k);                         // RN16(k x) (the product by a power of two is exact)
+    const h2 l = sat_h2(__builtin_fmaf(xs[2 * i], k, -(float)h[0]), __builtin_fmaf(xs[2 * i + 1], k, -(float)h[1]));   // RN16(k x - hi): the fma is exact
+    out[t * 16 + i] = hi[i]; out[t * 16 + 4 + i] = lo[i]; out[t * 16 + 8 + i] = __builtin_bit_cast(unsigned, h); out[t * 16 + 12 + i] = __builtin_bit_cast(unsigned, l);
+  }
+}
+
 __global__ void k_split(const float* x, unsigned* out, float k2048, int clampmode) {
   if (clampmode) fp16_overflow_clamp();
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,6 +77,21 @@ int main() {
       }
     printf("FP16_OVFL=%d: %ld register pairs compared; hi differs %ld, lo differs %ld (of those with both values inside the fp16 range: %ld)\n", clampmode, n / 2, bad_hi, bad_lo, bad_lo_in_range);
     if (first >= 0) printf("  first in-range difference at x = %.9g, %.9g\n", h[first], h[first + 1]);
+  }
+  for (int clampmode = 0; clampmode < 2; ++clampmode) {
+    hipLaunchKernelGGL(k_split_scaled, dim3(n / 8 / 256), dim3(256), 0, 0, dx, dout, 32.0f, clampmode);
+    hipMemcpy(o.data(), dout, n * 2 * 4, hipMemcpyDeviceToHost);
+    long bad_hi = 0, bad_lo = 0, bad_in = 0;
+    for (long t = 0; t < n / 8; ++t)
+      for (int i = 0; i < 4; ++i) {
+        const bool inr = fabsf(h[t * 8 + 2 * i]) <= 1000.0f && fabsf(h[t * 8 + 2 * i + 1]) <= 1000.0f;
+        // (a zero's sign is not compared: fma(-0, k, +0) = +0 where the plain product keeps -0)
+        auto half_differs = [](unsigned p_, unsigned q_) { return (p_ & 0xffffu) != (q_ & 0xffffu) && ((p_ | q_) & 0x7fffu) != 0; };
+        auto differ = [&](unsigned p_, unsigned q_) { return half_differs(p_, q_) || half_differs(p_ >> 16, q_ >> 16); };
+        if (differ(o[t * 16 + i], o[t * 16 + 8 + i])) { ++bad_hi; if (inr) ++bad_in; }
+        if (differ(o[t * 16 + 4 + i], o[t * 16 + 12 + i])) { ++bad_lo; if (inr) ++bad_in; }
+      }
+    printf("split8_raw_scaled(k = 32), FP16_OVFL=%d: hi differs %ld, lo differs %ld of %ld register pairs (with both |x| <= 1000: %ld)\n", clampmode, bad_hi, bad_lo, n / 2, bad_in);
   }
   float* dc; hipMalloc(&dc, 4);
   struct { unsigned short a, b; const char* what; } cases[] = {
