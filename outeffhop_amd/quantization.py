@@ -757,7 +757,7 @@ I8_PLAN = True
 
 
 class _I8LayerPlan:
-    __slots__ = ("xkey", "flags", "watch", "hookmods", "stream", "padkey", "proj", "attn", "outp", "bufs", "B", "T", "E", "H", "want_values", "hdtype", "as_index", "keep")
+    __slots__ = ("xkey", "flags", "watch", "hookmods", "mods", "stream", "padkey", "proj", "attn", "outp", "bufs", "B", "T", "E", "H", "want_values", "hdtype", "as_index", "keep")
 
     @staticmethod
     def watch_entries(owner, lins, consumer):
@@ -774,7 +774,7 @@ class _I8LayerPlan:
         out = []
         for d_, n_ in ents:
             t_ = d_.get(n_)
-            out.append((d_, n_, t_, None if t_ is None else t_._version))
+            out.append((d_, n_, t_, None if t_ is None else t_._version, None if t_ is None else t_.data_ptr()))   # (data_ptr: `p.data = other` keeps identity AND version)
         return out
 
     @staticmethod
@@ -788,15 +788,18 @@ class _I8LayerPlan:
         return tuple(fl)
 
     def valid(self, owner, x, lins, consumer, padvec, stream) -> bool:
-        if self.xkey != (x.shape, x.stride(), x.dtype, x.device) or self.stream != stream or (x.data_ptr() & 15):
+        if self.xkey != (x.shape, x.stride(), x.dtype, x.device) or self.stream != stream or (x.data_ptr() & 15) or x.device.index != torch.cuda.current_device():
+            return False
+        mods = (*lins, consumer)
+        if len(mods) != len(self.mods) or any(a is not b for a, b in zip(mods, self.mods)):   # (a projection swapped for another module)
             return False
         if self.padkey != (None if padvec is None else (padvec.dtype, padvec.shape, padvec.stride())):
             return False
         if self.flags != _I8LayerPlan.state_flags(owner, lins, consumer):
             return False
-        for d_, n_, t_, v_ in self.watch:
+        for d_, n_, t_, v_, p_ in self.watch:
             cur = d_.get(n_)
-            if cur is not t_ or (t_ is not None and t_._version != v_):
+            if cur is not t_ or (t_ is not None and (t_._version != v_ or t_.data_ptr() != p_)):
                 return False
         return not has_hooks(*self.hookmods)
 
@@ -951,7 +954,7 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
         the consumer's OUTPUT (`QuantLinear.linear_index`), marked by the third element of the result."""
         if not INT8_STORAGE or not hidden_states.is_cuda or head_dim != 64:
             return None
-        ckey = (H, float(scale), float(scale_div), bool(causal), float(mask_min), bool(want_values), fq.ctx_before_gate, id(consumer))
+        ckey = (H, float(scale), float(scale_div), bool(causal), float(mask_min), bool(want_values), fq.ctx_before_gate, id(consumer), self.softmax_fn)
         if I8_PLAN and gate is None:
             plan = self.__dict__.get("_oeh_i8_plan")
             if plan is not None and plan[0] == ckey and not torch.cuda.is_current_stream_capturing():
@@ -1066,7 +1069,7 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
         else:
             result = merged, (yk, yv), False
         if (I8_PLAN and gate is None and fused_consts is not None and (as_int8 if as_index else consumer is None) and hidden_states.is_contiguous()
-                and hidden_states.dtype == torch.float32 and not torch.cuda.is_current_stream_capturing()
+                and hidden_states.dtype == torch.float32 and not torch.cuda.is_current_stream_capturing() and hidden_states.device.index == torch.cuda.current_device()
                 and (padvec is None or (padvec.dtype in (torch.float16, torch.float32) and padvec.shape == (bsz, tgt_len) and padvec.stride(1) == 1))):
             try:
                 self.__dict__["_oeh_i8_plan"] = (ckey, self._build_i8_plan(hidden_states, lins, consumer, H, E, fused_consts, grids, fq_call, spec, scale, scale_div, causal,
@@ -1118,6 +1121,7 @@ class _QuantAttnBase(GateBookkeeping, QuantizedModel):
         pl.flags = _I8LayerPlan.state_flags(self, lins, consumer)
         pl.watch = _I8LayerPlan.watch_entries(self, lins, consumer)
         pl.hookmods = hookmods
+        pl.mods = (*lins, consumer)
         return pl
 
 

@@ -905,6 +905,11 @@ def test_frozen_int8_layers_replay_a_prebuilt_plan(oa):
         (o1, _, _), (o2, _, _), n = both(qm, x, attention_mask=mask)
         assert n == 0 and torch.equal(o1, o2)
         assert both(qm, x, attention_mask=mask)[2] == 1                     # (rebuilt: the next forward replays again)
+        # `p.data = other`: identity and version counter both stay - the storage address is watched too
+        qm.v_proj.weight.data = qm.v_proj.weight.data * 0.98
+        (o1, _, _), (o2, _, _), n = both(qm, x, attention_mask=mask)
+        assert n == 0 and torch.equal(o1, o2)
+        assert both(qm, x, attention_mask=mask)[2] == 1
         # another geometry
         xs = torch.randn(2, 64, E, device=dev)
         (o1, _, _), (o2, _, _), n = both(qm, xs, attention_mask=_decoder_mask(2, 64, [64, 64], torch.float32, dev))
