@@ -35,6 +35,7 @@
 #include "oeh_gemm.h"
 
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 
 namespace oeh {
@@ -61,6 +62,7 @@ struct Geo {
   static constexpr int AHI = 0, ALO = BM * GROWB, W = 2 * BM * GROWB, SLOT = W + BN * GROWB;
   static constexpr int PITCH_C = BM + 16, IMG_C = BM * BN, IMGS = IMG_C + BN * PITCH_C;   // the epilogue's byte images
   static constexpr int LDS = 2 * SLOT > IMGS ? 2 * SLOT : IMGS;
+  static constexpr int LDS3 = 3 * SLOT > IMGS ? 3 * SLOT : IMGS;   // the one-workgroup-per-CU loop's ring of three (LOOP == 1)
 };
 
 // Diagnostic knock-outs (OEH_GEMM_DBG, tools/exp/proj_time.py) exist only in a build with -DOEH_GEMM_EXPERIMENT (`make experiment`): in the
@@ -80,9 +82,16 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 // sixteen lanes of a group then hit sixteen different 16-byte bank groups, for both reads of a fragment
 __device__ __forceinline__ int swz32(int row) { return (int)((0x31765420u >> (4 * ((row >> 1) & 7))) & 7u); }
 
-template <int AM, int MI, int NJ>
-__global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(const GemmParams P) {
+// LOOP == 1 (round 5; fp32 activations, 128 x 288 tile): the K loop for launches that give a CU ONE workgroup - fewer than ~300 tiles, BERT-base's M = 4096:
+// 256 - where each SIMD has a single wave and nothing hides what that wave waits for.  Ring of three slots (tile t + 2 requested during step t, counted
+// wait), fragment-major groups (A fragment i against the NJ W fragments: 2 NJ MFMAs) with the LDS-DMA requests, the reads of fragment i + 2 and the split
+// of fragment i + 1 - one v_fma_mix instruction at a time - placed BETWEEN the MFMAs by construction (inline-asm MFMAs: volatile statements keep their
+// order); one wait + barrier per step.  tools/exp/big_gemm (profiles/r05_big_tile_gemm_experiment.txt) is where the structure was measured first.
+template <int AM, int MI, int NJ, int LOOP = 0>
+__global__ __launch_bounds__(256, (LOOP == 1 ? 1 : MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(const GemmParams P) {
   typedef Geo<MI, NJ> G;
+  static_assert(LOOP == 0 || (AM == A_F32 && MI == 4), "the one-workgroup-per-CU loop: fp32 activations, four row blocks per wave");
+  constexpr int RING = LOOP == 1 ? 3 : 2;
   constexpr bool PAIRS = AM == A_PAIRS || AM == A_F32;   // two MFMA products per term: (hi, lo) of fp32 activations
   constexpr int EB = AM == A_I8 ? 1 : 2;               // bytes per element of a and w (a K step is 64 bytes of a row either way)
 #ifndef OEH_GEMM_KPRE
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
   unsigned voff[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const int p = 4 * q + wave;
+    const int p = LOOP == 1 ? min(4 * q + wave, NP - 1) : 4 * q + wave;   // (LOOP == 1: the last round repeats piece NP - 1 - every wave issues NQ requests per tile)
     if (q < QL) {
       if constexpr (AM == A_F32) {
         // fp32 rows of 128 B (32 values = one K step): a piece = 8 rows, lane -> row 8 p + (lane >> 3), stored chunk lane & 7 = logical
@@ -148,13 +157,13 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
     }
   }
   auto issue_q = [&](int t, int q) {
-    const unsigned slot = lds_base + (unsigned)((t & 1) * G_SLOT);
+    const unsigned slot = lds_base + (unsigned)((RING == 2 ? (t & 1) : t % 3) * G_SLOT);
     const long kb = (long)t * (GBK * 2);
-    const int p = 4 * q + wave;
+    const int p = LOOP == 1 ? min(4 * q + wave, NP - 1) : 4 * q + wave;
     if (AM == A_F32 && q < QL) glds16_s(ab + 2 * kb, voff[q], slot + G_AHI + p * 1024);
     else if (q < QA) glds16_s(ab + kb, voff[q], slot + G_AHI + p * 1024);
     else if (q < QL) glds16_s(ab + (long)P.K * 2 + kb, voff[q], slot + G_ALO + (p - NPA) * 1024);
-    else if (q < NQ - 1 || wave < NP - 4 * (NQ - 1)) glds16_s(wb + kb, voff[q], slot + G_W + (p - QL * 4) * 1024);
+    else if (LOOP == 1 || q < NQ - 1 || wave < NP - 4 * (NQ - 1)) glds16_s(wb + kb, voff[q], __builtin_amdgcn_readfirstlane(slot + G_W + (p - QL * 4) * 1024));
   };
   auto issue = [&](int t) {
 #pragma unroll
@@ -175,6 +184,74 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (LOOP == 1) {
+    constexpr int PPG = (NQ + MI - 1) / MI;   // requests per group, the first groups
+    f4 raw[2][2];
+    unsigned hi[2][4], lo[2][4];
+    h8v fw[NJ];
+    const float kpre = kApre;
+    auto read_raw = [&](const unsigned char* sl, int i, f4 (&d)[2]) {
+      d[0] = *reinterpret_cast<const f4*>(sl + G_AHI + a32_off + i * 16 * 128);
+      d[1] = *reinterpret_cast<const f4*>(sl + G_AHI + (a32_off ^ 16u) + i * 16 * 128);
+    };
+    // one instruction of split8_raw_scaled (oeh_common.h) on the fragment's 8 values: k = 0..7 the hi halves, 8..15 the residuals
+    auto split_op = [&](int k, const f4 (&x)[2], unsigned (&h)[4], unsigned (&l)[4]) {
+      const int e = k & 7;
+      const float xe = x[e >> 2][e & 3];
+      unsigned& hr = h[e >> 1];
+      unsigned& lr = l[e >> 1];
+      if (k < 8) {
+        if (!(e & 1)) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(hr) : "v"(xe), "s"(kpre));
+        else asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(hr) : "v"(xe), "s"(kpre));
+      } else {
+        if (!(e & 1)) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lr) : "v"(xe), "s"(kpre), "v"(hr));
+        else asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lr) : "v"(xe), "s"(kpre), "v"(hr));
+      }
+    };
+    issue(0);
+    if (T > 1) issue(1);
+    auto step = [&](int t, auto dma_, auto w1_) {
+      constexpr bool DMA = decltype(dma_)::value;
+      // tile t has landed (the NQ requests of tile t + 1 may be in flight) - for every wave, and every wave has left tile t - 1: its slot takes tile t + 2
+      if constexpr (decltype(w1_)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      barrier_mem();
+      const unsigned char* sl = lds + (t % 3) * G_SLOT;
+      read_raw(sl, 0, raw[0]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) fw[j] = *reinterpret_cast<const h8v*>(sl + w_off + j * 16 * GROWB);
+      read_raw(sl, 1, raw[1]);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) split_op(k, raw[0], hi[0], lo[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        if constexpr (DMA) {
+#pragma unroll
+          for (int u = 0; u < PPG; ++u)
+            if (PPG * i + u < NQ) issue_q(t + 2, PPG * i + u);
+        }
+        if (i + 2 < MI) read_raw(sl, i + 2, raw[i & 1]);
+        const h8v ahv = __builtin_bit_cast(h8v, u4{hi[i & 1][0], hi[i & 1][1], hi[i & 1][2], hi[i & 1][3]});
+        const h8v alv = __builtin_bit_cast(h8v, u4{lo[i & 1][0], lo[i & 1][1], lo[i & 1][2], lo[i & 1][3]});
+#pragma unroll
+        for (int k = 0; k < 2 * NJ; ++k) {
+          const int j = k % NJ;
+          const h8v av = k < NJ ? ahv : alv;
+          asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(av), "v"(fw[j]));
+          if (i + 1 < MI && k >= 1 && k - 1 < 16) split_op(k - 1, raw[(i + 1) & 1], hi[(i + 1) & 1], lo[(i + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    {
+      int t = 0;
+      for (; t + 2 < T; ++t) step(t, std::true_type{}, std::true_type{});
+      step(t, std::false_type{}, std::true_type{});       // t = T - 2 (T >= 2: the host's rule)
+      step(t + 1, std::false_type{}, std::false_type{});
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (the last MFMAs' results before the epilogue reads them: inline-asm MFMAs are outside the compiler's hazard model)
+  } else {
   issue(0);
   for (int t = 0; t < T; ++t) {
     if (!(GEMM_DBG(P) & 8)) {
@@ -273,6 +350,8 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
     }
   }
 
+  }  // LOOP == 0
+
   // ---- epilogue.  C[row 16 i + 4 lq + r][col 16 j + l15]
   if (GEMM_DBG(P) & 1) {
 #pragma unroll
@@ -314,81 +393,106 @@ __global__ __launch_bounds__(256, (MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(c
         const char* ybase = g.y != nullptr ? reinterpret_cast<const char*>(g.y + (long)(m0 + 16 * MI * wm) * y_ld + (n - sg * P.E)) : nullptr;
         const unsigned y_voff = (unsigned)((4 * lq) * y_ld + l15) * 4u;
         const bool idx_r = g.out != nullptr && !g.transpose, idx_c = g.out != nullptr && g.transpose;
+        // the column tile's forms - values or not, index bytes row-major / transposed / none - are wave-uniform: ONE dispatch per column tile into a body
+        // compiled for the form (round 5: the tests sat inside the row-block loop - ~290 scalar branches per wave in an epilogue that a single wave per
+        // SIMD runs at the latency of its branches)
+        auto body = [&](auto values_, auto idxr_, auto idxc_) {
+          const bool VALUES = values_, IDXR = idxr_, IDXC = idxc_;   // (std::true_type / false_type: folded at compile time; plain bools: the int8 form keeps ONE body)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          unsigned word = 0;
-          const int rl = 16 * MI * wm + 16 * i + 4 * lq;  // tile-local first row of the lane's four
-          if (ybase != nullptr) {
-            const bool rows_in = m0 + 16 * MI * wm + 16 * i < P.M && !(GEMM_DBG(P) & 16);  // (M % 16 == 0: a 16-row tile is inside or outside as a whole)
+          for (int i = 0; i < MI; ++i) {
+            unsigned word = 0;
+            const int rl = 16 * MI * wm + 16 * i + 4 * lq;  // tile-local first row of the lane's four
+            if (VALUES) {
+              const bool rows_in = m0 + 16 * MI * wm + 16 * i < P.M && !(GEMM_DBG(P) & 16);  // (M % 16 == 0: a 16-row tile is inside or outside as a whole)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float rel = fq_rel(__builtin_fmaf(accv(i, r), alpha, bia), f);
-              word = __builtin_amdgcn_cvt_pk_u8_f32(rel + f.zp, r, word);
-              if (rows_in) store_wt4_s(ybase + (long)(16 * i + r) * y_ld * 4, y_voff, f.scale * rel);
+              for (int r = 0; r < 4; ++r) {
+                const float rel = fq_rel(__builtin_fmaf(accv(i, r), alpha, bia), f);
+                word = __builtin_amdgcn_cvt_pk_u8_f32(rel + f.zp, r, word);
+                if (rows_in) store_wt4_s(ybase + (long)(16 * i + r) * y_ld * 4, y_voff, f.scale * rel);
+              }
+            } else {
+              // (no values wanted: the conversion's saturation to [0, 255] is the clamp)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                word = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fq_quot(__builtin_fmaf(accv(i, r), alpha, bia), f)) + f.zp, r, word);
             }
-          } else {
-            // (no values wanted: the conversion's saturation to [0, 255] is the clamp)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              word = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fq_quot(__builtin_fmaf(accv(i, r), alpha, bia), f)) + f.zp, r, word);
+            word ^= 0x80808080u;
+            if (IDXC) *reinterpret_cast<unsigned*>(img_c + (nl + l15) * G_PITCH_C + rl) = word;
+            if (IDXR) {
+              // 4 x 4 byte transpose inside the quad of lanes (columns 4 a4 .. 4 a4 + 3): lane c4 ends with row rl + c4, four columns
+              const unsigned t0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0x00, 0xf, 0xf, false);
+              const unsigned t1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0x55, 0xf, 0xf, false);
+              const unsigned t2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0xaa, 0xf, 0xf, false);
+              const unsigned t3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0xff, 0xf, 0xf, false);
+              const unsigned lo2 = __builtin_amdgcn_perm(t1, t0, sel_t), hi2 = __builtin_amdgcn_perm(t3, t2, sel_t);
+              *reinterpret_cast<unsigned*>(img_r + (rl + c4) * GBN + nl + 4 * a4) = __builtin_amdgcn_perm(hi2, lo2, 0x05040100u);
+            }
           }
-          word ^= 0x80808080u;
-          if (idx_c) *reinterpret_cast<unsigned*>(img_c + (nl + l15) * G_PITCH_C + rl) = word;
-          if (idx_r) {
-            // 4 x 4 byte transpose inside the quad of lanes (columns 4 a4 .. 4 a4 + 3): lane c4 ends with row rl + c4, four columns
-            const unsigned t0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0x00, 0xf, 0xf, false);
-            const unsigned t1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0x55, 0xf, 0xf, false);
-            const unsigned t2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0xaa, 0xf, 0xf, false);
-            const unsigned t3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0xff, 0xf, 0xf, false);
-            const unsigned lo2 = __builtin_amdgcn_perm(t1, t0, sel_t), hi2 = __builtin_amdgcn_perm(t3, t2, sel_t);
-            *reinterpret_cast<unsigned*>(img_r + (rl + c4) * GBN + nl + 4 * a4) = __builtin_amdgcn_perm(hi2, lo2, 0x05040100u);
-          }
-        }
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        if constexpr (AM == A_I8) body(ybase != nullptr, idx_r, idx_c);   // (five bodies per column tile spill the 128 x 288 int8 form's scalar registers)
+        else if (ybase != nullptr) {
+          if (idx_r) body(T_{}, T_{}, F_{});
+          else if (idx_c) body(T_{}, F_{}, T_{});
+          else body(T_{}, F_{}, F_{});
+        } else if (idx_r) body(F_{}, T_{}, F_{});
+        else if (idx_c) body(F_{}, F_{}, T_{});
       }
     }
     barrier_mem();
     if (GEMM_DBG(P) & 32) return;
+    // The three segments' output pointers and layouts in scalar registers, selected per piece (round 5: the loops below indexed P.seg[] with a per-lane
+    // segment number - a dependent vector load of the descriptor from the kernel-argument segment in front of every store: 18 round trips per thread,
+    // 4.6-5.9 us of the launch).
+    signed char* const so0 = P.seg[0].out; signed char* const so1 = P.seg[1].out; signed char* const so2 = P.seg[2].out;
+    const bool st0 = P.seg[0].transpose != 0, st1 = P.seg[1].transpose != 0, st2 = P.seg[2].transpose != 0;
     // plain segments: BM rows x BN / 16 pieces, consecutive threads on consecutive pieces of a row
-    for (int e = tid; e < GBM * (GBN / 16); e += 256) {
-      const int row = e / (GBN / 16), c16 = e - row * (GBN / 16);
-      const int n = n0 + 16 * c16, m = m0 + row;
-      if (n < P.N && m < P.M) {
+    if ((so0 != nullptr && !st0) || (so1 != nullptr && !st1) || (so2 != nullptr && !st2)) {
+#pragma unroll
+      for (int it = 0; it < (GBM * (GBN / 16) + 255) / 256; ++it) {
+        const int e = tid + 256 * it;
+        const int row = e / (GBN / 16), c16 = e - row * (GBN / 16);
+        const int n = n0 + 16 * c16, m = m0 + row;
         const int sg = (n >= P.E) + (n >= 2 * P.E);
-        const GemmSeg& g = P.seg[sg];
-        if (g.out != nullptr && !g.transpose)
-          *reinterpret_cast<u4*>(g.out + (long)m * P.E + (n - sg * P.E)) = *reinterpret_cast<const u4*>(img_r + row * GBN + 16 * c16);
+        signed char* const so = sg == 0 ? so0 : sg == 1 ? so1 : so2;
+        const bool tr = sg == 0 ? st0 : sg == 1 ? st1 : st2;
+        if (e < GBM * (GBN / 16) && n < P.N && m < P.M && so != nullptr && !tr)
+          store_wt16(so + (long)m * P.E + (n - sg * P.E), *reinterpret_cast<const u4*>(img_r + row * GBN + 16 * c16));   // (write-through, as the values: see store_wt4_s)
       }
     }
     // transposed segments: BN columns x BM / 16 pieces of 16 rows (= 16 keys of one batch element: S % 16 == 0)
-    for (int e = tid; e < GBN * (GBM / 16); e += 256) {
-      const int col = e / (GBM / 16), pc = e - col * (GBM / 16);
-      const int n = n0 + col, m = m0 + 16 * pc;
-      if (n < P.N && m < P.M) {
+    if ((so0 != nullptr && st0) || (so1 != nullptr && st1) || (so2 != nullptr && st2)) {
+#pragma unroll
+      for (int it = 0; it < (GBN * (GBM / 16) + 255) / 256; ++it) {
+        const int e = tid + 256 * it;
+        const int col = e / (GBM / 16), pc = e - col * (GBM / 16);
+        const int n = n0 + col, m = m0 + 16 * pc;
         const int sg = (n >= P.E) + (n >= 2 * P.E);
-        const GemmSeg& g = P.seg[sg];
-        if (g.out != nullptr && g.transpose) {
+        signed char* const so = sg == 0 ? so0 : sg == 1 ? so1 : so2;
+        const bool tr = sg == 0 ? st0 : sg == 1 ? st1 : st2;
+        if (e < GBN * (GBM / 16) && n < P.N && m < P.M && so != nullptr && tr) {
           const int ns = n - sg * P.E;
           int bidx, srow;
           div_magic((unsigned)m, (unsigned)P.S, P.magic_s, bidx, srow);
-          *reinterpret_cast<u4*>(g.out + (((long)bidx * P.H + (ns >> 6)) * 64 + (ns & 63)) * P.S + srow) =
-              *reinterpret_cast<const u4*>(img_c + col * G_PITCH_C + 16 * pc);
+          store_wt16(so + (((long)bidx * P.H + (ns >> 6)) * 64 + (ns & 63)) * P.S + srow, *reinterpret_cast<const u4*>(img_c + col * G_PITCH_C + 16 * pc));
         }
       }
     }
   }
 }
 
-template <int AM, int MI, int NJ>
+template <int AM, int MI, int NJ, int LOOP = 0>
 static int launch_gemm_t(const GemmParams& P, hipStream_t st) {
   static bool attr[64] = {};   // (the LDS opt-in is per device: a process that drives several GPUs sets it on each)
-  const int ldsb = Geo<MI, NJ>::LDS;
+  const int ldsb = LOOP == 1 ? Geo<MI, NJ>::LDS3 : Geo<MI, NJ>::LDS;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -5;
   if (!attr[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&oeh_gemm_kernel<AM, MI, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return -5;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&oeh_gemm_kernel<AM, MI, NJ, LOOP>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return -5;
     attr[dev] = true;
   }
-  hipLaunchKernelGGL((oeh_gemm_kernel<AM, MI, NJ>), dim3(P.MT * P.NT), dim3(256), ldsb, st, P);
+  hipLaunchKernelGGL((oeh_gemm_kernel<AM, MI, NJ, LOOP>), dim3(P.MT * P.NT), dim3(256), ldsb, st, P);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
@@ -418,6 +522,12 @@ int launch_gemm(const GemmParams& P0, hipStream_t st) {
   if (big) {
     P.MT = (P.M + 127) / 128; P.NT = (P.N + 287) / 288;
     return P.pairs == 3 ? launch_gemm_t<A_I8, 4, 9>(P, st) : P.pairs == 2 ? launch_gemm_t<A_F32, 4, 9>(P, st) : P.pairs ? launch_gemm_t<A_PAIRS, 4, 9>(P, st) : launch_gemm_t<A_F16, 4, 9>(P, st);
+  }
+  // fp32 activations, 128 x 288 tiles for at most one workgroup per CU (BERT-base: M = 4096 -> 256 tiles): the one-workgroup-per-CU loop (LOOP == 1):
+  // 64 x 192 tiles would re-read A twelve and W sixty-four times; OEH_GEMM_TILE = 2 keeps the small tile (A/B)
+  if (P.pairs == 2 && !force && t0 >= 160 && t0 <= 256 && waste0 <= 1.06 && P.K >= 64) {
+    P.MT = (P.M + 127) / 128; P.NT = (P.N + 287) / 288;
+    return launch_gemm_t<A_F32, 4, 9, 1>(P, st);
   }
   P.MT = (P.M + 63) / 64; P.NT = (P.N + 191) / 192;
   return P.pairs == 3 ? launch_gemm_t<A_I8, 2, 6>(P, st) : P.pairs == 2 ? launch_gemm_t<A_F32, 2, 6>(P, st) : P.pairs ? launch_gemm_t<A_PAIRS, 2, 6>(P, st) : launch_gemm_t<A_F16, 2, 6>(P, st);

@@ -21,7 +21,7 @@ def _grid(v64):
 
 
 @pytest.mark.parametrize("B,S,H,K,want", [(16, 512, 12, 768, True), (4, 128, 12, 768, False), (3, 48, 2, 64, True), (5, 80, 12, 768, True), (2, 16, 1, 32, True),
-                                          (7, 144, 5, 320, False)])
+                                          (7, 144, 5, 320, False), (32, 128, 12, 768, True), (25, 160, 12, 64, False)])   # (the last two: one 128 x 288 tile per CU - the LOOP == 1 kernel; ragged rows, two K steps)
 def test_pair_gemm_with_quantiser_epilogue_vs_exact_arithmetic(B, S, H, K, want):
     """fp32 activations as operand pairs: every index within one step of the exact one and all but a few in 10^5 equal to it
     (the value sits on a rounding boundary to within the fp32 accumulation error: the library GEMM + quantiser pass it replaces
@@ -149,7 +149,7 @@ def test_fp32_activations_of_any_magnitude_vs_exact_arithmetic(mag):
     from outeffhop_amd import ops
 
     torch.manual_seed(int(mag * 1e4) + 3)
-    B, S, H, K = 4, 256, 12, 768
+    B, S, H, K = (4, 256, 12, 768) if mag != 0.05 else (32, 128, 12, 768)   # (one case on the one-workgroup-per-CU kernel)
     E, M = H * 64, B * S
     x = (torch.randn(M, K, device="cuda") * mag).clamp_(-2040.0, 2040.0)
     wi = torch.randint(-128, 128, (3 * E, K), device="cuda").to(torch.float16)
@@ -167,7 +167,7 @@ def test_fp32_activations_of_any_magnitude_vs_exact_arithmetic(mag):
         assert int(d.max()) <= 1 and rate <= (3e-5 if mag >= 1e-3 else 3e-4)   # (|x| ~ 1e-4 is 5 bits below 2^-8: 17 bits)
 
 
-@pytest.mark.parametrize("B,S,H,K", [(16, 512, 12, 768), (4, 128, 12, 768), (3, 48, 2, 64), (5, 80, 12, 768)])
+@pytest.mark.parametrize("B,S,H,K", [(16, 512, 12, 768), (4, 128, 12, 768), (3, 48, 2, 64), (5, 80, 12, 768), (32, 128, 12, 768), (25, 160, 12, 96)])
 def test_fp32_activations_split_inside_the_kernel_equal_the_operand_pairs(B, S, H, K):
     """`a` as the fp32 activation matrix (split into fp16 operands when a wave reads its fragments) against the same call on `oeh_split_pairs`'
     output.  Round 5: the in-kernel split keeps the residual UNSCALED, on 32 x (oeh_common.h: split8_raw_scaled - the matrix core takes fp16 subnormals

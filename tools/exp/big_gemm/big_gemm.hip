@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void big_gemm_pairs_kernel(const BigP P) {
   f4 raw[2][2];
   unsigned hi[2][4], lo[2][4];
   h8v fw[NJ];
-  static_assert(R == 3 && NQ <= 16 && MI == 8, "ring of three; pieces over the eight groups");
+  static_assert(R == 3 && NQ <= 16, "ring of three; pieces over the MI groups");
   constexpr int PPG = (NQ + MI - 1) / MI;   // pieces per group (2), the first groups
 
   issue_piece(0, 0);
@@ -414,9 +414,10 @@ extern "C" int big_gemm_f16(const void* a, const void* w, const float* bias, voi
   return (int)hipGetLastError();
 }
 
-extern "C" int big_gemm_pairs(const float* a, const void* w, const float* bias, void* c, int M, int N, int K, long lda, long ldw, long ldc, float alpha, void* stream) {
+template <int MI>
+static int big_gemm_pairs_t(const float* a, const void* w, const float* bias, void* c, int M, int N, int K, long lda, long ldw, long ldc, float alpha, void* stream) {
   using namespace oeh;
-  constexpr int MI = 8, NJ = 9, R = 3;
+  constexpr int NJ = 9, R = 3;
   BigP P;
   P.a = a; P.w = w; P.bias = bias; P.c = c; P.lda = lda; P.ldw = ldw; P.ldc = ldc; P.M = M; P.N = N; P.K = K; P.bf16 = 0; P.dbg = 0; P.alpha = alpha;
   P.MT = (M + 32 * MI - 1) / (32 * MI); P.NT = (N + 32 * NJ - 1) / (32 * NJ);
@@ -426,4 +427,10 @@ extern "C" int big_gemm_pairs(const float* a, const void* w, const float* bias, 
   if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(&big_gemm_pairs_kernel<MI, NJ, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); once = true; }
   hipLaunchKernelGGL((big_gemm_pairs_kernel<MI, NJ, R>), dim3(P.MT * P.NT), dim3(256), ldsb, reinterpret_cast<hipStream_t>(stream), P);
   return (int)hipGetLastError();
+}
+extern "C" int big_gemm_pairs(const float* a, const void* w, const float* bias, void* c, int M, int N, int K, long lda, long ldw, long ldc, float alpha, void* stream) {
+  return big_gemm_pairs_t<8>(a, w, bias, c, M, N, K, lda, ldw, ldc, alpha, stream);
+}
+extern "C" int big_gemm_pairs_m4(const float* a, const void* w, const float* bias, void* c, int M, int N, int K, long lda, long ldw, long ldc, float alpha, void* stream) {
+  return big_gemm_pairs_t<4>(a, w, bias, c, M, N, K, lda, ldw, ldc, alpha, stream);
 }

@@ -61,7 +61,9 @@ for (M, N, K) in shapes:
 
 lib.big_gemm_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, C.c_float, C.c_void_p]
 lib.big_gemm_pairs.restype = C.c_int
-for (M, N, K) in [(8192, 2304, 768), (4096, 2304, 768)]:
+lib.big_gemm_pairs_m4.argtypes = lib.big_gemm_pairs.argtypes
+lib.big_gemm_pairs_m4.restype = C.c_int
+for (M, N, K, fn_) in [(8192, 2304, 768, lib.big_gemm_pairs), (4096, 2304, 768, lib.big_gemm_pairs), (4096, 2304, 768, lib.big_gemm_pairs_m4), (8192, 2304, 768, lib.big_gemm_pairs_m4)]:
     torch.manual_seed(1)
     x = torch.randn(M, K, device="cuda")
     x[:, ::37] *= 30.0
@@ -71,7 +73,7 @@ for (M, N, K) in [(8192, 2304, 768), (4096, 2304, 768)]:
     alpha = 0.003
 
     def mine2():
-        rc = lib.big_gemm_pairs(x.data_ptr(), wi.data_ptr(), bias.data_ptr(), c.data_ptr(), M, N, K, K, K, N, alpha, torch.cuda.current_stream().cuda_stream)
+        rc = fn_(x.data_ptr(), wi.data_ptr(), bias.data_ptr(), c.data_ptr(), M, N, K, K, K, N, alpha, torch.cuda.current_stream().cuda_stream)
         assert rc == 0, rc
 
     mine2()
@@ -79,4 +81,4 @@ for (M, N, K) in [(8192, 2304, 768), (4096, 2304, 768)]:
     ref = (x.double() @ wi.double().t()) * alpha + bias.double()
     err = ((c.double() - ref).abs() / (ref.abs() + 1.0)).max().item()
     t1 = timed(mine2)
-    print(f"pairs M={M} N={N} K={K}: big_gemm_pairs {t1:.1f} us ({4 * M * N * K / t1 / 1e9:.2f} PFLOP/s executed); max rel err of the fp16 output {err:.3e}", flush=True)
+    print(f"pairs M={M} N={N} K={K} [{'128 x 288' if fn_ is lib.big_gemm_pairs_m4 else '256 x 288'}]: big_gemm_pairs {t1:.1f} us ({4 * M * N * K / t1 / 1e9:.2f} PFLOP/s executed); max rel err of the fp16 output {err:.3e}", flush=True)
