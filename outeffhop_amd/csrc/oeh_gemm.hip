@@ -82,16 +82,17 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 // sixteen lanes of a group then hit sixteen different 16-byte bank groups, for both reads of a fragment
 __device__ __forceinline__ int swz32(int row) { return (int)((0x31765420u >> (4 * ((row >> 1) & 7))) & 7u); }
 
-// LOOP == 1 (round 5; fp32 activations, 128 x 288 tile): the K loop for launches that give a CU ONE workgroup - fewer than ~300 tiles, BERT-base's M = 4096:
-// 256 - where each SIMD has a single wave and nothing hides what that wave waits for.  Ring of three slots (tile t + 2 requested during step t, counted
-// wait), fragment-major groups (A fragment i against the NJ W fragments: 2 NJ MFMAs) with the LDS-DMA requests, the reads of fragment i + 2 and the split
+// LOOP != 0 (round 5; fp32 activations, 128 x 288 tile): the pipelined K loop.  LOOP == 1: launches that give a CU ONE workgroup - 160-256 tiles, BERT-base's
+// M = 4096: 256 - where each SIMD has a single wave and nothing hides what that wave waits for: ring of THREE slots (tile t + 2 requested during step t, counted
+// wait).  LOOP == 2: the same body on the ring of two with two workgroups per CU (the OPT shape's 512 tiles: 0.97 of the round-4 loop, same box).  Fragment-major groups (A fragment i against the NJ W fragments: 2 NJ MFMAs) with the LDS-DMA requests, the reads of fragment i + 2 and the split
 // of fragment i + 1 - one v_fma_mix instruction at a time - placed BETWEEN the MFMAs by construction (inline-asm MFMAs: volatile statements keep their
 // order); one wait + barrier per step.  tools/exp/big_gemm (profiles/r05_big_tile_gemm_experiment.txt) is where the structure was measured first.
 template <int AM, int MI, int NJ, int LOOP = 0>
-__global__ __launch_bounds__(256, (LOOP == 1 ? 1 : MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(const GemmParams P) {
+__global__ __launch_bounds__(256, (LOOP == 1 ? 1 : MI * NJ > 16 ? 2 : 4)) void oeh_gemm_kernel(const GemmParams P) {   // (LOOP == 2: A/B form - the LOOP == 1 body on a ring of two, two workgroups per CU)
   typedef Geo<MI, NJ> G;
   static_assert(LOOP == 0 || (AM == A_F32 && MI == 4), "the one-workgroup-per-CU loop: fp32 activations, four row blocks per wave");
   constexpr int RING = LOOP == 1 ? 3 : 2;
+  constexpr bool PIPE = LOOP != 0;
   constexpr bool PAIRS = AM == A_PAIRS || AM == A_F32;   // two MFMA products per term: (hi, lo) of fp32 activations
   constexpr int EB = AM == A_I8 ? 1 : 2;               // bytes per element of a and w (a K step is 64 bytes of a row either way)
 #ifndef OEH_GEMM_KPRE
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256, (LOOP == 1 ? 1 : MI * NJ > 16 ? 2 : 4)) void o
   unsigned voff[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const int p = LOOP == 1 ? min(4 * q + wave, NP - 1) : 4 * q + wave;   // (LOOP == 1: the last round repeats piece NP - 1 - every wave issues NQ requests per tile)
+    const int p = PIPE ? min(4 * q + wave, NP - 1) : 4 * q + wave;   // (LOOP == 1: the last round repeats piece NP - 1 - every wave issues NQ requests per tile)
     if (q < QL) {
       if constexpr (AM == A_F32) {
         // fp32 rows of 128 B (32 values = one K step): a piece = 8 rows, lane -> row 8 p + (lane >> 3), stored chunk lane & 7 = logical
@@ -159,11 +160,11 @@ __global__ __launch_bounds__(256, (LOOP == 1 ? 1 : MI * NJ > 16 ? 2 : 4)) void o
   auto issue_q = [&](int t, int q) {
     const unsigned slot = lds_base + (unsigned)((RING == 2 ? (t & 1) : t % 3) * G_SLOT);
     const long kb = (long)t * (GBK * 2);
-    const int p = LOOP == 1 ? min(4 * q + wave, NP - 1) : 4 * q + wave;
+    const int p = PIPE ? min(4 * q + wave, NP - 1) : 4 * q + wave;
     if (AM == A_F32 && q < QL) glds16_s(ab + 2 * kb, voff[q], slot + G_AHI + p * 1024);
     else if (q < QA) glds16_s(ab + kb, voff[q], slot + G_AHI + p * 1024);
     else if (q < QL) glds16_s(ab + (long)P.K * 2 + kb, voff[q], slot + G_ALO + (p - NPA) * 1024);
-    else if (LOOP == 1 || q < NQ - 1 || wave < NP - 4 * (NQ - 1)) glds16_s(wb + kb, voff[q], __builtin_amdgcn_readfirstlane(slot + G_W + (p - QL * 4) * 1024));
+    else if (PIPE || q < NQ - 1 || wave < NP - 4 * (NQ - 1)) glds16_s(wb + kb, voff[q], __builtin_amdgcn_readfirstlane(slot + G_W + (p - QL * 4) * 1024));
   };
   auto issue = [&](int t) {
 #pragma unroll
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256, (LOOP == 1 ? 1 : MI * NJ > 16 ? 2 : 4)) void o
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-  if constexpr (LOOP == 1) {
+  if constexpr (PIPE) {
     constexpr int PPG = (NQ + MI - 1) / MI;   // requests per group, the first groups
     f4 raw[2][2];
     unsigned hi[2][4], lo[2][4];
@@ -209,14 +210,14 @@ __global__ __launch_bounds__(256, (LOOP == 1 ? 1 : MI * NJ > 16 ? 2 : 4)) void o
       }
     };
     issue(0);
-    if (T > 1) issue(1);
+    if (RING == 3 && T > 1) issue(1);
     auto step = [&](int t, auto dma_, auto w1_) {
       constexpr bool DMA = decltype(dma_)::value;
       // tile t has landed (the NQ requests of tile t + 1 may be in flight) - for every wave, and every wave has left tile t - 1: its slot takes tile t + 2
       if constexpr (decltype(w1_)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       barrier_mem();
-      const unsigned char* sl = lds + (t % 3) * G_SLOT;
+      const unsigned char* sl = lds + (RING == 2 ? (t & 1) : t % 3) * G_SLOT;
       read_raw(sl, 0, raw[0]);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) fw[j] = *reinterpret_cast<const h8v*>(sl + w_off + j * 16 * GROWB);
@@ -226,10 +227,12 @@ __global__ __launch_bounds__(256, (LOOP == 1 ? 1 : MI * NJ > 16 ? 2 : 4)) void o
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        if constexpr (DMA) {
+        // the group's LDS-DMA requests: with two waves per SIMD (LOOP == 2) in front of its MFMAs - the other wave keeps the matrix core busy; with ONE wave
+        // per SIMD (LOOP == 1) one at a time behind MFMAs 1, 7 and 13 (same box: 59.9 vs 61.0 us the first way at the OPT shape, 34.9 vs 35.1 the second at BERT-base's)
+        if constexpr (DMA && LOOP == 2) {
 #pragma unroll
           for (int u = 0; u < PPG; ++u)
-            if (PPG * i + u < NQ) issue_q(t + 2, PPG * i + u);
+            if (PPG * i + u < NQ) issue_q(t + RING - 1, PPG * i + u);
         }
         if (i + 2 < MI) read_raw(sl, i + 2, raw[i & 1]);
         const h8v ahv = __builtin_bit_cast(h8v, u4{hi[i & 1][0], hi[i & 1][1], hi[i & 1][2], hi[i & 1][3]});
@@ -240,15 +243,23 @@ __global__ __launch_bounds__(256, (LOOP == 1 ? 1 : MI * NJ > 16 ? 2 : 4)) void o
           const h8v av = k < NJ ? ahv : alv;
           asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(av), "v"(fw[j]));
           if (i + 1 < MI && k >= 1 && k - 1 < 16) split_op(k - 1, raw[(i + 1) & 1], hi[(i + 1) & 1], lo[(i + 1) & 1]);
+          if constexpr (DMA && LOOP == 1) {
+            if (k % 6 == 1 && k / 6 < PPG && PPG * i + k / 6 < NQ) issue_q(t + RING - 1, PPG * i + k / 6);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
     {
       int t = 0;
-      for (; t + 2 < T; ++t) step(t, std::true_type{}, std::true_type{});
-      step(t, std::false_type{}, std::true_type{});       // t = T - 2 (T >= 2: the host's rule)
-      step(t + 1, std::false_type{}, std::false_type{});
+      if constexpr (RING == 3) {
+        for (; t + 2 < T; ++t) step(t, std::true_type{}, std::true_type{});
+        step(t, std::false_type{}, std::true_type{});       // t = T - 2 (T >= 2: the host's rule)
+        step(t + 1, std::false_type{}, std::false_type{});
+      } else {
+        for (; t + 1 < T; ++t) step(t, std::true_type{}, std::false_type{});
+        step(t, std::false_type{}, std::false_type{});
+      }
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (the last MFMAs' results before the epilogue reads them: inline-asm MFMAs are outside the compiler's hazard model)
   } else {
@@ -519,9 +530,11 @@ int launch_gemm(const GemmParams& P0, hipStream_t st) {
   const long t0 = (long)((P.M + 127) / 128) * ((P.N + 287) / 288);
   const double waste0 = (double)t0 * 128.0 * 288.0 / ((double)P.M * (double)P.N);
   const bool big = force ? force == 1 : (t0 >= 512 && waste0 <= 1.06);
+  // fp32 activations on the 128 x 288 tile: the pipelined body (LOOP == 2: ring of two, two workgroups per CU; OEH_GEMM_LOOP0 = 1 keeps the round-4 loop for A/B)
+  static const int loop0 = [] { const char* e = getenv("OEH_GEMM_LOOP0"); return e ? atoi(e) : 0; }() * (hooks ? 1 : 0);
   if (big) {
     P.MT = (P.M + 127) / 128; P.NT = (P.N + 287) / 288;
-    return P.pairs == 3 ? launch_gemm_t<A_I8, 4, 9>(P, st) : P.pairs == 2 ? launch_gemm_t<A_F32, 4, 9>(P, st) : P.pairs ? launch_gemm_t<A_PAIRS, 4, 9>(P, st) : launch_gemm_t<A_F16, 4, 9>(P, st);
+    return P.pairs == 3 ? launch_gemm_t<A_I8, 4, 9>(P, st) : P.pairs == 2 ? (loop0 ? launch_gemm_t<A_F32, 4, 9>(P, st) : launch_gemm_t<A_F32, 4, 9, 2>(P, st)) : P.pairs ? launch_gemm_t<A_PAIRS, 4, 9>(P, st) : launch_gemm_t<A_F16, 4, 9>(P, st);
   }
   // fp32 activations, 128 x 288 tiles for at most one workgroup per CU (BERT-base: M = 4096 -> 256 tiles): the one-workgroup-per-CU loop (LOOP == 1):
   // 64 x 192 tiles would re-read A twelve and W sixty-four times; OEH_GEMM_TILE = 2 keeps the small tile (A/B)
