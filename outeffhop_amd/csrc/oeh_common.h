@@ -332,7 +332,7 @@ __device__ __forceinline__ void load8_split(const void* base, long elem_off, u4&
 // issued (measured: SQ_WAIT_ANY 54 % of wave cycles).  Invisible to the compiler, the transfers are ordered only by
 // the caller's counted `s_waitcnt vmcnt(N)` + s_barrier, as intended.  M0 (the LDS destination base) is saved and
 // restored inside the statement; `lds_addr` must be wave-uniform.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+__device__ __forceinline__ void glds16_keep(const void* gsrc, unsigned lds_addr) {
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
@@ -347,7 +347,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
 // The same transfer in scalar-base form: address = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit BYTE offset.
 // A tile stream then advances the scalar base and keeps the lane offsets constant: no per-tile vector address math and
 // half the address registers.  Lane offsets must stay below 4 GiB from the base (checked on the host).
-__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) {
+__device__ __forceinline__ void glds16_s_keep(const void* sbase, unsigned voff, unsigned lds_addr) {
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
@@ -359,7 +359,21 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
       : "v"(voff), "s"(sbase), "s"(lds_addr)
       : "memory");
 }
-__device__ __forceinline__ void glds16_s_nt(const void* sbase, unsigned voff, unsigned lds_addr) {
+// ... without saving / restoring M0 around the request (two scalar instructions less per request): for kernels whose code the compiler never gives M0
+// to (no indirect register indexing, no GWS / message instructions: the projection GEMM's loops) - M0 is declared clobbered
+__device__ __forceinline__ void glds16_s_m0(const void* sbase, unsigned voff, unsigned lds_addr) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff), "s"(sbase), "s"(lds_addr)
+      : "memory", "m0");
+#pragma clang diagnostic pop
+}
+__device__ __forceinline__ void glds16_s_nt_keep(const void* sbase, unsigned voff, unsigned lds_addr) {
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
@@ -371,6 +385,26 @@ __device__ __forceinline__ void glds16_s_nt(const void* sbase, unsigned voff, un
       : "v"(voff), "s"(sbase), "s"(lds_addr)
       : "memory");
 }
+// Round 5: the requests WITHOUT the save / restore of M0 (glds16_s_m0 above: M0 declared clobbered, two scalar instructions less per request) in every kernel;
+// -DOEH_KEEP_M0 builds keep the guarded forms (A/B: profiles/r05_m0_ab.txt).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void glds16_m0(const void* gsrc, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ void glds16_s_nt_m0(const void* sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+#ifdef OEH_KEEP_M0
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) { glds16_keep(gsrc, lds_addr); }
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) { glds16_s_keep(sbase, voff, lds_addr); }
+__device__ __forceinline__ void glds16_s_nt(const void* sbase, unsigned voff, unsigned lds_addr) { glds16_s_nt_keep(sbase, voff, lds_addr); }
+#else
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) { glds16_m0(gsrc, lds_addr); }
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) { glds16_s_m0(sbase, voff, lds_addr); }
+__device__ __forceinline__ void glds16_s_nt(const void* sbase, unsigned voff, unsigned lds_addr) { glds16_s_nt_m0(sbase, voff, lds_addr); }
+#endif
 // Output stores are WRITE-THROUGH (sc0 sc1).  A plain store leaves the line dirty in the XCD's L2; the whole output
 // (12.6 MB per OPT-125m launch, 1.6 MB per XCD: it all fits) then goes to memory in the end-of-kernel release, after
 // the last wave, where nothing overlaps it: measured 18.97 -> 16.2 us per launch on the headline workload (`nt` alone:

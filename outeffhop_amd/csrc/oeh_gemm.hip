@@ -48,6 +48,7 @@ __device__ __forceinline__ void store_wt4_s(const void* sbase, unsigned voff, fl
 }
 
 constexpr int GBK = kGemmBK, GROWB = 64;
+#define GLDS glds16_s   // (oeh_common.h: without the save / restore of M0 unless -DOEH_KEEP_M0)
 constexpr int kPer = 2;  // LDS-DMA pieces issued behind each of the first MFMA groups of a step (3 and 5 measured the same or slower)
 
 // activation forms: fp16 values; fp16 operand pairs [hi | lo] (oeh_split_pairs); fp32 values, split into (hi, lo) when a wave reads its
@@ -161,10 +162,10 @@ __global__ __launch_bounds__(256, (LOOP == 1 ? 1 : MI * NJ > 16 ? 2 : 4)) void o
     const unsigned slot = lds_base + (unsigned)((RING == 2 ? (t & 1) : t % 3) * G_SLOT);
     const long kb = (long)t * (GBK * 2);
     const int p = PIPE ? min(4 * q + wave, NP - 1) : 4 * q + wave;
-    if (AM == A_F32 && q < QL) glds16_s(ab + 2 * kb, voff[q], slot + G_AHI + p * 1024);
-    else if (q < QA) glds16_s(ab + kb, voff[q], slot + G_AHI + p * 1024);
-    else if (q < QL) glds16_s(ab + (long)P.K * 2 + kb, voff[q], slot + G_ALO + (p - NPA) * 1024);
-    else if (PIPE || q < NQ - 1 || wave < NP - 4 * (NQ - 1)) glds16_s(wb + kb, voff[q], __builtin_amdgcn_readfirstlane(slot + G_W + (p - QL * 4) * 1024));
+    if (AM == A_F32 && q < QL) GLDS(ab + 2 * kb, voff[q], slot + G_AHI + p * 1024);
+    else if (q < QA) GLDS(ab + kb, voff[q], slot + G_AHI + p * 1024);
+    else if (q < QL) GLDS(ab + (long)P.K * 2 + kb, voff[q], slot + G_ALO + (p - NPA) * 1024);
+    else if (PIPE || q < NQ - 1 || wave < NP - 4 * (NQ - 1)) GLDS(wb + kb, voff[q], __builtin_amdgcn_readfirstlane(slot + G_W + (p - QL * 4) * 1024));
   };
   auto issue = [&](int t) {
 #pragma unroll
