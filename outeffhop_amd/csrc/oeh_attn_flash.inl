@@ -455,6 +455,14 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     constexpr int J0 = decltype(j0c)::value;
     constexpr bool FIRST = decltype(firstc)::value;  // tile 0: V tile 0 is awaited between the two products
     constexpr int MODE = decltype(modec)::value;
+    // Round 5: the plain one-pass tile on 16-bit storage, tiles after the first: the exponentials in two halves - keys 0-31 of every block, then the first
+    // half's MFMAs (O^T += V^T P^T over those keys) with the exponentials of keys 32-63 placed BETWEEN them - instead of all 32 v_exp_f32 + 16 conversions
+    // in one lump in front of 20 back-to-back MFMAs (the compiler's schedule; profiles/r05_headline_tile_order.txt).
+#ifdef OEH_NO_PIPE_PV
+    constexpr bool PIPE_PV = false;
+#else
+    constexpr bool PIPE_PV = (MODE == 0) && !SRC32 && !FIRST && D <= 64 && OEH_KO == 0;   // (D = 128: 1.045 of the plain order - one wave per SIMD there, other limits)
+#endif
 #if OEH_KO == 2
     if constexpr (FIRST) {
       if (!GATE && 1 < n_kt) wait_vm(std::integral_constant<int, 2>{});
@@ -696,6 +704,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
           }
         }
       }
+      if constexpr (PIPE_PV) continue;   // (the exponentials follow in two halves, the second one between the first half's MFMAs: below)
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
@@ -724,6 +733,83 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     }
     // O^T += V^T P^T and l += 1^T P^T; every V^T fragment is read once and used by all active blocks
     if constexpr (MODE == 1 || MODE == 3) return;
+    if constexpr (PIPE_PV) {
+      // accumulating MFMA IN PLACE (inline asm, "+v"): from the builtin the register allocator gave the second half's results new registers and copied them
+      // back at the loop's end - ten v_mov_b64 behind waits for the matrix core, per tile.  (Outside the compiler's hazard model: the accumulators are next
+      // read by vector instructions behind the following tile's score MFMAs, or in the epilogue behind the padding after the loop.)
+      auto mfma_acc = [&](f4& acc, const u4 av, const u4 bv) {
+        if constexpr (IN == IN_BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv));
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv));
+      };
+      // e = 0..15: element of the block's score tile.  PLACED (volatile asm keeps its position among the MFMA statements; from the builtin the instruction
+      // selector sinks all of them to their first use behind the last MFMA of the half)
+      auto exp1 = [&](const int j, const int e) { asm volatile("v_exp_f32_e32 %0, %0" : "+v"(s[j][e >> 2][e & 3])); };
+      auto pack_half = [&](const int j, const int u) {
+        const f4 a = s[j][2 * u], bb = s[j][2 * u + 1];
+        if constexpr (IN == IN_BF16) pb[j][u] = u4{pack2_bf16(a[0], a[1]), pack2_bf16(a[2], a[3]), pack2_bf16(bb[0], bb[1]), pack2_bf16(bb[2], bb[3])};
+        else pb[j][u] = u4{pack2_f16(a[0], a[1]), pack2_f16(a[2], a[3]), pack2_f16(bb[0], bb[1]), pack2_f16(bb[2], bb[3])};
+      };
+      auto read_v = [&](const int u, u4 (&va)[DT]) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const unsigned char* a0 = vaddr[dt] + soff + u * 32 * ROWB;
+          const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0));
+          const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + 16 * ROWB));
+          const u2 l2 = __builtin_bit_cast(u2, lo), h2 = __builtin_bit_cast(u2, hi);
+          va[dt] = u4{l2.x, l2.y, h2.x, h2.y};
+        }
+      };
+      constexpr int NB = MQ - J0;              // active blocks
+      // HAZARD RULE of this path (the inline-asm MFMAs are outside the compiler's hazard model): a register an MFMA reads must not have been written by a
+      // vector instruction in the two issue slots in front of it (the compiler keeps that distance for its own MFMAs: the s_nop it puts behind a v_mov of
+      // the ones operand).  The ones operand is therefore materialised HERE (the first half's exponentials lie between it and its first use), the packed P
+      // of a half is followed by the half's V^T reads, and the second half's conversions by an explicit s_nop.  (Found as NaN row sums at MQ == 1.)
+      u4 ones_v = ones;
+      asm volatile("" : "+v"(ones_v));
+      // keys 0-31 of every block: exponentials, packed
+#pragma unroll
+      for (int j = J0; j < MQ; ++j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) exp1(j, e);
+        pack_half(j, 0);
+      }
+      u4 va[DT];
+      read_v(0, va);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 1" ::: "memory");   // (the hazard rule, whatever the scheduler did with the reads above)
+      __builtin_amdgcn_s_setprio(1);
+      // first half's NB (DT + 1) MFMAs, the 8 NB exponentials of keys 32-63 between them (about one per gap: a v_exp_f32 is the 8 issue cycles an MFMA of
+      // this shape leaves), the conversions behind
+      {
+        constexpr int NM = NB * (DT + 1), NE = 8 * NB;          // MFMAs of the half; exponentials to place (block-major: element 8 + (n & 7) of block J0 + n / 8)
+        constexpr int TWO = NE > NM ? NE - NM : 0;              // the first TWO gaps take two exponentials, the others one (all indices below are closed forms of m:
+#pragma unroll                                                   // a running counter would make the score tile a dynamically indexed array - in scratch memory)
+        for (int m = 0; m < NM; ++m) {
+          if (m < NB) mfma_acc(lacc[J0 + m], ones_v, pb[J0 + m][0]);
+          else mfma_acc(o[J0 + (m - NB) % NB][(m - NB) / NB], va[(m - NB) / NB], pb[J0 + (m - NB) % NB][0]);
+          const int first = m < TWO ? 2 * m : TWO + m, cnt = m < TWO ? 2 : 1;
+#pragma unroll
+          for (int q = 0; q < cnt; ++q)
+            if (first + q < NE) exp1(J0 + (first + q) / 8, 8 + ((first + q) & 7));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int n = (NM < TWO ? 2 * NM : TWO + NM); n < NE; ++n) exp1(J0 + n / 8, 8 + (n & 7));   // (whatever is left: none when NE <= 2 NM)
+      }
+#pragma unroll
+      for (int j = J0; j < MQ; ++j) pack_half(j, 1);
+      read_v(1, va);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 1" ::: "memory");   // (the conversions above -> the MFMAs below: the hazard rule)
+#pragma unroll
+      for (int j = J0; j < MQ; ++j) mfma_acc(lacc[j], ones_v, pb[j][1]);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int j = J0; j < MQ; ++j) mfma_acc(o[j][dt], va[dt], pb[j][1]);
+      __builtin_amdgcn_s_setprio(0);
+      return;
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -861,6 +947,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   }
   }
   OEH_STAMP(2);
+#ifndef OEH_NO_PIPE_PV
+  if constexpr (!SRC32 && TP == 0) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // (the in-place MFMAs of the last tile, written as inline asm, against the epilogue's vector reads of their results)
+#endif
 
   // ---- epilogue: denominators and gate, O^T staged through a free LDS stage so that global stores are whole rows
   // (per-lane stores of the MFMA layout would touch 16 rows x 32 B per instruction).  Stage n_kt % R is free: its
