@@ -4,7 +4,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 cd $ROOT
-L=$ROOT/outeffhop_amd/lib/nopipe/liboeh_hip.so
+L=$ROOT/outeffhop_amd/lib/${ALT:-nopipe}/liboeh_hip.so
 mkdir -p gpurun_out/r05_pipe_pv
 {
 python -m pytest tests/test_attn_gpu.py -m gpu -q -x 2>&1 | tail -3
