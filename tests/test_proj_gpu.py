@@ -21,7 +21,7 @@ def _grid(v64):
 
 
 @pytest.mark.parametrize("B,S,H,K,want", [(16, 512, 12, 768, True), (4, 128, 12, 768, False), (3, 48, 2, 64, True), (5, 80, 12, 768, True), (2, 16, 1, 32, True),
-                                          (7, 144, 5, 320, False), (32, 128, 12, 768, True), (25, 160, 12, 64, False)])   # (the last two: one 128 x 288 tile per CU - the LOOP == 1 kernel; ragged rows, two K steps)
+                                          (7, 144, 5, 320, False), (32, 128, 12, 768, True), (25, 160, 12, 64, False), (17, 480, 12, 96, True)])   # (one 128 x 288 tile per CU - the LOOP == 1 kernel; ragged rows, two K steps; the last: the pipelined two-per-CU loop with a ragged last row tile, three K steps)
 def test_pair_gemm_with_quantiser_epilogue_vs_exact_arithmetic(B, S, H, K, want):
     """fp32 activations as operand pairs: every index within one step of the exact one and all but a few in 10^5 equal to it
     (the value sits on a rounding boundary to within the fp32 accumulation error: the library GEMM + quantiser pass it replaces
