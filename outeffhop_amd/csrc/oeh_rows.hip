@@ -413,66 +413,93 @@ __global__ __launch_bounds__(64 * NW) void oeh_gate_logit_fast_kernel(const void
 // lane's column, hidden units over registers).  BERT-base B=32 S=128 fp32, 64 -> 16 -> 1: 9.3 -> 6.2 us, 64 -> 64 -> 1: 18.6 -> 11.5 us,
 // B=512: 95 -> 66 us; the kernel above stays for
 // bf16 (a bf16 pair carries 16 mantissa bits) and the element kernel for everything else.
-template <int IN, int D>
+// Round 5: a workgroup takes TG groups of 64 consecutive tokens of its head (grid x = ceil(ntok / (64 TG))) with the first layer's weight fragments - loaded,
+// split into the fp16 pair and kept in registers ONCE (up to 64 hidden units: 4 x KS x 2 fragments) - instead of once per 64 tokens: the launch was made of
+// 3 072 short workgroups per 25 MB of layer input and ran at 1.0-1.4 TB/s (B = 128, S = 128 fp32: 17.7 us).
+template <int IN, int D, int TG>
 __global__ __launch_bounds__(256) void oeh_gate_mfma_kernel(const void* __restrict__ hidden, long ntok, int T, int H, long hs_b, long hs_t,
                                                             const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                                             const float* __restrict__ b2, int m_units, int apply_sigmoid, float scaling, float* out) {
   static_assert(IN == IN_F16 || IN == IN_F32, "fp16 pairs");
   typedef _Float16 h8v __attribute__((ext_vector_type(8)));
-  constexpr int KS = D / 32;
+  constexpr int KS = D / 32, MT = 4;   // up to MT 16-unit tiles of hidden units held in registers (the host sends wider predictors to the kernel above)
   const int h = blockIdx.y;
   const int mm = m_units > 0 ? m_units : 1;
+  const int ntau = (mm + 15) >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  long tok = (long)blockIdx.x * 64 + wave * 16 + c;
-  const bool live = tok < ntok;
-  if (!live) tok = ntok - 1;
-  const long b = tok / T;
-  const int t = (int)(tok - b * T);
   fp16_overflow_clamp();
-  u4 xf[KS], xl[IN == IN_F32 ? KS : 1];
-  if constexpr (IN == IN_F32) {
-    const float* xp = reinterpret_cast<const float*>(hidden) + b * hs_b + (long)t * hs_t + (long)h * D + 8 * g;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) split8(*reinterpret_cast<const f4*>(xp + 32 * ks), *reinterpret_cast<const f4*>(xp + 32 * ks + 4), xf[ks], xl[ks]);
-  } else {
-    const unsigned short* xp = reinterpret_cast<const unsigned short*>(hidden) + b * hs_b + (long)t * hs_t + (long)h * D + 8 * g;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const u4*>(xp + 32 * ks);
-  }
   auto mma = [](u4 a, u4 bb, f4 acc) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, bb), acc, 0, 0, 0); };
-  float a = 0.0f;
-  for (int tau = 0; tau * 16 < mm; ++tau) {  // 16 hidden units per pass: unit 16 tau + c supplies the A rows, units 16 tau + 4g + r come back
-    const int u = 16 * tau + c;
-    const bool uv = u < mm;
-    const float* wr = w1 + ((long)h * mm + (uv ? u : 0)) * D + 8 * g;
-    f4 acc = f4{0.f, 0.f, 0.f, 0.f}, accx = f4{0.f, 0.f, 0.f, 0.f};
+  // the weights of this head: unit 16 tau + c supplies the A rows; b1 / w2 of the units 16 tau + 4 g + r that come back in the lane's accumulator registers
+  u4 wh[MT][KS], wl[MT][KS];
+  float b1r[MT][4], w2r[MT][4];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      f4 w0 = *reinterpret_cast<const f4*>(wr + 32 * ks), w1v = *reinterpret_cast<const f4*>(wr + 32 * ks + 4);
-      if (!uv) w0 = w1v = f4{0.f, 0.f, 0.f, 0.f};
-      u4 wh, wl;
-      split8(w0, w1v, wh, wl);
-      acc = mma(wh, xf[ks], acc);
-      accx = mma(wl, xf[ks], accx);
-      if constexpr (IN == IN_F32) accx = mma(wh, xl[ks], accx);
-    }
+  for (int tau = 0; tau < MT; ++tau) {
+    if (tau < ntau) {
+      const int u = 16 * tau + c;
+      const bool uv = u < mm;
+      const float* wr = w1 + ((long)h * mm + (uv ? u : 0)) * D + 8 * g;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ur = 16 * tau + 4 * g + r;
-      const float lg = __builtin_fmaf(accx[r], kSplitDown, acc[r]);
-      if (m_units > 0) {
-        if (ur < mm) a = __builtin_fmaf(__builtin_fmaxf(lg + b1[(long)h * mm + ur], 0.0f), w2[(long)h * mm + ur], a);
-      } else if (ur == 0) {
-        a = lg + b1[h];  // Linear(D,1): unit 0 only
+      for (int ks = 0; ks < KS; ++ks) {
+        f4 w0 = *reinterpret_cast<const f4*>(wr + 32 * ks), w1v = *reinterpret_cast<const f4*>(wr + 32 * ks + 4);
+        if (!uv) w0 = w1v = f4{0.f, 0.f, 0.f, 0.f};
+        split8(w0, w1v, wh[tau][ks], wl[tau][ks]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ur = 16 * tau + 4 * g + r;
+        b1r[tau][r] = (m_units > 0 ? ur < mm : ur == 0) ? b1[(long)h * mm + ur] : 0.0f;
+        w2r[tau][r] = (m_units > 0 && ur < mm) ? w2[(long)h * mm + ur] : 0.0f;
       }
     }
   }
-  a += __shfl_xor(a, 16);  // the row's four lanes hold disjoint hidden units
-  a += __shfl_xor(a, 32);
-  if (m_units > 0) a = a + b2[h];
-  if (apply_sigmoid) a = (1.0f / (1.0f + exp_acc(-a))) * scaling;
-  if (live && g == 0) out[(b * H + h) * T + t] = a;
+  const float b2h = m_units > 0 ? b2[h] : 0.0f;
+  for (int tg = 0; tg < TG; ++tg) {
+    long tok = ((long)blockIdx.x * TG + tg) * 64 + wave * 16 + c;
+    if ((long)(blockIdx.x * TG + tg) * 64 >= ntok) break;   // (workgroup-uniform)
+    const bool live = tok < ntok;
+    if (!live) tok = ntok - 1;
+    const long b = tok / T;
+    const int t = (int)(tok - b * T);
+    u4 xf[KS], xl[IN == IN_F32 ? KS : 1];
+    if constexpr (IN == IN_F32) {
+      const float* xp = reinterpret_cast<const float*>(hidden) + b * hs_b + (long)t * hs_t + (long)h * D + 8 * g;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) split8(*reinterpret_cast<const f4*>(xp + 32 * ks), *reinterpret_cast<const f4*>(xp + 32 * ks + 4), xf[ks], xl[ks]);
+    } else {
+      const unsigned short* xp = reinterpret_cast<const unsigned short*>(hidden) + b * hs_b + (long)t * hs_t + (long)h * D + 8 * g;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const u4*>(xp + 32 * ks);
+    }
+    float a = 0.0f;
+#pragma unroll
+    for (int tau = 0; tau < MT; ++tau) {
+      if (tau < ntau) {
+        f4 acc = f4{0.f, 0.f, 0.f, 0.f}, accx = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          acc = mma(wh[tau][ks], xf[ks], acc);
+          accx = mma(wl[tau][ks], xf[ks], accx);
+          if constexpr (IN == IN_F32) accx = mma(wh[tau][ks], xl[ks], accx);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ur = 16 * tau + 4 * g + r;
+          const float lg = __builtin_fmaf(accx[r], kSplitDown, acc[r]);
+          if (m_units > 0) {
+            if (ur < mm) a = __builtin_fmaf(__builtin_fmaxf(lg + b1r[tau][r], 0.0f), w2r[tau][r], a);
+          } else if (ur == 0) {
+            a = lg + b1r[tau][r];  // Linear(D,1): unit 0 only
+          }
+        }
+      }
+    }
+    a += __shfl_xor(a, 16);  // the row's four lanes hold disjoint hidden units
+    a += __shfl_xor(a, 32);
+    if (m_units > 0) a = a + b2h;
+    if (apply_sigmoid) a = (1.0f / (1.0f + exp_acc(-a))) * scaling;
+    if (live && g == 0) out[(b * H + h) * T + t] = a;
+  }
 }
 
 template <int IN, int D>
@@ -493,15 +520,22 @@ static bool launch_gate_fast(const void* hidden, int B, int T, int H, int d, lon
   const long ntok = (long)B * T;
   if constexpr (IN != IN_BF16) {  // the first layer on the matrix cores (fp16 operand pairs: fp32-accurate)
     if ((reinterpret_cast<uintptr_t>(w1) & 15) == 0 && (d == 32 || d == 64 || d == 128)) {
-      const dim3 grid((unsigned)((ntok + 63) / 64), (unsigned)H);
-#define OEH_GM(D_) hipLaunchKernelGGL((oeh_gate_mfma_kernel<IN, D_>), grid, dim3(256), 0, st, hidden, ntok, T, H, hs_b, hs_t, w1, b1, w2, b2, m_units, apply_sigmoid, scaling, out)
-      if (d == 32) OEH_GM(32);
-      else if (d == 64) OEH_GM(64);
-      else OEH_GM(128);
+      // (token groups per workgroup: 4 once that still leaves every CU four workgroups)
+      const long groups = (ntok + 63) / 64;
+      const bool tg4 = groups * H >= 4096 && m_units <= 64;
+      const dim3 grid((unsigned)(tg4 ? (groups + 3) / 4 : groups), (unsigned)H);
+#define OEH_GM(D_) \
+      if (m_units > 64) goto element_kernel; \
+      if (tg4) hipLaunchKernelGGL((oeh_gate_mfma_kernel<IN, D_, 4>), grid, dim3(256), 0, st, hidden, ntok, T, H, hs_b, hs_t, w1, b1, w2, b2, m_units, apply_sigmoid, scaling, out); \
+      else hipLaunchKernelGGL((oeh_gate_mfma_kernel<IN, D_, 1>), grid, dim3(256), 0, st, hidden, ntok, T, H, hs_b, hs_t, w1, b1, w2, b2, m_units, apply_sigmoid, scaling, out)
+      if (d == 32) { OEH_GM(32); }
+      else if (d == 64) { OEH_GM(64); }
+      else { OEH_GM(128); }
 #undef OEH_GM
       return true;
     }
   }
+element_kernel:
   switch (d) {
     case 32: launch_gate_fast_d<IN, 32>(hidden, ntok, T, H, hs_b, hs_t, w1, b1, w2, b2, m_units, apply_sigmoid, scaling, out, st); return true;
     case 64: launch_gate_fast_d<IN, 64>(hidden, ntok, T, H, hs_b, hs_t, w1, b1, w2, b2, m_units, apply_sigmoid, scaling, out, st); return true;

@@ -620,8 +620,13 @@ def fused_gate_ok(B, H, Sq, Sk, D, dtype, clip: bool = False, fq: bool = False, 
     v = attn_variant(B, H, Sq, Sk, D, dtype, clip=clip, gate_hidden=True, **problem)
     if v is None:
         return False
-    if dtype == torch.float32:  # fp32 storage: the full-row kernel's operand-pair form (rows of <= 512 keys)
-        return v.startswith("fast16/")
+    if dtype == torch.float32:  # fp32 storage: the full-row kernel's operand-pair form (rows of <= 512 keys) ...
+        if not v.startswith("fast16/"):
+            return False
+        # ... unless the problem WITHOUT the predictor runs the one-pass kernel: that kernel + one `gate_fwd` launch is the faster pair
+        # (round 5, OPT-125m shape B=16 S=512 fp32: 42.1 + ~10 us against 58.3 us for the full-row fp32 kernel with the predictor inside)
+        v0 = attn_variant(B, H, Sq, Sk, D, dtype, clip=clip, gate_hidden=False, **problem)
+        return not (v0 or "").startswith("flash16/")
     return v.startswith("fast16/") or v.startswith("flash16/")
 
 

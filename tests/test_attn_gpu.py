@@ -1695,7 +1695,10 @@ def test_gate_predictor_fused_on_fp32_storage(ops, units, S, clip):
     pad = torch.from_numpy(_pad_mask(B, S, lens, fmin)).cuda()
     sm = "clippedsoftmax1(-.025:1)" if clip else "softmax1"
     gp = ops.GatePredictor(hidden, w1, b1, w2, b2, scaling=2.0, out=torch.empty((B, H, S), dtype=torch.float32, device="cuda"))
-    assert ops.fused_gate_ok(B, H, S, S, D, dt, units=units, clip=clip, key_pad=True, scale_div=8.0, mask_min=fmin)
+    # (round 5: the host takes the fused form only where it is the faster one - not where the problem without the predictor runs the one-pass fp32 kernel:
+    # that kernel + one gate launch wins there; the library call itself, below, works either way)
+    plain = ops.attn_variant(B, H, S, S, D, dt, clip=clip, key_pad=True, scale_div=8.0, mask_min=fmin)
+    assert ops.fused_gate_ok(B, H, S, S, D, dt, units=units, clip=clip, key_pad=True, scale_div=8.0, mask_min=fmin) == (not plain.startswith("flash16/"))
     assert ops.attn_variant(B, H, S, S, D, dt, clip=clip, key_pad=True, scale_div=8.0, mask_min=fmin, gate_hidden=True).startswith("fast16/")
     got = ops.attn_fwd(view(q), view(k), view(v), softmax=_spec(ops, sm), scale_div=8.0, key_pad_mask=pad, mask_min=fmin, gate_mlp=gp)
     if units:
