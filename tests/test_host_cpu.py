@@ -249,6 +249,13 @@ def test_attn_variant_describes_the_real_problem():
     assert not ops.fused_gate_ok(2, 4, 96, 64, 64, f16, causal=True)            # Sq > Sk causal: general kernel
     assert not ops.fused_gate_ok(2, 4, 64, 64, 64, f16, full_mask=True)
     assert ops.fused_gate_ok(2, 4, 64, 64, 64, f16) and ops.fused_gate_ok(2, 4, 64, 64, 64, f16, units=64) and not ops.fused_gate_ok(2, 4, 64, 64, 64, f16, units=65)
+    # fp32 storage (round 5): fused where the full-row fp32 kernel is what the problem runs anyway (BERT-base's rows), NOT where the problem without the
+    # predictor runs the one-pass fp32 kernel (OPT-125m's: that kernel + one gate launch is the faster pair); the library call works either way
+    f32 = torch.float32
+    assert ops.fused_gate_ok(32, 12, 128, 128, 64, f32, key_pad=True, scale_div=8.0, clip=True)
+    assert ops.attn_variant(16, 12, 512, 512, 64, f32, causal=True).startswith("flash16/") and not ops.fused_gate_ok(16, 12, 512, 512, 64, f32, causal=True)
+    assert ops.attn_variant(16, 12, 512, 512, 64, f32, causal=True, gate_hidden=True).startswith("fast16/")
+    assert ops.fused_gate_ok(16, 12, 512, 512, 64, f16, causal=True)
 
 
 def test_sparse_activations_match_the_reference():
