@@ -26,10 +26,12 @@ int oeh_debug_set_variant(int off_mask, int flash_mq_force);
 int oeh_debug_set_stamps(void* device_buffer);
 
 /* Environment switches of the projection GEMM (oeh_proj_quant_i8; csrc/oeh_gemm.hip), read once, inert unless OEH_DEBUG_HOOKS=1:
- *   OEH_GEMM_TILE = 1 | 2   force the 128 x 288 | 64 x 192 output tile;
+ *   OEH_GEMM_TILE = 1 | 2   force the 128 x 288 | 64 x 192 output tile (2 also keeps BERT-base-sized launches off the one-workgroup-per-CU loop);
+ *   OEH_GEMM_LOOP0 = 1      fp32 activations on the 128 x 288 tile: the round-4 K loop instead of the pipelined one (A/B);
  *   OEH_GEMM_DBG  = bits    knock parts of the kernel out for timing - the results are then WRONG (tools/exp/proj_time.py):
  *                           1 no epilogue, 4 no LDS-DMA after the first step, 8 no wait + barrier per step, 16 no value stores,
- *                           32 no index output stage, 64 the whole next tile's DMA issued at the top of a step. */
+ *                           32 no index output stage, 64 the whole next tile's DMA issued at the top of a step (the knock-outs exist in
+ *                           `make experiment` builds only; the pipelined loops honour bits 1, 16 and 32). */
 
 #ifdef __cplusplus
 }
