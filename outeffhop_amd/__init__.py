@@ -26,7 +26,8 @@ from .quantization import (  # noqa: F401
     get_quant_config,
     val_qparams,
 )
-from .softmax import SOFTMAX_MAPPING, Softmax_1, clipped_softmax, clipped_softmax1, softmax_1  # noqa: F401
+from .softmax import (SOFTMAX_MAPPING, ClipSoftmax, ClipSoftmax_1, Softmax_1, clipped_softmax, clipped_softmax1, clipped_softmax_1,  # noqa: F401
+                      make_clipped_softmax, make_clipped_softmax1, softmax_1, spec_of)
 from .sparse_activations import EntmaxAlpha, Sparsemax, entmax15, entmax_bisect, sparsemax  # noqa: F401
 from .vit_attention import ViTSelfAttentionWithExtras  # noqa: F401
 

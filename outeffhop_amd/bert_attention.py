@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from .attention import AttentionGateType, GateBookkeeping, GateState, attention_core, autograd_needed, build_gate, fused_qkv, has_hooks, unfused_core
-from .softmax import clipped_softmax, spec_of
+from .softmax import make_clipped_softmax, spec_of
 
 
 class BertSelfAttentionWithExtras(GateBookkeeping, nn.Module):
@@ -45,7 +45,7 @@ class BertSelfAttentionWithExtras(GateBookkeeping, nn.Module):
         self.ssm_eps, self.tau, self.max_seq_length = ssm_eps, tau, max_seq_length
         if alpha is not None:  # bert_attention.py:89-92: alpha selects a clipped softmax with gamma = -alpha / max_seq_length
             assert max_seq_length is not None
-            self.softmax_fn = clipped_softmax(gamma=-alpha / max_seq_length, eta=1.0)
+            self.softmax_fn = make_clipped_softmax(-alpha / max_seq_length, 1.0)  # = partial(clipped_softmax, gamma=, eta=1.0)
         else:
             self.softmax_fn = softmax_fn
         self.skip_attn = skip_attn

@@ -32,6 +32,9 @@
 #ifndef OEH_KO
 #define OEH_KO 0
 #endif
+#ifndef OEH_NSUB_MASK
+#define OEH_NSUB_MASK 1
+#endif
 
 #include <type_traits>
 
@@ -449,12 +452,22 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     }
   }
 
+  // the ones operand of the row-sum MFMAs, kept in registers across the tile loop (round 6: it was rebuilt - five v_mov - in every tile)
+  u4 ones_live = ones;
+  asm volatile("" : "+v"(ones_live));
   // ---- one 64-key tile for blocks J0..MQ-1 of this wave (J0 = 1: block 0's rows end before this tile)
   // MODE 0: the one-pass tile; CLIP: 1 = statistics pass (no second product), 2 = final pass (final reference, clip)
-  auto tile = [&](auto j0c, auto firstc, auto modec, const int i, const int soff) {
+  auto tile = [&](auto j0c, auto firstc, auto modec, auto nsc, const int i, const int soff) {
     constexpr int J0 = decltype(j0c)::value;
     constexpr bool FIRST = decltype(firstc)::value;  // tile 0: V tile 0 is awaited between the two products
     constexpr int MODE = decltype(modec)::value;
+    // Round 6: NSa[j] = how many of the tile's four 16-key sub-tiles hold a key that ANY row of block j may see (4 = all; the caller passes
+    // fewer only for the placed order below).  The sub-tiles behind are masked for the whole block (the causal diagonal, the ragged last
+    // tile): their scores would be set to the sentinel, their exponentials are exactly 0 and their products add exactly 0 - so the MFMAs,
+    // the scale / max / exp / convert steps and the K fragment reads of those sub-tiles are simply not issued; results bit for bit the same.
+    constexpr int NSP = decltype(nsc)::value;
+    constexpr int NSa[2] = {NSP & 15, (NSP >> 4) & 15};
+    constexpr int NSMAX = (MQ == 2) ? ((J0 == 0 && NSa[0] > NSa[1]) ? NSa[0] : NSa[1]) : NSa[0];
     // Round 5: the plain one-pass tile on 16-bit storage, tiles after the first: the exponentials in two halves - keys 0-31 of every block, then the first
     // half's MFMAs (O^T += V^T P^T over those keys) with the exponentials of keys 32-63 placed BETWEEN them - instead of all 32 v_exp_f32 + 16 conversions
     // in one lump in front of 20 back-to-back MFMAs (the compiler's schedule; profiles/r05_headline_tile_order.txt).
@@ -463,6 +476,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
 #else
     constexpr bool PIPE_PV = (MODE == 0) && !SRC32 && !FIRST && D <= 64 && OEH_KO == 0;   // (D = 128: 1.045 of the plain order - one wave per SIMD there, other limits)
 #endif
+    static_assert(NSP == 0x44 || PIPE_PV, "partial tiles: the placed order only");
 #if OEH_KO == 2
     if constexpr (FIRST) {
       if (!GATE && 1 < n_kt) wait_vm(std::integral_constant<int, 2>{});
@@ -478,6 +492,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     f4 s[MQ][4];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
+      if (sub >= NSMAX) continue;
       u4 kf[KS], kl[SRC32 ? KS : 1];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -486,6 +501,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       }
 #pragma unroll
       for (int j = J0; j < MQ; ++j) {
+        if (sub >= NSa[j]) continue;
         f4 acc = f4{0.f, 0.f, 0.f, 0.f};
         for (int ks = 0; ks < KS; ++ks) acc = mfma16<IN>(kf[ks], qf[j][ks], acc);
         if constexpr (SRC32) {
@@ -513,6 +529,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     if constexpr (has_pad) {
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
+        if (sub >= NSMAX) continue;
         const int kb = 64 * i + 16 * sub + 4 * g;
         f4 padv;
         if (pad_in_lds) {
@@ -527,6 +544,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
         } else {
 #pragma unroll
           for (int j = J0; j < MQ; ++j) {
+            if (sub >= NSa[j]) continue;
             if (P.full != nullptr) {
               // a (B,1,Sq,Sk) additive mask on rows of more than 512 keys (the general kernel takes the shorter ones): read per
               // block from memory - compiler-visible loads inside the LDS-DMA stream, i.e. its waits drain the ring; slow next to
@@ -562,7 +580,8 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[j][sub][r] = __builtin_fmaf(s[j][sub][r], c1, mcneg[j]);
+        for (int r = 0; r < 4; ++r)
+          if (sub < NSa[j]) s[j][sub][r] = __builtin_fmaf(s[j][sub][r], c1, mcneg[j]);
     }
     // causal / tail mask, classified per 16x16 sub-tile with wave-uniform tests: untouched, all masked, or mixed
 #pragma unroll
@@ -573,6 +592,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       const int klim = causal ? min(rb[j] + c + off, Sk - 1) : Sk - 1;
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
+        if (sub >= NSa[j]) continue;   // (masked for the whole block: not computed at all)
         const int k0 = 64 * i + 16 * sub;
         if (k0 > lim_hi) {
           s[j][sub] = f4{NEGT, NEGT, NEGT, NEGT};
@@ -652,7 +672,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       }
       // row maximum of the exponent arguments (fma / select results: no canonicalising v_max is needed in front)
       // (v_max3 written out: from fmaxf the compiler puts two canonicalising v_max x,x,x in front of every chain)
-      float mt = max3_raw(s[j][0][0], s[j][0][1], s[j][0][2]);
+      float mt;
+#ifdef OEH_R5_MAXCHAIN
+      mt = max3_raw(s[j][0][0], s[j][0][1], s[j][0][2]);
       mt = max3_raw(mt, s[j][0][3], s[j][1][0]);
       mt = max3_raw(mt, s[j][1][1], s[j][1][2]);
       mt = max3_raw(mt, s[j][1][3], s[j][2][0]);
@@ -660,6 +682,12 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       mt = max3_raw(mt, s[j][2][3], s[j][3][0]);
       mt = max3_raw(mt, s[j][3][1], s[j][3][2]);
       mt = max3_raw(mt, s[j][3][3], s[j][3][3]);
+#else
+      if (NSa[j] == 1) mt = max_first<1>(s[j]);        // (one statement each: oeh_common.h)
+      else if (NSa[j] == 2) mt = max_first<2>(s[j]);
+      else if (NSa[j] == 3) mt = max_first<3>(s[j]);
+      else mt = max16_tree(s[j]);
+#endif
       // Move the reference: always on the first tile (to that tile's row maximum, unless every key of it is masked),
       // later only for rows whose maximum exceeds it by 2^8.  The common case is decided on the LANE maxima (no cross-lane
       // step); the row maximum is formed only when some row moves.  Decided per ROW, so that a row's result depends on
@@ -685,7 +713,8 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[j][sub][r] -= delta;
+          for (int r = 0; r < 4; ++r)
+            if (sub < NSa[j]) s[j][sub][r] -= delta;
         if (i != 0) {
           float alpha = __builtin_amdgcn_exp2f(-delta);
           if constexpr (has_pad && (MODE == 0 || MODE == 1)) alpha = (thr_j < -1.0e19f) ? 1.0f : alpha;  // nothing accumulated yet (and exp2(-delta) may overflow)
@@ -744,8 +773,10 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       // e = 0..15: element of the block's score tile.  PLACED (volatile asm keeps its position among the MFMA statements; from the builtin the instruction
       // selector sinks all of them to their first use behind the last MFMA of the half)
       auto exp1 = [&](const int j, const int e) { asm volatile("v_exp_f32_e32 %0, %0" : "+v"(s[j][e >> 2][e & 3])); };
-      auto pack_half = [&](const int j, const int u) {
-        const f4 a = s[j][2 * u], bb = s[j][2 * u + 1];
+      auto pack_half = [&](const int j, const int u) {   // the visible sub-tiles of half u (NSa[j] - 2 u >= 1 of them); a masked one: zeros
+        const f4 a = s[j][2 * u];
+        f4 bb = f4{0.f, 0.f, 0.f, 0.f};
+        if (NSa[j] - 2 * u >= 2) bb = s[j][2 * u + 1];
         if constexpr (IN == IN_BF16) pb[j][u] = u4{pack2_bf16(a[0], a[1]), pack2_bf16(a[2], a[3]), pack2_bf16(bb[0], bb[1]), pack2_bf16(bb[2], bb[3])};
         else pb[j][u] = u4{pack2_f16(a[0], a[1]), pack2_f16(a[2], a[3]), pack2_f16(bb[0], bb[1]), pack2_f16(bb[2], bb[3])};
       };
@@ -762,51 +793,74 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       constexpr int NB = MQ - J0;              // active blocks
       // HAZARD RULE of this path (the inline-asm MFMAs are outside the compiler's hazard model): a register an MFMA reads must not have been written by a
       // vector instruction in the two issue slots in front of it (the compiler keeps that distance for its own MFMAs: the s_nop it puts behind a v_mov of
-      // the ones operand).  The ones operand is therefore materialised HERE (the first half's exponentials lie between it and its first use), the packed P
+      // the ones operand).  The ones operand is therefore materialised ahead (round 6: once, in front of the tile loop), the packed P
       // of a half is followed by the half's V^T reads, and the second half's conversions by an explicit s_nop.  (Found as NaN row sums at MQ == 1.)
+#ifdef OEH_R5_ONES_PER_TILE
       u4 ones_v = ones;
       asm volatile("" : "+v"(ones_v));
+#else
+      const u4 ones_v = ones_live;
+#endif
       // keys 0-31 of every block: exponentials, packed
 #pragma unroll
       for (int j = J0; j < MQ; ++j) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) exp1(j, e);
-        pack_half(j, 0);
+        for (int e = 0; e < 8; ++e)
+          if (e < 4 * NSa[j]) exp1(j, e);
+      }
+      // (trans -> VALU: a conversion that reads an exponential needs one wait state; the compiler does not insert it behind inline asm - structural
+      // here, and checked on the built library's disassembly by tools/check_disasm.py: ADVICE r5)
+      asm volatile("s_nop 0" ::: "memory");
+#pragma unroll
+      for (int j = J0; j < MQ; ++j) pack_half(j, 0);
+      {
       }
       u4 va[DT];
       read_v(0, va);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_nop 1" ::: "memory");   // (the hazard rule, whatever the scheduler did with the reads above)
       __builtin_amdgcn_s_setprio(1);
-      // first half's NB (DT + 1) MFMAs, the 8 NB exponentials of keys 32-63 between them (about one per gap: a v_exp_f32 is the 8 issue cycles an MFMA of
-      // this shape leaves), the conversions behind
+      // first half's NB (DT + 1) MFMAs, the exponentials of keys 32-63 (8 per block with all four sub-tiles, 4 with three, none with fewer) between them
+      // (about one per gap: a v_exp_f32 is the 8 issue cycles an MFMA of this shape leaves), the conversions behind
+      constexpr int E2_0 = (J0 == 0) ? 4 * (NSa[0] > 2 ? NSa[0] - 2 : 0) : 0;             // block 0's exponentials of the second half (not active: none)
+      constexpr int E2_1 = (MQ == 2) ? 4 * (NSa[1] > 2 ? NSa[1] - 2 : 0) : 0;
       {
-        constexpr int NM = NB * (DT + 1), NE = 8 * NB;          // MFMAs of the half; exponentials to place (block-major: element 8 + (n & 7) of block J0 + n / 8)
+        constexpr int NM = NB * (DT + 1), NE = E2_0 + E2_1;     // MFMAs of the half; exponentials to place (block-major: block 0's E2_0 first)
         constexpr int TWO = NE > NM ? NE - NM : 0;              // the first TWO gaps take two exponentials, the others one (all indices below are closed forms of m:
-#pragma unroll                                                   // a running counter would make the score tile a dynamically indexed array - in scratch memory)
+        auto exp2nd = [&](const int n) {                        // a running counter would make the score tile a dynamically indexed array - in scratch memory)
+          if (MQ == 2 && J0 == 0 && n >= E2_0) exp1(1, 8 + n - E2_0);
+          else exp1(J0, 8 + n);
+        };
+#pragma unroll
         for (int m = 0; m < NM; ++m) {
           if (m < NB) mfma_acc(lacc[J0 + m], ones_v, pb[J0 + m][0]);
           else mfma_acc(o[J0 + (m - NB) % NB][(m - NB) / NB], va[(m - NB) / NB], pb[J0 + (m - NB) % NB][0]);
           const int first = m < TWO ? 2 * m : TWO + m, cnt = m < TWO ? 2 : 1;
 #pragma unroll
           for (int q = 0; q < cnt; ++q)
-            if (first + q < NE) exp1(J0 + (first + q) / 8, 8 + ((first + q) & 7));
+            if (first + q < NE) exp2nd(first + q);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int n = (NM < TWO ? 2 * NM : TWO + NM); n < NE; ++n) exp1(J0 + n / 8, 8 + (n & 7));   // (whatever is left: none when NE <= 2 NM)
+        for (int n = (NM < TWO ? 2 * NM : TWO + NM); n < NE; ++n) exp2nd(n);   // (whatever is left: none when NE <= 2 NM)
       }
+      if constexpr (E2_0 + E2_1 > 0) {
+        asm volatile("s_nop 0" ::: "memory");   // (the last placed exponential -> its conversion: as above)
 #pragma unroll
-      for (int j = J0; j < MQ; ++j) pack_half(j, 1);
-      read_v(1, va);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_nop 1" ::: "memory");   // (the conversions above -> the MFMAs below: the hazard rule)
+        for (int j = J0; j < MQ; ++j)
+          if (NSa[j] > 2) pack_half(j, 1);
+        read_v(1, va);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1" ::: "memory");   // (the conversions above -> the MFMAs below: the hazard rule)
 #pragma unroll
-      for (int j = J0; j < MQ; ++j) mfma_acc(lacc[j], ones_v, pb[j][1]);
+        for (int j = J0; j < MQ; ++j)
+          if (NSa[j] > 2) mfma_acc(lacc[j], ones_v, pb[j][1]);
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int j = J0; j < MQ; ++j) mfma_acc(o[j][dt], va[dt], pb[j][1]);
+          for (int j = J0; j < MQ; ++j)
+            if (NSa[j] > 2) mfma_acc(o[j][dt], va[dt], pb[j][1]);
+      }
       __builtin_amdgcn_s_setprio(0);
       return;
     }
@@ -865,6 +919,16 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   };
   using J0_0 = std::integral_constant<int, 0>;
   using J0_1 = std::integral_constant<int, 1>;
+  using NS_FULL = std::integral_constant<int, 0x44>;
+  // bodies specialised for partly masked tiles exist where the placed order does (tile: PIPE_PV)
+#if defined(OEH_NO_PIPE_PV) || defined(OEH_NO_NSUB) || defined(OEH_R5_MAXCHAIN) || OEH_KO != 0
+  constexpr bool NSV = false;
+#else
+  constexpr bool NSV = (TP == 0) && !SRC32 && D <= 64;
+#endif
+  int lh[MQ];   // last key any row of block j may see: a 16-key sub-tile that starts behind it is masked for the whole block
+#pragma unroll
+  for (int j = 0; j < MQ; ++j) lh[j] = causal ? min(rb[j] + 15 + off, Sk - 1) : Sk - 1;
   if constexpr (SRC32) {
     auto stream32 = [&](auto modec) {  // one pass over the register-staged stream (stage 0 is in the registers on entry)
       int slot_r = 0;
@@ -876,9 +940,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
         slot_r ^= 1;
         if (i >= nkb[MQ - 1]) continue;
         if (MQ == 2 && i >= nkb[0]) {
-          if constexpr (MQ == 2) tile(J0_1{}, std::false_type{}, modec, i, soff);
+          if constexpr (MQ == 2) tile(J0_1{}, std::false_type{}, modec, NS_FULL{}, i, soff);
         } else {
-          tile(J0_0{}, std::false_type{}, modec, i, soff);
+          tile(J0_0{}, std::false_type{}, modec, NS_FULL{}, i, soff);
         }
       }
     };
@@ -893,7 +957,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     }
   } else {
   using MODE_A = std::integral_constant<int, CLIP ? 1 : (FQ2 ? 3 : 0)>;  // the (first) pass over the keys
-  tile(J0_0{}, std::true_type{}, MODE_A{}, 0, 0);  // every block sees key 0: tile 0 is computed by every wave, for all its blocks
+  tile(J0_0{}, std::true_type{}, MODE_A{}, NS_FULL{}, 0, 0);  // every block sees key 0: tile 0 is computed by every wave, for all its blocks
   OEH_STAMP(6);
   int slot_i = 1;
   for (int i = 1; i < n_kt; ++i) {
@@ -910,10 +974,32 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     const int soff = slot_i * STAGEB;
     slot_i = (slot_i == R - 1) ? 0 : slot_i + 1;
     if (i >= nkb[MQ - 1]) continue;  // this wave's rows end before this tile (causal): nothing to compute
+    // Round 6: a tile in which only the first n < 4 sixteen-key sub-tiles hold a key the block may see (every block's causal diagonal tile, the ragged last
+    // tile) runs a body specialised for n: for the block that ends in this tile (block 0 beside a full block 1; or block 1 alone; or the only block)
     if (MQ == 2 && i >= nkb[0]) {
-      if constexpr (MQ == 2) tile(J0_1{}, std::false_type{}, MODE_A{}, i, soff);
+      if constexpr (MQ == 2) {
+        const int n1 = NSV ? ((lh[1] - 64 * i) >> 4) + 1 : 4;
+        if constexpr (NSV && (OEH_NSUB_MASK & 1)) {
+          if (n1 == 1) tile(J0_1{}, std::false_type{}, MODE_A{}, std::integral_constant<int, 0x14>{}, i, soff);
+          else if (n1 == 2) tile(J0_1{}, std::false_type{}, MODE_A{}, std::integral_constant<int, 0x24>{}, i, soff);
+          else if (n1 == 3) tile(J0_1{}, std::false_type{}, MODE_A{}, std::integral_constant<int, 0x34>{}, i, soff);
+          else tile(J0_1{}, std::false_type{}, MODE_A{}, NS_FULL{}, i, soff);
+        } else {
+          tile(J0_1{}, std::false_type{}, MODE_A{}, NS_FULL{}, i, soff);
+        }
+      }
     } else {
-      tile(J0_0{}, std::false_type{}, MODE_A{}, i, soff);
+      if constexpr (NSV && (OEH_NSUB_MASK & 2)) {
+        const int n0 = ((lh[0] - 64 * i) >> 4) + 1;
+        const int nl = ((lh[MQ - 1] - 64 * i) >> 4) + 1;   // the last block: full, or (MQ == 1) the block itself
+        if (MQ == 2 && nl < 4) tile(J0_0{}, std::false_type{}, MODE_A{}, NS_FULL{}, i, soff);   // (both blocks partial - Sq != Sk layouts: the general body)
+        else if (n0 == 1) tile(J0_0{}, std::false_type{}, MODE_A{}, std::integral_constant<int, 0x41>{}, i, soff);
+        else if (n0 == 2) tile(J0_0{}, std::false_type{}, MODE_A{}, std::integral_constant<int, 0x42>{}, i, soff);
+        else if (n0 == 3) tile(J0_0{}, std::false_type{}, MODE_A{}, std::integral_constant<int, 0x43>{}, i, soff);
+        else tile(J0_0{}, std::false_type{}, MODE_A{}, NS_FULL{}, i, soff);
+      } else {
+        tile(J0_0{}, std::false_type{}, MODE_A{}, NS_FULL{}, i, soff);
+      }
     }
     if (i < 8) OEH_STAMP(6 + 3 * i);
   }
@@ -939,9 +1025,9 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       slot_b = (slot_b == R - 1) ? 0 : slot_b + 1;
       if (i >= nkb[MQ - 1]) continue;
       if (MQ == 2 && i >= nkb[0]) {
-        if constexpr (MQ == 2) tile(J0_1{}, std::false_type{}, MODE_B{}, i, soff);
+        if constexpr (MQ == 2) tile(J0_1{}, std::false_type{}, MODE_B{}, NS_FULL{}, i, soff);
       } else {
-        tile(J0_0{}, std::false_type{}, MODE_B{}, i, soff);
+        tile(J0_0{}, std::false_type{}, MODE_B{}, NS_FULL{}, i, soff);
       }
     }
   }

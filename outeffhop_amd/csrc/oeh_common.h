@@ -435,6 +435,52 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
   return r;
 }
 
+// Lane maximum of the 16 exponent arguments of one 16 x 64 score block, as ONE statement: behind every single-instruction asm the compiler
+// puts an `s_nop 0` (8 per block and tile in the chain form above), and a chain of eight dependent v_max3 pays the dependent-issue latency
+// eight times.  Five independent v_max3, then depth 2 more (round 6; max is exact, so the value is the chain's bit for bit).
+__device__ __forceinline__ float max16_tree(const f4 (&s)[4]) {
+  float r, t1, t2, t3, t4;
+  asm("v_max3_f32 %0, %5, %6, %7\n\t"
+      "v_max3_f32 %1, %8, %9, %10\n\t"
+      "v_max3_f32 %2, %11, %12, %13\n\t"
+      "v_max3_f32 %3, %14, %15, %16\n\t"
+      "v_max3_f32 %4, %17, %18, %19\n\t"
+      "v_max3_f32 %0, %0, %1, %2\n\t"
+      "v_max3_f32 %3, %3, %4, %20\n\t"
+      "v_max_f32_e32 %0, %0, %3"
+      : "=&v"(r), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
+      : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]), "v"(s[1][3]), "v"(s[2][0]), "v"(s[2][1]),
+        "v"(s[2][2]), "v"(s[2][3]), "v"(s[3][0]), "v"(s[3][1]), "v"(s[3][2]), "v"(s[3][3]));
+  return r;
+}
+// ... of the first 4 n (n = 1, 2, 3) of them (a tile in which only the first n 16-key sub-tiles of the block hold a visible key)
+template <int N4>
+__device__ __forceinline__ float max_first(const f4 (&s)[4]) {
+  static_assert(N4 >= 1 && N4 <= 3, "1..3 sub-tiles");
+  float r, t1, t2;
+  if constexpr (N4 == 1) {
+    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32_e32 %0, %0, %4" : "=&v"(r) : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]));
+  } else if constexpr (N4 == 2) {
+    asm("v_max3_f32 %0, %3, %4, %5\n\t"
+        "v_max3_f32 %1, %6, %7, %8\n\t"
+        "v_max3_f32 %0, %0, %9, %10\n\t"
+        "v_max_f32_e32 %0, %0, %1"
+        : "=&v"(r), "=&v"(t1), "=&v"(t2)
+        : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]), "v"(s[1][3]));
+  } else {
+    asm("v_max3_f32 %0, %3, %4, %5\n\t"
+        "v_max3_f32 %1, %6, %7, %8\n\t"
+        "v_max3_f32 %2, %9, %10, %11\n\t"
+        "v_max3_f32 %0, %0, %12, %13\n\t"
+        "v_max3_f32 %1, %1, %2, %14\n\t"
+        "v_max_f32_e32 %0, %0, %1"
+        : "=&v"(r), "=&v"(t1), "=&v"(t2)
+        : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]), "v"(s[1][3]), "v"(s[2][0]), "v"(s[2][1]),
+          "v"(s[2][2]), "v"(s[2][3]));
+  }
+  return r;
+}
+
 // Workgroup placement.  With every workgroup of a launch resident at once, CU c is given the block ids c, c + 256,
 // c + 512 (tools/timeline.py reads HW_ID), so with the causal q tiles in heaviest-first order a quarter of the CUs get
 // 8 + 6 + 4 key tiles and a quarter 6 + 4 + 2.  Walking every second row of 256 ids backwards (in units of 8, so that a

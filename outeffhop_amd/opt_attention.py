@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from .attention import AttentionGateType, GateBookkeeping, GateState, attention_core, autograd_needed, build_gate, fused_qkv, has_hooks, linear_fp32, unfused_core
-from .softmax import clipped_softmax, clipped_softmax1, spec_of
+from .softmax import make_clipped_softmax, make_clipped_softmax1, spec_of
 
 
 class OPTAttentionWithExtras(GateBookkeeping, nn.Module):
@@ -47,8 +47,8 @@ class OPTAttentionWithExtras(GateBookkeeping, nn.Module):
         self.max_seq_length, self.ssm_eps, self.tau, self.attn_softmax = max_seq_length, ssm_eps, tau, attn_softmax
         if alpha is not None:  # opt_attention.py:70-77 (the reference tests `attn_softmax is "softmax1"`)
             assert max_seq_length is not None
-            make = clipped_softmax1 if attn_softmax == "softmax1" else clipped_softmax
-            self.softmax_fn = make(gamma=-alpha / max_seq_length, eta=1.0)
+            # = partial(clipped_softmax[1], gamma=, eta=1.0) as in the reference (a functools.partial subclass that also carries .spec)
+            self.softmax_fn = (make_clipped_softmax1 if attn_softmax == "softmax1" else make_clipped_softmax)(-alpha / max_seq_length, 1.0)
         else:
             self.softmax_fn = softmax_fn
         self.skip_attn = skip_attn  # accepted and ignored, as in the reference

@@ -611,7 +611,9 @@ class QuantLinear(QuantizedModule, nn.Linear):
         run to 255, exact in fp16 (the fp16-integer form of `linear_index` serves them) but not as int8 - 128 ... 255 would wrap
         (ADVICE r4).  One host read per weight / weight-range version, cached."""
         qz = self.weight_quantizer.quantizer
-        key = (self.weight.data_ptr(), self.weight._version, qz._delta.data_ptr(), qz._delta._version)
+        sg = getattr(qz, "_signed", None)   # (the symmetric quantiser's signed / unsigned switch and its bit width decide whether the integers run to 255: ADVICE r5)
+        key = (self.weight.data_ptr(), self.weight._version, qz._delta.data_ptr(), qz._delta._version, getattr(qz, "n_bits", None),
+               None if sg is None else (sg.data_ptr(), sg._version) if torch.is_tensor(sg) else sg)
         hit = self.__dict__.get("_int8_fit_cache")
         if hit is None or hit[0] != key:
             with torch.no_grad():
@@ -785,6 +787,15 @@ class _I8LayerPlan:
                 fl += [m.training, m._qa, m._qw, m.activation_quantizer.state, m.weight_quantizer.state]
         for aq in (owner.attn_scores_act_quantizer, owner.attn_probs_act_quantizer, owner.context_act_quantizer):
             fl += [aq._qa, aq.activation_quantizer.state]
+        # the quantisers' Python attributes that are baked into the plan's specs (not registered buffers: the watch list cannot see them)
+        for m in (*lins, consumer):
+            if m is not None:
+                for mg in (m.weight_quantizer, m.activation_quantizer):
+                    qz = mg.quantizer
+                    fl += [type(qz).__name__, getattr(qz, "n_bits", None), getattr(qz, "eps", None)]
+        for aq in (owner.attn_scores_act_quantizer, owner.attn_probs_act_quantizer, owner.context_act_quantizer):
+            qz = aq.activation_quantizer.quantizer
+            fl += [type(qz).__name__, getattr(qz, "n_bits", None), getattr(qz, "eps", None)]
         return tuple(fl)
 
     def valid(self, owner, x, lins, consumer, padvec, stream) -> bool:
@@ -796,6 +807,11 @@ class _I8LayerPlan:
         if self.padkey != (None if padvec is None else (padvec.dtype, padvec.shape, padvec.stride())):
             return False
         if self.flags != _I8LayerPlan.state_flags(owner, lins, consumer):
+            return False
+        # The plan replays forward-only kernels: when autograd is recording and the input or a watched parameter requires grad, the full
+        # path must run - it raises / takes the differentiable route as before (a plan built under no_grad used to be
+        # replayed here and returned tensors without grad_fn - gradients dropped silently).  The predicate of ops.grad_recording.
+        if torch.is_grad_enabled() and (x.requires_grad or any(t_ is not None and t_.requires_grad for _, _, t_, _, _ in self.watch)):
             return False
         for d_, n_, t_, v_, p_ in self.watch:
             cur = d_.get(n_)

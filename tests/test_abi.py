@@ -190,3 +190,18 @@ int main(void) {{
                     "-Wl,--allow-shlib-undefined"], check=True, capture_output=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert out[0] == "6" and out[-2:] == ["-22", "-22"], out
+
+
+def test_built_library_disassembly_keeps_the_hand_kept_hazard_rules():
+    """the LDS-DMA requests clobber M0 without saving it, and the placed tile issues v_exp_f32 as inline asm - both outside
+    what the compiler checks.  tools/check_disasm.py reads the built library's gfx950 disassembly: no compiler-emitted M0 user, no M0
+    operand outside the request pattern, no transcendental instruction immediately followed by a reader of its result, no spills in the
+    headline kernels."""
+    import subprocess
+    import sys
+
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_disasm.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "findings: 0" in r.stdout

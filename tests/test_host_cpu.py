@@ -53,6 +53,45 @@ def test_registry_matches_reference_keys_and_parameters():
         oa.SOFTMAX_MAPPING["clippedsoftmax1(-.025:1)"](torch.zeros(2, 2), dim=-1, dtype=torch.float32)
 
 
+def test_clipped_softmax_callables_have_the_reference_signature_and_still_fuse(monkeypatch):
+    """models/softmax.py:10-19 + the reference's own idiom `partial(clipped_softmax, gamma=g, eta=1.0)` (opt_attention.py:75-77,
+    bert_attention.py:92): data-first callables; a partial of them handed to a module as softmax_fn= takes the FUSED kernel path."""
+    import inspect
+    from functools import partial
+
+    from outeffhop_amd import _lib
+    from outeffhop_amd import opt_attention as OA
+    from outeffhop_amd.softmax import spec_of
+
+    for f in (oa.clipped_softmax, oa.clipped_softmax1):
+        sig = inspect.signature(f)
+        assert list(sig.parameters) == ["data", "dim", "eta", "gamma", "kw"]
+        assert (sig.parameters["dim"].default, sig.parameters["eta"].default, sig.parameters["gamma"].default) == (1, 1.1, -0.1)
+    p = partial(oa.clipped_softmax, gamma=-0.03, eta=1.0)
+    assert spec_of(p) == oa.ops.SoftmaxSpec(0, True, -0.03, 1.0)
+    assert spec_of(partial(oa.clipped_softmax1, gamma=-0.01)) == oa.ops.SoftmaxSpec(1, True, -0.01, 1.1)   # eta: the function's default
+    assert spec_of(partial(oa.clipped_softmax, dtype=torch.float32)) is None                                # a bound kwarg the kernel does not model
+    assert spec_of(partial(oa.clipped_softmax, 1)) is None                                                  # a bound positional
+    e = oa.SOFTMAX_MAPPING["clipped(-.025:1)"]   # registry entries are such partials, as in the reference (softmax.py:26-63)
+    assert isinstance(e, partial) and e.func is oa.clipped_softmax and e.keywords == {"gamma": -0.025, "eta": 1.0}
+    with pytest.raises(_lib.OehError):   # positional (input, dim, eta, gamma) as cross_models/clip_softmax.py:33 calls it: reaches the HIP op (no CPU path)
+        oa.clipped_softmax(torch.zeros(2, 3), 1, 1.1, -0.1)
+    with pytest.raises(TypeError, match="unexpected keyword argument 'dtype'"):
+        oa.clipped_softmax1(torch.zeros(2, 3), dim=-1, dtype=torch.float32)
+    assert isinstance(oa.ClipSoftmax_1(dim=-1, eta=1.0, gamma=-0.1), torch.nn.Module)   # (the reference's constructor raises: clip_softmax.py:46)
+    seen = {}
+
+    def fake_core(q, k, v, **kw):
+        seen.update(kw)
+        return torch.zeros(q.shape[0], q.shape[2], q.shape[1] * q.shape[3])
+
+    monkeypatch.setattr(OA, "attention_core", fake_core)
+    m = oa.OPTAttentionWithExtras(128, 2, softmax_fn=p).eval()
+    with torch.no_grad():
+        m(torch.randn(2, 5, 128))
+    assert seen["softmax_fn"] is p and spec_of(seen["softmax_fn"]).gamma == -0.03
+
+
 def test_gate_enum():
     T = oa.AttentionGateType
     assert T.list_names() == ["none", "unconditional_per_head", "conditional_per_head", "conditional_per_token"]

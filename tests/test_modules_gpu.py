@@ -930,6 +930,32 @@ def test_frozen_int8_layers_replay_a_prebuilt_plan(oa):
         finally:
             Q.INDEX_GEMM = True
 
+    # ---- autograd: a plan built under no_grad must NOT be replayed once autograd is recording and the weights / the input
+    # require grad - the replay is forward-only and would hand back tensors without grad_fn.  The full path's behaviour then (a
+    # differentiable result, or its forward-only error), with the plan-run counter unchanged.
+    with torch.no_grad():
+        qm(x, attention_mask=mask)
+        assert both(qm, x, attention_mask=mask)[2] == 1                     # (a live plan for this geometry)
+    before = qm.__dict__.get("_i8_plan_runs", 0)
+    with torch.enable_grad():                                               # parameters require grad (the default after construction)
+        assert any(p_.requires_grad for p_ in qm.parameters())
+        try:
+            out = qm(x, attention_mask=mask)[0]
+            assert out.requires_grad and out.grad_fn is not None
+        except Q.ops._lib.OehError:
+            pass                                                            # (forward-only path refusing loudly is also the full path's behaviour)
+        assert qm.__dict__.get("_i8_plan_runs", 0) == before
+        for p_ in qm.parameters():
+            p_.requires_grad_(False)
+        xg = x.clone().requires_grad_(True)                                 # frozen weights, an input that requires grad
+        try:
+            out = qm(xg, attention_mask=mask)[0]
+            assert out.requires_grad
+        except Q.ops._lib.OehError:
+            pass
+        assert qm.__dict__.get("_i8_plan_runs", 0) == before
+        assert both(qm, x, attention_mask=mask)[2] == 1                     # nothing requires grad: the plan again, although grad mode is on
+
     # ---- BERT (key padding: the mask's pointer is patched per call)
     bq = oa.QuantizedBertSelfAttentionWithExtras(oa.BertSelfAttentionWithExtras(Cfg(), softmax_fn=oa.SOFTMAX_MAPPING["softmax1"]).to(dev).eval(),
                                                  **_qparams(oa)).to(dev).eval()

@@ -35,6 +35,29 @@ def test_softmax_rows_all_registry_keys(ops):
                 np.testing.assert_allclose(got, g[f"edge_y[{e}][{k}]"], rtol=2e-6, atol=1e-7, err_msg=f"{k}/{e}")
 
 
+def test_clipped_softmax_callables_positional_as_the_reference_calls_them(ops):
+    """models/softmax.py:10-19 as data-first callables: `clipped_softmax(input, dim, eta, gamma)` (cross_models/clip_softmax.py:33), the
+    registry's partials, and STanHop's ClipSoftmax / ClipSoftmax_1 modules - all the HIP row kernel, against the reference's rows."""
+    from functools import partial
+
+    import outeffhop_amd as oa
+
+    g = load_golden("softmax_rows.npz")
+    x = torch.from_numpy(g["x"]).cuda()
+    for k, (b, ga, et) in O.softmax_table().items():
+        if ga == 0.0 and et == 1.0:
+            continue
+        f = oa.clipped_softmax1 if b == 1 else oa.clipped_softmax
+        np.testing.assert_allclose(f(x, -1, et, ga).cpu().numpy(), g[f"y[{k}]"], rtol=2e-6, atol=1e-7, err_msg=k)
+        np.testing.assert_allclose(partial(f, gamma=ga, eta=et)(x, dim=-1).cpu().numpy(), g[f"y[{k}]"], rtol=2e-6, atol=1e-7, err_msg=k)
+        np.testing.assert_allclose(oa.SOFTMAX_MAPPING[k](x, dim=-1).cpu().numpy(), g[f"y[{k}]"], rtol=2e-6, atol=1e-7, err_msg=k)
+    k = "clippedsoftmax1(-.025:1)"
+    np.testing.assert_allclose(oa.ClipSoftmax_1(-1, 1.1, -0.025)(x).cpu().numpy(), g[f"y[{k}]"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(oa.ClipSoftmax(-1, 1.0, -0.025)(x).cpu().numpy(), g["y[clipped(-.025:1)]"], rtol=2e-6, atol=1e-7)
+    xt = x.t().contiguous()   # the callables' default dim is 1, as in the reference
+    np.testing.assert_allclose(oa.clipped_softmax(xt.t().contiguous().t(), 0, 1.0, -0.025).t().cpu().numpy(), g["y[clipped(-.025:1)]"], rtol=2e-6, atol=1e-7)
+
+
 def test_softmax_rows_dims_dtypes_and_long_rows(ops):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(3, 40, 17, generator=g)
