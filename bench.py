@@ -30,6 +30,10 @@ if ROOT not in sys.path:
 # OEH_BENCH_SHARE_ONE_GPU=1: run the N > 1 code path (own launcher, barriers, max-over-ranks, shard check) with every rank on
 # cuda:0 and gloo collectives - a plumbing test for boxes with one GPU (tests/test_multi_gpu.py); its line says so.
 SHARE_ONE_GPU = os.environ.get("OEH_BENCH_SHARE_ONE_GPU") == "1"
+# OEH_BENCH_STUB_CPU=1: the rank plumbing of the contract alone, WITHOUT any GPU (tests/test_dist_cpu.py: 8 ranks on gloo in the build
+# container): own launcher or torch.distributed.run, the WORLD_SIZE / --gpus guard, barriers around K no-op steps, max-over-ranks,
+# ranks_seen, exactly one JSON line from rank 0 - whose `value` is null and which says it is a stub.  Never a measurement.
+STUB_CPU = os.environ.get("OEH_BENCH_STUB_CPU") == "1"
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 WORKLOADS = {
@@ -347,6 +351,47 @@ def fp16_check():
     return out
 
 
+def stub_ranks(a, world, rank):
+    """OEH_BENCH_STUB_CPU=1 (see the top of the file): the N-rank protocol of main() on CPU ranks over gloo with a no-op step."""
+    import torch
+
+    from outeffhop_amd.dist import max_over_ranks, ranks_seen
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    x = torch.zeros(8)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        x += 1
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        x += 1
+    fence()
+    wall = time.perf_counter() - t0
+    seen = 1
+    if dist is not None:
+        wall = max_over_ranks(wall)
+        seen = ranks_seen()
+    if rank == 0:
+        print(json.dumps({"metric": "attention tokens/sec/GPU (OPT-125m S=512 softmax1); INT8 max-abs-err vs ref", "value": None,
+                          "unit": "attention-layer tokens/s (all GPUs)", "n_gpus": world, "rccl_ranks_seen": seen, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": wall * 1e3 / max(1, a.steps), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": None,
+                          "data": "none - CPU STUB of the rank plumbing (OEH_BENCH_STUB_CPU=1): no kernel ran, no GPU was touched, value is null",
+                          "stub": True, "config": {"workload": "stub", "parallelism": f"{world} CPU ranks over gloo [PLUMBING TEST]"}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     import numpy as np
@@ -359,7 +404,7 @@ def main():
         from outeffhop_amd.dist import launch_ranks
 
         have = torch.cuda.device_count()  # counting devices does not initialise the GPU
-        if have < a.gpus and not SHARE_ONE_GPU:
+        if have < a.gpus and not SHARE_ONE_GPU and not STUB_CPU:
             print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible; refusing to report a {a.gpus}-GPU line", file=sys.stderr)
             sys.exit(2)
         sys.exit(launch_ranks(os.path.abspath(__file__), a.gpus, sys.argv[1:]))
@@ -369,6 +414,8 @@ def main():
     if world != a.gpus:
         print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or without a launcher)", file=sys.stderr)
         sys.exit(2)
+    if STUB_CPU:
+        return stub_ranks(a, world, rank)
     if world > 1:
         import torch.distributed as dist
 

@@ -758,13 +758,161 @@ def gen_train_grads():
     save("train_grads.npz", **arrays)
 
 
+# --------------------------------------------------------------------------------------
+# Round 6: reference outputs at the shapes the FAST kernels run - long rows, 12 heads, the BASELINE cfg4
+# calibration - so that those paths are pinned to the reference directly, not only through the oracle.  Inputs and weights come from
+# tests/golden/synth.py (seeded numpy streams the tests regenerate); only the reference's outputs are stored.
+def _load_synth():
+    sys.path.insert(0, OUT)
+    import synth
+
+    return synth
+
+
+def gen_core_long():
+    """core_attn_long.npz: (a) OPT order, S = 512, causal, B = 1, H = 2, d = 64 - softmax1 / clippedsoftmax1(-.025:1) / vanilla;
+    (b) BERT order, S = 704 keys with left and right key padding, softmax1 / vanilla.  fp32 math on fp16-rounded inputs, as core_attn.npz."""
+    from transformers_language.models.softmax import SOFTMAX_MAPPING
+
+    sy = _load_synth()
+    arrays = {}
+    q, k, v = (torch.from_numpy(a) for a in sy.long_causal_qkv())
+    B, H, S, d = q.shape
+    mask = torch.from_numpy(sy.opt_decoder_mask(B, S, [S]))
+    for sm in ("softmax1", "clippedsoftmax1(-.025:1)", "vanilla"):
+        fn = SOFTMAX_MAPPING[sm]
+        sc = torch.bmm(q.view(B * H, S, d), k.view(B * H, S, d).transpose(1, 2)).view(B, H, S, S)     # opt_attention.py:204
+        sc = torch.max(sc + mask, torch.tensor(torch.finfo(torch.float32).min))                       # :220-224
+        p = fn(sc.view(B * H, S, S), dim=-1)                                                          # :232
+        arrays[f"opt512[{sm}].ctx"] = _np(torch.bmm(p, v.view(B * H, S, d)).view(B, H, S, d))          # :263
+        arrays[f"opt512[{sm}].probs_rowsum"] = _np(p.sum(-1).view(B, H, S))
+    q, k, v = (torch.from_numpy(a) for a in sy.long_padded_qkv())
+    B, H, S, d = q.shape
+    pad = torch.from_numpy(sy.key_padding(B, S, sy.LONG_PAD_LEFT, sy.LONG_PAD_RIGHT)).view(B, 1, 1, S)
+    for sm in ("softmax1", "vanilla"):
+        fn = SOFTMAX_MAPPING[sm]
+        sc = torch.matmul(q, k.transpose(-1, -2)) / np.sqrt(d)                                        # bert_attention.py:222,265
+        p = fn(sc + pad, dim=-1)                                                                      # :272,276
+        arrays[f"bert704[{sm}].ctx"] = _np(torch.matmul(p, v))                                        # :292
+    save("core_attn_long.npz", **arrays)
+
+
+class _Cfg12:
+    hidden_size = 768
+    num_attention_heads = 12
+    attention_probs_dropout_prob = 0.1
+    position_embedding_type = "absolute"
+    is_decoder = False
+    max_position_embeddings = 512
+
+
+def _load_synth_weights(mod, sy, seed, **kw):
+    shapes = {k_: tuple(v_.shape) for k_, v_ in mod.state_dict().items()}
+    sd = {k_: torch.from_numpy(v_) for k_, v_ in sy.state_dict_like(shapes, seed, **kw).items()}
+    mod.load_state_dict(sd, strict=True)
+    return mod.eval()
+
+
+def gen_h12():
+    """bert_attn_h12.npz / opt_attn_h12.npz: module I/O at E = 768, H = 12, S = 64, B = 2 (BERT-base / OPT-125m widths), one plain and
+    one gated case each; weights = synth.state_dict_like over the module's own state_dict names."""
+    from transformers_language.models.bert_attention import AttentionGateType, BertSelfAttentionWithExtras
+    from transformers_language.models.opt_attention import OPTAttentionWithExtras
+    from transformers_language.models.softmax import SOFTMAX_MAPPING
+
+    sy = _load_synth()
+    B, S, E, H = sy.H12_B, sy.H12_S, sy.H12_E, sy.H12_H
+    # ---- BERT: key padding (32 and 49 visible keys... of 64)
+    hidden = torch.from_numpy(sy.h12_hidden(6201))
+    mask = torch.from_numpy(sy.key_padding(B, S, [0, 0], [0, 15])).view(B, 1, 1, S)
+    arrays, meta = {}, []
+    for i, (sm, gc) in enumerate((("softmax1", "nogate"), ("softmax1", "tok_mlp"), ("clipped(-.025:1)", "nogate"))):
+        kw = dict(GATE_CASES[gc])
+        if "attn_gate_type" in kw:
+            kw["attn_gate_type"] = AttentionGateType[kw["attn_gate_type"]]
+        mod = _load_synth_weights(BertSelfAttentionWithExtras(_Cfg12(), softmax_fn=SOFTMAX_MAPPING[sm], **kw), sy, 6210 + i, w_std=0.04)
+        with torch.no_grad():
+            arrays[f"[{sm}|{gc}].ctx"] = _np(mod(hidden, attention_mask=mask)[0])
+        if mod.last_gate_avg_prob is not None:
+            arrays[f"[{sm}|{gc}].last_gate_avg_prob"] = _np(mod.last_gate_avg_prob)
+        meta.append(dict(softmax=sm, gate=gc, seed=6210 + i, w_std=0.04))
+    arrays["meta_json"] = np.array(json.dumps(meta))
+    save("bert_attn_h12.npz", **arrays)
+    # ---- OPT: decoder mask (causal + right padding of sample 1)
+    hidden = torch.from_numpy(sy.h12_hidden(6202))
+    mask = torch.from_numpy(sy.opt_decoder_mask(B, S, [S, 50]))
+    arrays, meta = {}, []
+    for i, (sm, gc) in enumerate((("softmax1", "nogate"), ("clippedsoftmax1(-.025:1)", "nogate"), ("softmax1", "tok_linear"))):
+        kw = dict(GATE_CASES[gc])
+        if "attn_gate_type" in kw:
+            kw["attn_gate_type"] = AttentionGateType[kw["attn_gate_type"]]
+        mod = _load_synth_weights(OPTAttentionWithExtras(E, H, is_decoder=True, softmax_fn=SOFTMAX_MAPPING[sm], **kw), sy, 6220 + i, w_std=0.04)
+        with torch.no_grad():
+            out, _, past = mod(hidden, attention_mask=mask)
+        arrays[f"[{sm}|{gc}].out"] = _np(out)
+        meta.append(dict(softmax=sm, gate=gc, seed=6220 + i, w_std=0.04))
+    arrays["meta_json"] = np.array(json.dumps(meta))
+    save("opt_attn_h12.npz", **arrays)
+
+
+def gen_cfg4_calib():
+    """cfg4_calib.npz (BASELINE.json config 4): the reference's QuantizedOPTAttentionWithExtras at OPT-125m size
+    (E = 768, H = 12, S = 512, B = 16), softmax1, asymmetric 8-bit activations, running_minmax with percentile 99.999 and EMA 0.9
+    (validate_clm.py:444-454) over 4 calibration batches (seeds 2000-2003); then for the evaluation batch (seed 2004) the index
+    HISTOGRAMS (256 bins) of the three attention quantisers, the output's max-abs / mean-abs and a few sampled output values.
+    Scalars and 3 x 256 integers - no tensors.  About two minutes of CPU time and ~6 GB."""
+    from transformers_language.models.opt_attention import OPTAttentionWithExtras
+    from transformers_language.models.quantized_opt import QuantizedOPTAttentionWithExtras
+    from transformers_language.models.softmax import SOFTMAX_MAPPING
+
+    sy = _load_synth()
+    B, S, E, H = sy.CFG4_B, sy.CFG4_S, sy.CFG4_E, sy.CFG4_H
+    torch.set_num_threads(8)
+    org = _load_synth_weights(OPTAttentionWithExtras(E, H, is_decoder=True, softmax_fn=SOFTMAX_MAPPING["softmax1"]), sy, sy.CFG4_WEIGHT_SEED, w_std=0.05)
+    qmod = QuantizedOPTAttentionWithExtras(org, **_qparams())
+    qmod.set_quant_state(weight_quant=True, act_quant=True)
+    qmod.eval()
+    mask = torch.from_numpy(sy.opt_decoder_mask(B, S, [S] * B))
+    arrays = {}
+    with torch.no_grad():
+        for i, seed in enumerate(sy.CFG4_CALIB_SEEDS):
+            qmod(torch.from_numpy(sy.cfg4_hidden(seed)), attention_mask=mask)
+            snap = {}
+            _dump_quantizers(f"after{i + 1}", qmod, snap)   # the EMA's trajectory, batch by batch
+            arrays.update(snap)
+            print(f"  calibration batch {i + 1} done", flush=True)
+        qmod.fix_ranges()
+        _dump_quantizers("final", qmod, arrays)
+        hist = {}
+
+        def mk(tag, m):
+            def hook(mod, inp, out):
+                idx = mod.activation_quantizer.quantizer.to_integer_forward(inp[0].detach())
+                hist[tag] = np.bincount(idx.to(torch.int64).flatten().numpy(), minlength=256).astype(np.int64)
+                hist[tag + ".in_absmax"] = np.float64(float(inp[0].abs().max()))
+
+            return m.register_forward_hook(hook)
+
+        hs = [mk("scores", qmod.attn_scores_act_quantizer), mk("probs", qmod.attn_probs_act_quantizer), mk("ctx", qmod.context_act_quantizer)]
+        out = qmod(torch.from_numpy(sy.cfg4_hidden(sy.CFG4_EVAL_SEED)), attention_mask=mask)[0]
+        for h in hs:
+            h.remove()
+    for k_, v_ in hist.items():
+        arrays[f"eval.hist.{k_}"] = v_
+    arrays["eval.out_absmax"] = np.float64(float(out.abs().max()))
+    arrays["eval.out_absmean"] = np.float64(float(out.abs().mean()))
+    arrays["eval.out_sample"] = _np(out[::2, ::7, ::11])     # 8 x 74 x 70 sampled outputs
+    save("cfg4_calib.npz", **arrays)
+    torch.set_num_threads(1)
+
+
 def main():
     only = set(sys.argv[1:])
     assert os.path.isdir(REF), "reference not mounted: golden fixtures can only be generated in the build container"
     torch.set_num_threads(1)  # deterministic reduction order for the captured outputs
     _shim()
     gens = [gen_softmax_rows, gen_fakequant, gen_range_estimators, gen_bert_fp, gen_opt_fp, gen_int8, gen_vit, gen_core_cases,
-            gen_stanhop, gen_theory_cfg1, gen_sparse_acts, gen_train_grads]
+            gen_stanhop, gen_theory_cfg1, gen_sparse_acts, gen_train_grads, gen_core_long, gen_h12, gen_cfg4_calib]
     sys.path.insert(0, os.path.join(REF, "OutEffHop"))
     for fn in gens:  # `make_golden.py gen_vit` regenerates one file
         if not only or fn.__name__ in only:

@@ -1029,6 +1029,43 @@ def _check_arithmetic_1e3(ops, q, k, v, want, msg, **kw):
     return err
 
 
+def test_long_rows_against_the_reference_itself(ops):
+    """Round 6 (VERDICT r5 next #2a): the kernels that serve LONG rows - the one-pass multi-tile loop (softmax1 / vanilla at S = 512 causal,
+    704 padded keys), the full-row NT = 32 kernel (clippedsoftmax1 at 512 keys), their fp32-storage forms - against outputs captured from
+    the REFERENCE at those shapes (tests/golden/core_attn_long.npz; inputs regenerated from tests/golden/synth.py), not only against the
+    oracle.  fp16 storage: the stated contract (1e-3 before the output rounding, + half an fp16 ulp stored); fp32 storage: 5e-4."""
+    from tests.golden import synth as sy
+
+    g = load_golden("core_attn_long.npz")
+    fmin = float(np.finfo(np.float32).min)
+    q, k, v = (torch.from_numpy(a) for a in sy.long_causal_qkv())
+    seen = set()
+    for sm in ("softmax1", "clippedsoftmax1(-.025:1)", "vanilla"):
+        want = g[f"opt512[{sm}].ctx"]
+        kw = dict(softmax=_spec(ops, sm), causal=True, clamp_min=True, mask_min=fmin)
+        q16, k16, v16 = q.half().cuda(), k.half().cuda(), v.half().cuda()
+        assert torch.equal(q16.float().cpu(), q)   # (the fixture's inputs are fp16 values)
+        seen.add(ops.attn_variant(1, sy.LONG_H, sy.LONG_S, sy.LONG_S, sy.LONG_D, torch.float16, clip=SPECS[sm]["clip"], causal=True).split("/")[0])
+        e16 = _check_fp16_contract(ops.attn_fwd(q16, k16, v16, **kw), want, f"reference S=512 causal {sm} fp16")
+        ea = _check_arithmetic_1e3(ops, q16, k16, v16, want, f"reference S=512 causal {sm}", **kw)
+        got32 = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), **kw)
+        _check(got32, want, dict(atol=5e-4, rtol=5e-4), f"reference S=512 causal {sm} fp32 storage")
+        gotb = ops.attn_fwd(q.bfloat16().cuda(), k.bfloat16().cuda(), v.bfloat16().cuda(), **kw)
+        wantb = O.attn_core(_np32(q.bfloat16()), _np32(k.bfloat16()), _np32(v.bfloat16()), causal=True, clamp_min=True, **SPECS[sm])
+        _check(gotb, wantb, BF16_TOL, f"S=512 causal {sm} bf16 (oracle on the bf16-rounded inputs)")
+        print(f"reference fixture S=512 causal {sm}: fp16 stored {e16:.2e}, before output rounding {ea:.2e}, fp32 storage {float(np.abs(_np32(got32) - want).max()):.2e}")
+    assert {"flash16", "fast16"} <= seen, seen   # both fast families were the ones measured
+    q, k, v = (torch.from_numpy(a) for a in sy.long_padded_qkv())
+    pad = torch.from_numpy(sy.key_padding(sy.LONG_PAD_B, sy.LONG_PAD_S, sy.LONG_PAD_LEFT, sy.LONG_PAD_RIGHT)).cuda()
+    for sm in ("softmax1", "vanilla"):
+        want = g[f"bert704[{sm}].ctx"]
+        kw = dict(softmax=_spec(ops, sm), scale_div=8.0, key_pad_mask=pad, mask_min=fmin)
+        e16 = _check_fp16_contract(ops.attn_fwd(q.half().cuda(), k.half().cuda(), v.half().cuda(), **kw), want, f"reference 704 padded keys {sm} fp16")
+        got32 = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), **kw)
+        _check(got32, want, dict(atol=5e-4, rtol=5e-4), f"reference 704 padded keys {sm} fp32 storage")
+        print(f"reference fixture 704 padded keys {sm}: fp16 stored {e16:.2e}, fp32 storage {float(np.abs(_np32(got32) - want).max()):.2e}")
+
+
 def test_full_size_bert_softmax1_cfg2(ops):
     """BASELINE config 2 at full size: BERT-base B=32 S=128 H=12 d=64 fp16, key-padding mask, softmax1.  Properties: a padded
     key never matters (bitwise), a sample's rows do not depend on its batch neighbours (bitwise), row sums < 1; oracle slices."""
@@ -2229,3 +2266,185 @@ def test_repeated_calls_reuse_a_prebuilt_descriptor(ops):
         from outeffhop_amd._lib import OehError
         with pytest.raises(OehError, match="forward-only"):
             ops.attn_fwd(q.clone().requires_grad_(True), k, v, scale_div=8.0, mask_min=fmin)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the OUTLIER regime - what the reference exists to measure (kurtosis / inf-norm of attention activations:
+# transformers_language/utils.py:9-20, validate_clm.py:596-621).  Every parity test above draws q, k, v from N(0, 1); here they are
+# heavy-tailed, carry outlier channels, saturate the 8-bit grids, or put a row's maximum in its LAST key tile by far more than the lazy
+# reference's 2^8 threshold.
+#
+# Contract for 16-bit storage in this regime, stated once and asserted below (measured on MI355X: margins of 3x ... 18x, printed per case):
+#     |hip - oracle| <= A * max(1, |V|max) + ulp_storage(oracle) / 2,     A = 1e-3 (fp16), 8e-3 (bf16);  fp32 storage: 5e-4 * max(1, |V|max) + 5e-4 |oracle|
+# with |V|max the largest |v| of the (b, h) slice.  Why it scales with V: the probabilities enter the second product rounded to the storage
+# dtype (2^-11 relative for fp16), so the absolute error of sum_j p_j v_j is at most 2^-11 * sum_j p_j |v_j| <= 2^-11 * |V|max - an ABSOLUTE
+# 1e-3 cannot hold once |V| > 2, by construction.  With N(0, 1) inputs the factor is 1 and this is north_star's 1e-3.
+# Large scores (|s| up to 180 here) cost nothing extra: the kernels subtract the row reference in fp32 before the exponential, as the
+# reference does.  The float64 evaluation of the same formula is printed beside each case: with outlier channels the reference's own fp32
+# arithmetic (the oracle) sits 1e-3 ... 2e-3 from it - the same order as the kernels' distance to the oracle.
+def _outlier_qkv(kind, B, H, S, D, seed):
+    """float32 (q already multiplied by D ** -0.5: OPT order), k, v for one outlier flavour."""
+    rs = np.random.RandomState(seed)
+    sh = (B, H, S, D)
+    if kind == "normal":         # unit variance (the baseline the other flavours are compared with)
+        q, k, v = rs.standard_normal(sh), rs.standard_normal(sh), rs.standard_normal(sh)
+    elif kind == "student_t3":   # heavy tails everywhere (kurtosis -> infinity)
+        q, k, v = rs.standard_t(3, sh), rs.standard_t(3, sh), rs.standard_t(3, sh)
+    elif kind == "channel":      # outlier channels of the hidden state show up in q, k and v alike (x6 / x20 / x60 on 2 of the 64 head channels)
+        q, k, v = rs.standard_normal(sh), rs.standard_normal(sh), rs.standard_normal(sh)
+        q[..., [5, 41]] *= 6.0
+        k[..., [5]] *= 20.0
+        v[..., [5, 41]] *= 60.0
+    elif kind == "last_tile_jump":   # the last 64 keys score ~ +25 (natural units) above everything before: the reference moves in the LAST tile, alpha ~ e^-25
+        q, k, v = rs.standard_normal(sh), rs.standard_normal(sh), rs.standard_normal(sh) * 3.0
+        u = rs.standard_normal(D)
+        u /= np.linalg.norm(u)
+        q += 8.0 * u
+        k[:, :, S - 64:] += 25.0 * u
+    elif kind == "ascending":    # scores grow ~0.25 per key: every 64-key tile lifts the row maximum by ~16 (23 in log2 units): the reference moves every tile
+        q, k, v = rs.standard_normal(sh) * 0.3, rs.standard_normal(sh) * 0.3, rs.standard_t(3, sh)
+        u = rs.standard_normal(D)
+        u /= np.linalg.norm(u)
+        q += 8.0 * u
+        k += (0.25 * np.arange(S))[None, None, :, None] * u
+    else:
+        raise ValueError(kind)
+    return (q * D ** -0.5).astype(np.float32), k.astype(np.float32), v.astype(np.float32)
+
+
+def _attn_f64(q, k, v, *, base, clip, gamma, eta, causal):
+    """the reference formula in float64 on the same (storage-rounded) inputs: how far the fp32 oracle itself is from exact arithmetic"""
+    s = np.matmul(q.astype(np.float64), np.swapaxes(k.astype(np.float64), -1, -2))
+    if causal:
+        S_ = s.shape[-1]
+        s = np.where(np.triu(np.ones((S_, S_), bool), 1), -np.inf, s)
+    m = s.max(-1, keepdims=True)
+    e = np.exp(s - m)
+    p = e / (e.sum(-1, keepdims=True) + (np.exp(-m) if base else 0.0))
+    if clip:
+        p = np.clip(p * (eta - gamma) + gamma, 0, 1)
+    return np.matmul(p, v.astype(np.float64)), np.abs(np.where(np.isfinite(s), s, 0.0)).max(axis=(-1, -2))
+
+
+def _outlier_limit(want, vmax, dt):
+    scale = np.maximum(1.0, vmax)[..., None, None]
+    if dt == torch.float32:
+        return 5e-4 * scale + 5e-4 * np.abs(want), scale
+    if dt == torch.float16:
+        return 1e-3 * scale + 0.5 * np.spacing(np.abs(want).astype(np.float16)).astype(np.float32), scale
+    return 8e-3 * scale + np.abs(want) * 2.0 ** -8, scale
+
+
+@pytest.mark.parametrize("kind", ["normal", "student_t3", "channel", "last_tile_jump", "ascending"])
+@pytest.mark.parametrize("path", ["one_pass", "one_pass_bf16", "full_row_clip", "vanilla", "fp32"])
+def test_outlier_inputs_16bit_and_fp32_storage(ops, kind, path):
+    """one-pass (softmax1, fp16 / bf16), full-row clipped, vanilla softmax, fp32 storage - S = 512 causal, the headline geometry."""
+    B, H, S, D = 2, 3, 512, 64
+    fmin = float(np.finfo(np.float32).min)
+    dt = {"one_pass_bf16": torch.bfloat16, "fp32": torch.float32}.get(path, torch.float16)
+    sm = {"full_row_clip": "clippedsoftmax1(-.025:1)", "vanilla": "vanilla"}.get(path, "softmax1")
+    q, k, v = (torch.from_numpy(a).to(dt) for a in _outlier_qkv(kind, B, H, S, D, 4000 + len(kind)))
+    qn, kn, vn = _np32(q), _np32(k), _np32(v)
+    want = O.attn_core(qn, kn, vn, causal=True, clamp_min=True, **SPECS[sm])
+    exact, smax = _attn_f64(qn, kn, vn, causal=True, **SPECS[sm])
+    vmax = np.abs(vn).max(axis=(-1, -2))
+    kw = dict(softmax=_spec(ops, sm), causal=True, clamp_min=True, mask_min=fmin)
+    var = ops.attn_variant(B, H, S, S, D, dt, clip=SPECS[sm]["clip"], causal=True)
+    got = _np32(ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), **kw))
+    assert np.isfinite(got).all(), f"{kind}/{path}: non-finite output"
+    err = np.abs(got - want)
+    lim, scale = _outlier_limit(want, vmax, dt)
+    rel = err / np.maximum(np.abs(want), 1e-3 * scale)
+    e_hip64, e_or64 = np.abs(got - exact).max(), np.abs(want - exact).max()
+    print(f"outlier {kind:15s} {path:14s} [{var}] |V|max {vmax.max():6.1f} |s|max {smax.max():6.1f}: abs err {err.max():.2e} (worst err/limit {float((err / lim).max()):.2f}), "
+          f"rel err {rel.max():.2e}; vs float64: kernel {e_hip64:.2e}, fp32 oracle {e_or64:.2e}")
+    _le(float((err / lim).max()), 1.0, f"outlier[{kind},{path}] err/limit")
+    assert (err <= lim).all(), f"{kind}/{path}: max abs err {err.max():.3e}, worst excess {float((err - lim).max()):.3e} (|V|max {vmax.max():.1f})"
+    if dt == torch.float16 and path in ("one_pass", "full_row_clip"):   # the arithmetic before the output rounding: the same scaled bound without the ulp term
+        a32 = _np32(ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), out_dtype=torch.float32, **kw))
+        assert (np.abs(a32 - want) <= 1e-3 * scale).all(), f"{kind}/{path}: arithmetic error {np.abs(a32 - want).max():.3e}"
+        print(f"        before the output rounding: abs err {np.abs(a32 - want).max():.2e} = {float((np.abs(a32 - want) / scale).max()):.2e} x max(1, |V|max)")
+
+
+@pytest.mark.parametrize("kind", ["student_t3", "channel", "scores_x4"])
+@pytest.mark.parametrize("dt", [torch.float16, torch.float32])
+def test_outlier_inputs_fused_int8_chain(ops, kind, dt):
+    """The fused fake-quant chain (fp16 and fp32 storage) on heavy-tailed / outlier-channel inputs and on SURVEY 8d cfg4's "scores x 4" variant
+    (the grids are calibrated on the unscaled data, then q is multiplied by 4: both ends of the score grid and the top of the probability grid
+    saturate).  Index dumps against the oracle: differences of one step only, rarer than FLIP_RATE; outputs on the oracle's grid point outside
+    flipped elements."""
+    B, H, S, D = 2, 2, 512, 64
+    fmin = float(np.finfo(np.float32).min)
+    base_kind = "normal" if kind == "scores_x4" else kind
+    q, k, v = (torch.from_numpy(a).to(dt) for a in _outlier_qkv(base_kind, B, H, S, D, 4100 + len(kind)))
+    common = dict(base=1, causal=True, clamp_min=True)
+    ctx_fp, fp = O.attn_core(_np32(q), _np32(k), _np32(v), want=("scores", "probs"), **common)
+    d_s = O.quant_range_to_params(*np.percentile(fp["scores"], (0.001, 99.999)))
+    d_p = O.quant_range_to_params(*np.percentile(fp["probs"], (0.001, 99.999)))
+    d_c = O.quant_range_to_params(*np.percentile(ctx_fp, (0.001, 99.999)))
+    if kind == "scores_x4":
+        q = (q.float() * 4.0).to(dt)
+    want, ex = O.attn_core(_np32(q), _np32(k), _np32(v), fq_scores=d_s, fq_probs=d_p, fq_ctx=d_c, ctx_quant_before_gate=True,
+                           want=("scores_idx", "probs_idx", "ctx_idx"), **common)
+    dumps = [torch.zeros((B, H, S, S), dtype=torch.uint8, device="cuda"), torch.zeros((B, H, S, S), dtype=torch.uint8, device="cuda"),
+             torch.zeros((B, H, S, D), dtype=torch.uint8, device="cuda")]
+    FQ = ops.FakeQuantSpec.from_delta
+    fq = ops.AttnFakeQuant(FQ(*d_s, dump=dumps[0]), FQ(*d_p, dump=dumps[1]), FQ(*d_c, dump=dumps[2]), ctx_before_gate=True)
+    kw = dict(causal=True, clamp_min=True, mask_min=fmin)
+    got = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=fq, **kw)
+    rates = []
+    for name, dump in zip(("scores", "probs", "ctx"), dumps):
+        want_idx = ex[f"{name}_idx"]
+        mx, rate = _flip_stats(dump.cpu().numpy(), want_idx)
+        rates.append(f"{name} flips {rate:.1e} (at 0 / 255: {float((want_idx == 0).mean()):.1%} / {float((want_idx == 255).mean()):.2%})")
+        assert mx <= 1 and _le(rate, FLIP_RATE, f"outlier_int8[{kind},{dt}] {name} flip rate", n=dump.numel()), f"{kind} {name}: max index diff {mx}, flip rate {rate:.2e}"
+    step = float(np.float32(d_c[0]))
+    err = np.abs(_np32(got) - want)
+    tol = 1e-3 + 1e-3 * np.abs(want) if dt == torch.float16 else 1e-5 + 1e-6 * np.abs(want)
+    off = float((err > tol).mean())
+    print(f"outlier int8 chain {kind:11s} {str(dt)[6:]:8s}: {', '.join(rates)}; outputs off their grid point {off:.1e}, max err {err.max() / step:.2f} steps")
+    assert _le(off, OUT_OFF, f"outlier_int8[{kind},{dt}] outputs off", n=err.size) and err.max() <= 1.05 * step + 2e-3
+    # the production form (no dumps) gives the same bits
+    got2 = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), fq=ops.AttnFakeQuant(FQ(*d_s), FQ(*d_p), FQ(*d_c), ctx_before_gate=True), **kw)
+    assert torch.equal(got, got2)
+
+
+@pytest.mark.parametrize("kind", ["student_t3", "channel", "scores_x4"])
+def test_outlier_inputs_int8_storage(ops, kind):
+    """The integer-matrix-core kernel (INT8 storage) with q / k / v grids calibrated on heavy-tailed / outlier-channel activations - the
+    percentile range clips the tails, so many indices sit at 0 / 255 - and with the score grid saturated ("scores x 4": the q grid's scale
+    multiplied by 4 after calibration).  Against the oracle on the dequantised values: at most one context-grid step, rarely."""
+    B, H, S, D = 2, 3, 512, 64
+    fmin = float(np.finfo(np.float32).min)
+    base_kind = "normal" if kind == "scores_x4" else kind
+    qf, kf, vf = _outlier_qkv(base_kind, B, H, S, D, 4200 + len(kind))
+    flat = lambda t: np.ascontiguousarray(t.transpose(0, 2, 1, 3).reshape(B, S, H * D))  # noqa: E731
+    scaling = D ** -0.5
+    # grids from the 99th percentile: ~2 % of the indices clip to 0 / 255 (a range estimator that ignores the tails, or a stale range)
+    (qi, qd, qg), (ki, kd, kg), (vi, vd, vg) = (_quantise_to_grid(flat(t), pct=99.0) for t in (qf / np.float32(scaling), kf, vf))
+    heads = lambda t: np.ascontiguousarray(t.reshape(B, S, H, D).transpose(0, 2, 1, 3))  # noqa: E731
+    qdh, kdh, vdh = heads(qd) * np.float32(scaling), heads(kd), heads(vd)
+    common = dict(base=1, causal=True, clamp_min=True)
+    ctx_fp, fp = O.attn_core(qdh, kdh, vdh, want=("scores", "probs"), **common)
+    d_s = O.quant_range_to_params(*np.percentile(fp["scores"], (0.001, 99.999)))
+    d_p = O.quant_range_to_params(*np.percentile(fp["probs"], (0.001, 99.999)))
+    d_c = O.quant_range_to_params(*np.percentile(ctx_fp, (0.001, 99.999)))
+    if kind == "scores_x4":
+        qg = (qg[0] * 4.0, qg[1])
+        qdh = qdh * np.float32(4.0)
+    want = O.attn_core(qdh, kdh, vdh, fq_scores=d_s, fq_probs=d_p, fq_ctx=d_c, ctx_quant_before_gate=True, **common)
+    FQ = ops.FakeQuantSpec.from_delta
+    fq = ops.AttnFakeQuant(FQ(*d_s), FQ(*d_p), FQ(*d_c), ctx_before_gate=True)
+    dev = lambda t: torch.from_numpy(t).cuda()  # noqa: E731
+    qc = ops.centre_indices(dev(qi)).view(B, S, H, D).permute(0, 2, 1, 3)
+    kc = ops.centre_indices(dev(ki)).view(B, S, H, D).permute(0, 2, 1, 3)
+    vt = ops.centre_indices(dev(vi)).view(B, S, H, D).permute(0, 2, 3, 1).contiguous()
+    grids = (ops.QuantGrid(*qg), ops.QuantGrid(*kg), ops.QuantGrid(*vg))
+    got = ops.attn_fwd_i8(qc, kc, vt, grids, fq=fq, out_dtype=torch.float32, softmax=ops.SoftmaxSpec(1, False, 0.0, 1.0), scale=scaling,
+                          causal=True, clamp_min=True, mask_min=fmin)
+    step = float(np.float32(d_c[0]))
+    err = np.abs(_np32(got) - want)
+    off = float((err > 1e-6 + 1e-6 * np.abs(want)).mean())
+    sat = [float(((t == 0) | (t == 255)).mean()) for t in (qi, ki, vi)]
+    print(f"outlier int8 storage {kind:11s}: q/k/v indices saturated {sat[0]:.2%} / {sat[1]:.2%} / {sat[2]:.2%}; outputs off their grid point {off:.1e}, max err {err.max() / step:.2f} steps")
+    assert err.max() <= 1.01 * step + 1e-6 and _le(off, 1e-3, f"outlier_i8[{kind}] outputs off", n=err.size)

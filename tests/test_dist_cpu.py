@@ -81,3 +81,32 @@ def test_bench_refuses_an_n_gpu_line_it_cannot_measure():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env={**env, "WORLD_SIZE": "2", "RANK": "0"},
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr and "n_gpus" not in r.stdout
+
+
+def test_bench_eight_rank_protocol_on_cpu_stub():
+    """`python bench.py --gpus 8` has never met 8 GPUs.  Its rank protocol - own launcher (one process per rank, started
+    before anything touches a GPU), the WORLD_SIZE guard, barriers, max-over-ranks, ranks_seen, ONE JSON line from rank 0 - runs here with 8
+    CPU ranks over gloo (OEH_BENCH_STUB_CPU=1: a no-op step, `value` null, the line says it is a stub), both through bench.py's own launcher
+    and as the driver starts it (`python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(OEH_BENCH_STUB_CPU="1", OMP_NUM_THREADS="1")
+    port = 29700 + (os.getpid() % 200)
+    cmds = [[sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2", "--no-check"],
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+             os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2", "--no-check"]]
+    for cmd in cmds:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 8 and rec["rccl_ranks_seen"] == 8 and rec["steps"] == 5 and rec["warmup"] == 2 and rec["scaling"] == "weak"
+        assert rec["stub"] is True and rec["value"] is None
+    # a launcher whose WORLD_SIZE disagrees with --gpus is refused in stub mode too
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env={**env, "WORLD_SIZE": "2", "RANK": "0"}, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr and "n_gpus" not in r.stdout

@@ -3,6 +3,7 @@ Modules run in fp32 here (the reference captured fp32): the kernel rounds q/k/v 
 the tolerance is the fp16 contract (1e-3 + 1e-3*|ref|, tests/test_attn_gpu.py) widened to 2e-3 for the out_proj that
 follows in OPT/ViT.  `-m gpu`."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -166,6 +167,155 @@ def test_theory_verification_config1(oa):
     w = {kk[2:]: torch.from_numpy(g[kk]).cuda() for kk in g.files if kk.startswith("w.")}
     full = torch.nn.functional.linear(out.reshape(4, 64, -1), w["out_projection.weight"], w["out_projection.bias"])
     _close(full, g["out_softmax1"], "cfg1 layer output")
+
+
+def _load_synth(mod, seed, w_std):
+    from tests.golden import synth as sy
+
+    shapes = {k_: tuple(v_.shape) for k_, v_ in mod.state_dict().items()}
+    mod.load_state_dict({k_: torch.from_numpy(v_) for k_, v_ in sy.state_dict_like(shapes, seed, w_std=w_std).items()}, strict=True)
+    return mod
+
+
+def test_modules_at_twelve_heads_against_the_reference(oa):
+    """Round 6 (VERDICT r5 next #2b): BERT-base / OPT-125m WIDTH (E = 768, H = 12, d = 64; S = 64, B = 2) - the 12-head strides the
+    BASELINE configs run with - against module outputs captured from the reference (bert_attn_h12.npz / opt_attn_h12.npz); weights and
+    inputs regenerated from tests/golden/synth.py.  fp32 modules (what the reference captured) and fp16 modules (fp16 kernels, the in-kernel
+    gate predictor) on the same weights."""
+    from tests.golden import synth as sy
+
+    class Cfg12(Cfg):
+        hidden_size = 768
+        num_attention_heads = 12
+        max_position_embeddings = 512
+
+    B, S, E, H = sy.H12_B, sy.H12_S, sy.H12_E, sy.H12_H
+    fmin16 = torch.finfo(torch.float16).min
+    g = load_golden("bert_attn_h12.npz")
+    hidden = torch.from_numpy(sy.h12_hidden(6201)).cuda()
+    mask = torch.from_numpy(sy.key_padding(B, S, [0, 0], [0, 15])).view(B, 1, 1, S).cuda()
+    for c in json.loads(str(g["meta_json"])):
+        want = g[f"[{c['softmax']}|{c['gate']}].ctx"]
+        m = _load_synth(oa.BertSelfAttentionWithExtras(Cfg12(), softmax_fn=oa.SOFTMAX_MAPPING[c["softmax"]], **gate_kwargs(c["gate"])), c["seed"], c["w_std"]).cuda().eval()
+        with torch.no_grad():
+            got = m(hidden, attention_mask=mask)[0]
+            _close(got, want, f"bert h12 {c} fp32")
+            if c["gate"] != "nogate":
+                _close(m.last_gate_avg_prob, g[f"[{c['softmax']}|{c['gate']}].last_gate_avg_prob"], f"bert h12 {c} gate avg", dict(atol=1e-4, rtol=1e-4))
+            got16 = m.half()(hidden.half(), attention_mask=mask.half().clamp(min=fmin16))[0]
+        # fp16 module: fp16 weights and hidden states (2^-11 relative each, through a 768-term dot product) on top of the kernel's contract
+        _close(got16, want, f"bert h12 {c} fp16", dict(atol=4e-3, rtol=4e-3))   # (measured 1.3e-3 ... 2.2e-3)
+        print(f"bert h12 {c['softmax']}|{c['gate']}: fp32 module max err {float(np.abs(got.cpu().numpy() - want).max()):.2e}, fp16 module {float(np.abs(got16.float().cpu().numpy() - want).max()):.2e}")
+    g = load_golden("opt_attn_h12.npz")
+    hidden = torch.from_numpy(sy.h12_hidden(6202)).cuda()
+    mask = torch.from_numpy(sy.opt_decoder_mask(B, S, [S, 50])).cuda()
+    for c in json.loads(str(g["meta_json"])):
+        want = g[f"[{c['softmax']}|{c['gate']}].out"]
+        m = _load_synth(oa.OPTAttentionWithExtras(E, H, is_decoder=True, softmax_fn=oa.SOFTMAX_MAPPING[c["softmax"]], **gate_kwargs(c["gate"])), c["seed"], c["w_std"]).cuda().eval()
+        with torch.no_grad():
+            got = m(hidden, attention_mask=mask)[0]
+            _close(got, want, f"opt h12 {c} fp32", dict(atol=2e-3, rtol=2e-3))
+            got16 = m.half()(hidden.half(), attention_mask=mask.half().clamp(min=fmin16))[0]
+        _close(got16, want, f"opt h12 {c} fp16", dict(atol=4e-3, rtol=4e-3))    # (measured 1.2e-3 ... 2.2e-3)
+        print(f"opt h12 {c['softmax']}|{c['gate']}: fp32 module max err {float(np.abs(got.cpu().numpy() - want).max()):.2e}, fp16 module {float(np.abs(got16.float().cpu().numpy() - want).max()):.2e}")
+
+
+# (measured on MI355X, round 6: attention / projection quantisers 4e-7 and 6e-5; out_proj's OUTPUT quantiser 3e-5 and 4e-3 - its
+# input is the quantised context, where one index flip in 1e5 among the ~60 largest outputs moves the 99.999th percentile)
+# eval on the reference's grids: 2.0e-3 of 41 440 sampled outputs one output-grid step off (never more) - every output sums 768 context indices
+# x weights, and the share of context indices that differ from the reference's by one step is 1.5e-5 (test_attn_gpu.py: cfg4 full size)
+CFG4_LIMITS = dict(delta=2e-6, zero=2e-4, delta_out=1e-4, zero_out=1e-2, hist=1e-4, steps=1.05, off=4e-3)   # hist: measured 7e-6 / 2e-6 / 3.6e-5 (scores / probs / ctx); the suite's FLIP_RATE
+
+
+def test_cfg4_calibration_and_eval_at_full_size_against_the_reference(oa):
+    """Round 6 (VERDICT r5 next #2c; BASELINE config 4): the reference's QuantizedOPTAttentionWithExtras at OPT-125m size
+    (E = 768, H = 12, S = 512, B = 16) calibrated over 4 batches (percentile 99.999, EMA 0.9: range_estimators.py:83-106) - its quantiser
+    scalars after EVERY batch, then for the evaluation batch the index histograms of the three attention quantisers and sampled outputs
+    (tests/golden/cfg4_calib.npz: scalars and 3 x 256 integers).  Here: the same flow through `oeh_attn_calibrate` + `oeh_percentile_ema`
+    (no S x S tensor), fix_ranges, the fused INT8 forward; the histograms from the index dumps of `oeh_attn_fwd` on the module's own
+    quantised q / k / v.  Limits (measured values are printed; CFG4_LIMITS): the calibrated delta of the three attention quantisers and of the
+    q / k / v projections' output quantisers within 2e-6 relative (measured 4e-7) and their zero_float within 2e-4 absolute after EACH batch;
+    out_proj's output quantiser - downstream of the quantised context - within 1e-4 / 1e-2; index histograms equal up to a 1e-4 share of moved
+    indices (measured 7e-6 / 2e-6 / 3.6e-5); with the reference's grids loaded, sampled outputs never more than one output-grid step off and at
+    most 4e-3 of them one step off (measured 2.0e-3)."""
+    from outeffhop_amd import ops
+    from tests.golden import synth as sy
+
+    g = load_golden("cfg4_calib.npz")
+    B, S, E, H = sy.CFG4_B, sy.CFG4_S, sy.CFG4_E, sy.CFG4_H
+    dev = torch.device("cuda:0")
+    org = _load_synth(oa.OPTAttentionWithExtras(E, H, is_decoder=True, softmax_fn=oa.SOFTMAX_MAPPING["softmax1"]), sy.CFG4_WEIGHT_SEED, 0.05)
+    qm = oa.QuantizedOPTAttentionWithExtras(org.to(dev), **_qparams(oa)).to(dev).eval()
+    qm.set_quant_state(weight_quant=True, act_quant=True)
+    mask = torch.from_numpy(sy.opt_decoder_mask(B, S, [S] * B)).to(dev)
+    names = [n for n, m_ in qm.named_modules() if hasattr(m_, "quantizer") and not n.endswith("range_estimator")]
+
+    def scalars(prefix):
+        """worst relative error of a calibrated delta / absolute error of a zero_float: (attention + q/k/v projection quantisers, out_proj's output quantiser)"""
+        worst = {False: [0.0, 0.0], True: [0.0, 0.0]}
+        detail = []
+        for n in names:
+            qz = qm.get_submodule(n).quantizer
+            key = f"{prefix}.q.{n}.delta"
+            if key not in g.files or getattr(qz, "_delta", None) is None:
+                continue
+            ref_d = float(g[key])
+            w_ = worst[n.startswith("out_proj.activation")]
+            w_[0] = max(w_[0], abs(float(qz._delta) - ref_d) / ref_d)
+            zk = f"{prefix}.q.{n}.zero_float"
+            if zk in g.files:
+                w_[1] = max(w_[1], abs(float(qz._zero_float) - float(g[zk])))
+            detail.append(f"{n.replace('.activation_quantizer', '').replace('_act_quantizer', '')}: {abs(float(qz._delta) - ref_d) / ref_d:.1e}")
+        if os.environ.get("OEH_TEST_VERBOSE"):
+            print("   ", prefix, "; ".join(detail))
+        return worst[False], worst[True]
+
+    with torch.no_grad():
+        for i, seed in enumerate(sy.CFG4_CALIB_SEEDS):
+            qm(torch.from_numpy(sy.cfg4_hidden(seed)).to(dev), attention_mask=mask)
+            (wd, wz), (od, oz) = scalars(f"after{i + 1}")
+            print(f"cfg4 calibration batch {i + 1}: worst delta rel err {wd:.2e}, worst zero_float abs err {wz:.2e}; out_proj's output quantiser {od:.2e} / {oz:.2e}")
+            assert wd <= CFG4_LIMITS["delta"] and wz <= CFG4_LIMITS["zero"] and od <= CFG4_LIMITS["delta_out"] and oz <= CFG4_LIMITS["zero_out"], (i, wd, wz, od, oz)
+        assert qm.__dict__.get("_fused_calib_calls", 0) == len(sy.CFG4_CALIB_SEEDS), "calibration materialised the score tensors"
+        qm.fix_ranges()
+        # the evaluation runs on the REFERENCE's calibrated grids (the fixture's `final.*` scalars written into the quantisers): a 3e-5 shift of the
+        # output grid alone would move ~1 % of the outputs that sit near a rounding boundary, and hide what the eval kernels themselves do
+        for n in names:
+            qz = qm.get_submodule(n).quantizer
+            if f"final.q.{n}.delta" in g.files and getattr(qz, "_delta", None) is not None:
+                qz._delta.copy_(torch.as_tensor(float(g[f"final.q.{n}.delta"]), dtype=qz._delta.dtype))
+                if f"final.q.{n}.zero_float" in g.files:
+                    qz._zero_float.copy_(torch.as_tensor(float(g[f"final.q.{n}.zero_float"]), dtype=qz._zero_float.dtype))
+        x = torch.from_numpy(sy.cfg4_hidden(sy.CFG4_EVAL_SEED)).to(dev)
+        out = qm(x, attention_mask=mask)[0]
+        assert qm.__dict__.get("_i8_calls", 0) >= 1, "the integer-matrix-core path did not run"
+        # ---- sampled outputs, in steps of the output quantiser's grid
+        step = float(g["final.q.out_proj.activation_quantizer.delta"])
+        err = np.abs(out[::2, ::7, ::11].float().cpu().numpy() - g["eval.out_sample"])
+        off, steps = float((err > 0.5 * step).mean()), float(err.max() / step)
+        am, mean = float(out.abs().max()), float(out.abs().mean())
+        print(f"cfg4 eval: sampled outputs > half a step off {off:.2e}, max error {steps:.2f} steps; |out| max {am:.4f} (reference {float(g['eval.out_absmax']):.4f}), "
+              f"mean {mean:.6f} (reference {float(g['eval.out_absmean']):.6f})")
+        assert steps <= CFG4_LIMITS["steps"] and off <= max(CFG4_LIMITS["off"], 2.0 / err.size)
+        assert abs(am - float(g["eval.out_absmax"])) <= 1.05 * step and abs(mean - float(g["eval.out_absmean"])) <= 1e-3 * float(g["eval.out_absmean"])
+        # ---- index histograms of the three attention quantisers: oeh_attn_fwd with index dumps on the module's own quantised q / k / v
+        d = E // H
+        heads = lambda t: t.view(B, S, H, d).permute(0, 2, 1, 3)  # noqa: E731
+        q, k, v = heads(qm.q_proj(x) * qm.scaling), heads(qm.k_proj(x)), heads(qm.v_proj(x))
+        dumps = [torch.zeros((B, H, S, S), dtype=torch.uint8, device=dev), torch.zeros((B, H, S, S), dtype=torch.uint8, device=dev),
+                 torch.zeros((B, H, S, d), dtype=torch.uint8, device=dev)]
+        FQ = ops.FakeQuantSpec.from_delta
+        trio = [getattr(qm, n).activation_quantizer.quantizer for n in ("attn_scores_act_quantizer", "attn_probs_act_quantizer", "context_act_quantizer")]
+        fq = ops.AttnFakeQuant(*(FQ(float(z._delta), float(z._zero_float), dump=t_) for z, t_ in zip(trio, dumps)), ctx_before_gate=True)
+        ops.attn_fwd(q, k, v, fq=fq, causal=True, clamp_min=True, mask_min=float(np.finfo(np.float32).min))
+        for name, t_ in zip(("scores", "probs", "ctx"), dumps):
+            h = torch.bincount(t_.flatten().to(torch.int64), minlength=256).cpu().numpy()
+            ref = g[f"eval.hist.{name}"]
+            assert h.sum() == ref.sum()
+            moved = float(np.abs(h - ref).sum()) / 2.0 / float(ref.sum())
+            print(f"cfg4 eval {name} index histogram: share of indices in another bin than the reference's {moved:.2e} (bins used {int((ref > 0).sum())}, "
+                  f"saturated low / high {int(ref[0])} / {int(ref[255])})")
+            assert moved <= CFG4_LIMITS["hist"], (name, moved)
 
 
 def _qparams(oa):

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("workload", ["opt_softmax1", "bert_gated"])
+@pytest.mark.parametrize("workload", ["opt_softmax1", "bert_gated", "opt_int8"])
 def test_bench_two_ranks_over_rccl(workload):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs")
@@ -36,7 +36,7 @@ def test_bench_two_ranks_plumbing_on_one_gpu():
         pytest.skip("no GPU")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env["OEH_BENCH_SHARE_ONE_GPU"] = "1"
-    for workload in ("opt_softmax1", "bert_gated"):
+    for workload in ("opt_softmax1", "bert_gated", "opt_int8", "opt_int8_i8"):   # (bert_gated: B = 32 per rank, BASELINE config 5's shard)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload],
                            env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]

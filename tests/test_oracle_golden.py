@@ -244,3 +244,71 @@ def test_eager_torch_matches_golden():
     assert (np.abs(out.numpy() - want) > 1e-5).mean() < 2e-3
     m = E.causal_mask(2, 5)
     assert m.shape == (2, 1, 5, 5) and m[0, 0, 0, 1] == torch.finfo(torch.float32).min and m[0, 0, 1, 0] == 0
+
+
+# ---- round 6: the oracle against reference outputs at the shapes the fast kernels run (inputs regenerated from tests/golden/synth.py)
+def test_core_long_rows_against_reference():
+    """core_attn_long.npz: OPT order at S = 512 causal (3 softmax kinds) and BERT order at 704 keys with left + right key padding."""
+    from tests.golden import synth as sy
+
+    g = load_golden("core_attn_long.npz")
+    tbl = O.softmax_table()
+    q, k, v = sy.long_causal_qkv()
+    for sm in ("softmax1", "clippedsoftmax1(-.025:1)", "vanilla"):
+        b, ga, et = tbl[sm]
+        ctx, ex = O.attn_core(q, k, v, base=b, gamma=ga, eta=et, clip=not (ga == 0.0 and et == 1.0), causal=True, clamp_min=True, want=("probs",))
+        np.testing.assert_allclose(ctx, g[f"opt512[{sm}].ctx"], err_msg=sm, **MM)
+        np.testing.assert_allclose(ex["probs"].sum(-1), g[f"opt512[{sm}].probs_rowsum"], err_msg=sm, rtol=2e-5, atol=2e-6)
+    q, k, v = sy.long_padded_qkv()
+    pad = sy.key_padding(sy.LONG_PAD_B, sy.LONG_PAD_S, sy.LONG_PAD_LEFT, sy.LONG_PAD_RIGHT)
+    for sm in ("softmax1", "vanilla"):
+        b, ga, et = tbl[sm]
+        ctx = O.attn_core(q, k, v, scale=math.sqrt(q.shape[-1]), scale_is_divisor=True, base=b, pad_mask=pad)
+        np.testing.assert_allclose(ctx, g[f"bert704[{sm}].ctx"], err_msg=sm, **MM)
+
+
+def _synth_state(shapes, seed, w_std):
+    from tests.golden import synth as sy
+
+    return sy.state_dict_like(shapes, seed, w_std=w_std)
+
+
+def _gate_shapes(E, H, gate):
+    d = E // H
+    sh = {}
+    if gate == "tok_linear":
+        for h in range(H):
+            sh[f"alpha.{h}.weight"], sh[f"alpha.{h}.bias"] = (1, d), (1,)
+    elif gate == "tok_mlp":
+        for h in range(H):
+            sh[f"alpha.{h}.0.weight"], sh[f"alpha.{h}.0.bias"] = (d // 4, d), (d // 4,)
+            sh[f"alpha.{h}.2.weight"], sh[f"alpha.{h}.2.bias"] = (1, d // 4), (1,)
+    return sh
+
+
+def test_modules_at_twelve_heads_against_reference():
+    """bert_attn_h12.npz / opt_attn_h12.npz: E = 768, H = 12, S = 64, B = 2 - plain, clipped and gated cases."""
+    from tests.golden import synth as sy
+
+    tbl = O.softmax_table()
+    E, H, B, S = sy.H12_E, sy.H12_H, sy.H12_B, sy.H12_S
+    g = load_golden("bert_attn_h12.npz")
+    hidden = sy.h12_hidden(6201)
+    mask = sy.key_padding(B, S, [0, 0], [0, 15]).reshape(B, 1, 1, S)
+    for c in json.loads(str(g["meta_json"])):
+        shapes = {f"{n}.{p_}": ((E, E) if p_ == "weight" else (E,)) for n in ("query", "key", "value") for p_ in ("weight", "bias")}
+        shapes.update(_gate_shapes(E, H, c["gate"]))
+        sd = _synth_state(shapes, c["seed"], c["w_std"])
+        b, ga, et = tbl[c["softmax"]]
+        ctx = O.bert_self_attention(sd, hidden, H, mask=mask, base=b, gamma=ga, eta=et, clip=not (ga == 0.0 and et == 1.0))
+        np.testing.assert_allclose(ctx, g[f"[{c['softmax']}|{c['gate']}].ctx"], err_msg=str(c), rtol=2e-5, atol=5e-6)
+    g = load_golden("opt_attn_h12.npz")
+    hidden = sy.h12_hidden(6202)
+    mask = sy.opt_decoder_mask(B, S, [S, 50])
+    for c in json.loads(str(g["meta_json"])):
+        shapes = {f"{n}.{p_}": ((E, E) if p_ == "weight" else (E,)) for n in ("q_proj", "k_proj", "v_proj", "out_proj") for p_ in ("weight", "bias")}
+        shapes.update(_gate_shapes(E, H, c["gate"]))
+        sd = _synth_state(shapes, c["seed"], c["w_std"])
+        b, ga, et = tbl[c["softmax"]]
+        out = O.opt_attention(sd, hidden, H, mask=mask, base=b, gamma=ga, eta=et, clip=not (ga == 0.0 and et == 1.0))
+        np.testing.assert_allclose(out, g[f"[{c['softmax']}|{c['gate']}].out"], err_msg=str(c), rtol=2e-5, atol=2e-5)
