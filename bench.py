@@ -54,6 +54,12 @@ WORKLOADS = {
     "opt_int8_i8": dict(B=16, H=12, S=512, d=64, order="opt", sm=(1, False, 0.0, 1.0), int8=True, gate=False, i8=True,
                         desc="OPT-125m attention core B=16 H=12 S=512 d=64 causal softmax1, q/k/v as int8 indices of 8-bit grids (v transposed), "
                              "both products on v_mfma_i32_16x16x64_i8, 3 fused INT8 quantisers, fp32 output"),
+    # ... and with the output the quantised modules REALLY ask for (quantization.py: QuantizedOPTAttentionWithExtras, `ctx_emit_index`): the context
+    # quantiser's centred indices as int8, what the int8 x int8 out_proj takes - 25.2 MB of algorithmic traffic instead of 44 MB (VERDICT r5 weak #5:
+    # the fp32 output above flatters the roofline fraction of the same launch time)
+    "opt_int8_i8_o8": dict(B=16, H=12, S=512, d=64, order="opt", sm=(1, False, 0.0, 1.0), int8=True, gate=False, i8=True, o8=True,
+                           desc="OPT-125m attention core B=16 H=12 S=512 d=64 causal softmax1, q/k/v int8 indices in, context-quantiser int8 indices out "
+                                "(ctx_emit_index: what QuantizedOPTAttentionWithExtras runs), both products on v_mfma_i32_16x16x64_i8"),
     # STanHop's Association (cross_models/hopfield.py:42-51): B*data_dim = 32*7 series, L = S = 28 segments, H = 4, E = 64, fp32
     "stanhop": dict(B=224, H=4, S=28, d=64, order="none", sm=(1, False, 0.0, 1.0), int8=False, gate=False, fp32=True, layers=48,
                     desc="STanHop Association B*data_dim=224 L=S=28 H=4 E=64 fp32 softmax1, (B,L,H,E) layout: one wave per (batch, head)"),
@@ -348,6 +354,36 @@ def fp16_check():
                      "stored_output_within_1e-3_plus_half_fp16_ulp_of_reference": bool((e16 <= 1e-3 + half_ulp).all()),
                      "max_abs_reference": float(np.abs(want).max())}
     out["sample"] = f"B={B} H={H} S={S} d={D} fp16 causal, vs oracle/oeh_oracle.py (fp32 reference arithmetic on the fp16 values)"
+    # The regime the reference measures (activation outliers: transformers_language/utils.py:9-20): Student-t(3) q / k / v and outlier channels
+    # (x20 on a key channel, x60 on two value channels).  An ABSOLUTE 1e-3 cannot hold once |V| > 2 - the probabilities enter the second product
+    # rounded to fp16 (2^-11 relative) - so the contract scales with the values: |err| <= 1e-3 max(1, |V|max) + ulp16(ref) / 2
+    # (tests/test_attn_gpu.py: test_outlier_inputs_16bit_and_fp32_storage, where it is asserted per (b, h) slice).
+    heavy = {}
+    for kind in ("student_t3", "outlier_channels"):
+        rs = np.random.RandomState(77)
+        if kind == "student_t3":
+            qn, kn, vn = (rs.standard_t(3, (B, H, S, D)) for _ in range(3))
+        else:
+            qn, kn, vn = (rs.standard_normal((B, H, S, D)) for _ in range(3))
+            qn[..., [5, 41]] *= 6.0
+            kn[..., [5]] *= 20.0
+            vn[..., [5, 41]] *= 60.0
+        qh, kh, vh = (torch.from_numpy(np.asarray(a, np.float32)) for a in (qn * D ** -0.5, kn, vn))
+        qh, kh, vh = qh.half(), kh.half(), vh.half()
+        want = O.attn_core(qh.float().numpy(), kh.float().numpy(), vh.float().numpy(), base=1, causal=True, clamp_min=True)
+        kw = dict(softmax=ops.SoftmaxSpec(1, False, 0.0, 1.0), causal=True, clamp_min=True, mask_min=fmin)
+        got16 = ops.attn_fwd(qh.cuda(), kh.cuda(), vh.cuda(), **kw).float().cpu().numpy()
+        got32 = ops.attn_fwd(qh.cuda(), kh.cuda(), vh.cuda(), out_dtype=torch.float32, **kw).cpu().numpy()
+        vmax = np.abs(vh.float().numpy()).max(axis=(-1, -2))[..., None, None]
+        scale = np.maximum(1.0, vmax)
+        half_ulp = 0.5 * np.spacing(np.abs(want).astype(np.float16)).astype(np.float32)
+        e16, e32 = np.abs(got16 - want), np.abs(got32 - want)
+        heavy[kind] = {"V_abs_max": float(vmax.max()), "max_abs_err_fp16_output": float(e16.max()),
+                       "max_abs_err_before_output_rounding": float(e32.max()),
+                       "arithmetic_err_over_max(1,|V|max)": float((e32 / scale).max()),
+                       "within_1e-3_x_max(1,|V|max)_plus_half_fp16_ulp": bool((e16 <= 1e-3 * scale + half_ulp).all()),
+                       "within_absolute_1e-3_plus_half_fp16_ulp": bool((e16 <= 1e-3 + half_ulp).all())}
+    out["heavy_tailed"] = heavy
     return out
 
 
@@ -444,7 +480,7 @@ def main():
     # ---- synthetic inputs, resident in HBM before the timed region; one buffer set per layer.  Per-rank data come from a
     # generator seeded with the rank (so that rank 0 can regenerate any rank's shard for the parity check); the gate
     # predictor weights are replicated (one seed for all ranks).
-    sdt = torch.float32 if (w.get("fp32") or w.get("i8")) else torch.float16  # (i8: the dtype of o)
+    sdt = torch.int8 if w.get("o8") else torch.float32 if (w.get("fp32") or w.get("i8")) else torch.float16  # (i8: the dtype of o)
 
     def gen_layers(r, n_layers):
         """CPU tensors of rank r's first n_layers layers: [(q, k, v, gate_in | None)], (B,S,E) fp16 values."""
@@ -510,7 +546,7 @@ def main():
         dsc = _lib.oeh_attn_desc()
         dsc.B, dsc.H, dsc.Sq, dsc.Sk, dsc.D, dsc.dtype = B, H, S, S, d, (_lib.OEH_I8 if w.get("i8") else _lib.OEH_F32 if w.get("fp32") else _lib.OEH_F16)
         if w.get("i8"):
-            dsc.o_dtype = _lib.OEH_F32
+            dsc.o_dtype = _lib.OEH_I8 if w.get("o8") else _lib.OEH_F32
             for name, (sc_, zp_) in zip(("q_grid", "k_grid", "v_grid"), I8_GRIDS):
                 getattr(dsc, name).scale, getattr(dsc, name).zero_point = sc_, zp_
         for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", o)):
@@ -534,6 +570,7 @@ def main():
             fqd = _lib.oeh_fq_desc()
             ops._fill_fq(fqd.scores, fq.scores), ops._fill_fq(fqd.probs, fq.probs), ops._fill_fq(fqd.ctx, fq.ctx)
             fqd.ctx_quant_before_gate = int(fq.ctx_before_gate)
+            fqd.ctx_emit_index = int(bool(w.get("o8")))
         args = (C.byref(dsc), C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()),
                 C.c_void_p(o.data_ptr()), None if fqd is None else C.byref(fqd))
         return args, (dsc, fqd)
@@ -660,7 +697,7 @@ def main():
         layer_tokens = world * B * S * L * a.steps
         kern_s = dev_ms * 1e-3 / launches
         elt = 4 if w.get("fp32") else 2
-        alg_bytes = (3 * B * H * S * d * 1 + B * H * S * d * 4 + (B * S * 4 if pad is not None else 0)) if w.get("i8") else 4 * B * H * S * d * elt + (B * S * 4 if pad is not None else 0) + (B * S * H * d * elt if gate is not None else 0)  # + gate input (hidden states)
+        alg_bytes = (3 * B * H * S * d * 1 + B * H * S * d * (1 if w.get("o8") else 4) + (B * S * 4 if pad is not None else 0)) if w.get("i8") else 4 * B * H * S * d * elt + (B * S * 4 if pad is not None else 0) + (B * S * H * d * elt if gate is not None else 0)  # + gate input (hidden states)
         achieved = alg_bytes / kern_s / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -684,7 +721,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int8 index storage of q/k/v, i32 matrix-core accumulation, f32 output, 8-bit fake-quant grids" if w.get("i8") else ("f32 storage, f16 (hi,lo) operand pairs on the matrix cores = f32-accurate products, f32 accumulate" if w.get("fp32") else "f16 storage, f32 accumulate") + (", 8-bit fake-quant grids" if w["int8"] else ""),
+            "dtype": ("int8 index storage of q/k/v, i32 matrix-core accumulation, int8 index output, 8-bit grids" if w.get("o8") else "int8 index storage of q/k/v, i32 matrix-core accumulation, f32 output, 8-bit fake-quant grids") if w.get("i8") else ("f32 storage, f16 (hi,lo) operand pairs on the matrix cores = f32-accurate products, f32 accumulate" if w.get("fp32") else "f16 storage, f32 accumulate") + (", 8-bit fake-quant grids" if w["int8"] else ""),
             "data": "synthetic",
             "config": {
                 "workload": w["desc"], "variant": (lib.oeh_attn_variant(calls[0][0][0], calls[0][0][5]) or b"?").decode(),  # what the library picks for the timed descriptor

@@ -207,6 +207,19 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     ++nx_tile;
     nx_slot = (nx_slot == R - 1) ? 0 : nx_slot + 1;
   };
+  // (round 6, OEH_PIPE_QK == 1: the same stage request in its 2 G pieces, so that the placed tile can put one behind each sub-tile's score MFMAs;
+  // full stages only - the ragged last stage is never requested from inside a tile: the caller tests `nx_tile * 64 + 64 <= Sk`)
+  auto issue_piece = [&](const int p) {
+    const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(nx_slot * STAGEB + wave * G * 1024));
+    if (p < G) glds16_s(kcur, koff[p], slot + p * 1024);
+    else glds16_s(vcur, voff[p - G], slot + TILEB + (p - G) * 1024);
+  };
+  auto issue_advance = [&]() {
+    kcur += kstep;
+    vcur += vstep;
+    ++nx_tile;
+    nx_slot = (nx_slot == R - 1) ? 0 : nx_slot + 1;
+  };
   // ---- Q rides the same LDS-DMA stream, FIRST, into the stage the ring does not use yet (slab j as a K-shaped tile at
   // j*TILEB of stage R-1).  The bytes a workgroup needs before its first MFMA are then Q + K tile 0; with Q as ordinary
   // register loads behind the first two stages (returns are in issue order) they were Q + 2 K tiles + 2 V tiles, and the
@@ -457,7 +470,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   asm volatile("" : "+v"(ones_live));
   // ---- one 64-key tile for blocks J0..MQ-1 of this wave (J0 = 1: block 0's rows end before this tile)
   // MODE 0: the one-pass tile; CLIP: 1 = statistics pass (no second product), 2 = final pass (final reference, clip)
-  auto tile = [&](auto j0c, auto firstc, auto modec, auto nsc, const int i, const int soff) {
+  auto tile = [&](auto j0c, auto firstc, auto modec, auto nsc, const int i, const int soff, const bool in_tile_issue = false) {
     constexpr int J0 = decltype(j0c)::value;
     constexpr bool FIRST = decltype(firstc)::value;  // tile 0: V tile 0 is awaited between the two products
     constexpr int MODE = decltype(modec)::value;
@@ -490,9 +503,66 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     // S^T = K Q^T; every K fragment is read once and used by all active blocks
     __builtin_amdgcn_s_setprio(1);  // matrix-core phases at a higher issue priority than the other waves' softmax arithmetic (dense S=512: -2.7 %)
     f4 s[MQ][4];
+#ifdef OEH_PIPE_QK
+    // Round 6, measured and NOT landed (profiles/r06_headline_tile_asm.txt): the FIRST half of the steady-state tile as a placed order too - the scale /
+    // reference step of sub-tile s between the score MFMAs of sub-tile s + 1 (pinned by scheduling barriers; the compiler keeps its own hazard distances),
+    // and (OEH_PIPE_QK == 1) the next stage's LDS-DMA requests one piece behind each sub-tile's MFMAs instead of all four at the top of the tile.
+    constexpr bool PIPE_QK = PIPE_PV && NSP == 0x44 && !has_pad && D == 64;
+#else
+    constexpr bool PIPE_QK = false;
+#endif
+    if constexpr (PIPE_QK) {
+      auto score_sub = [&](const int sub) {
+        u4 kf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const u4*>(kaddr[ks] + soff + sub * 16 * ROWB);
+#pragma unroll
+        for (int j = J0; j < MQ; ++j) {
+          f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+          for (int ks = 0; ks < KS; ++ks) acc = mfma16<IN>(kf[ks], qf[j][ks], acc);
+          s[j][sub] = acc;
+        }
+      };
+      auto scale_sub = [&](const int sub) {
+#pragma unroll
+        for (int j = J0; j < MQ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[j][sub][r] = __builtin_fmaf(s[j][sub][r], c1, mcneg[j]);
+#pragma unroll
+        for (int j = J0; j < MQ; ++j) asm volatile("" : "+v"(s[j][sub]));   // (pins the step HERE: the compiler otherwise sinks it to its first use behind the last MFMA)
+      };
+      auto piece = [&](const int p) {
+#if OEH_PIPE_QK == 1
+        if (in_tile_issue) issue_piece(p);
+#endif
+      };
+      score_sub(0);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(0);
+      score_sub(1);
+      __builtin_amdgcn_sched_barrier(0);
+      scale_sub(0);
+      piece(1);
+      __builtin_amdgcn_sched_barrier(0);
+      score_sub(2);
+      __builtin_amdgcn_sched_barrier(0);
+      scale_sub(1);
+      piece(2);
+      __builtin_amdgcn_sched_barrier(0);
+      score_sub(3);
+      __builtin_amdgcn_sched_barrier(0);
+      scale_sub(2);
+      piece(3);
+#if OEH_PIPE_QK == 1
+      if (in_tile_issue) issue_advance();
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
+      scale_sub(3);
+    }
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
-      if (sub >= NSMAX) continue;
+      if (PIPE_QK || sub >= NSMAX) continue;
       u4 kf[KS], kl[SRC32 ? KS : 1];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -516,7 +586,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
         s[j][sub] = acc;
       }
     }
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (!PIPE_QK) __builtin_amdgcn_s_setprio(0);
     u4 pb[MQ][2];
 #if OEH_KO == 3
 #pragma unroll
@@ -581,7 +651,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (sub < NSa[j]) s[j][sub][r] = __builtin_fmaf(s[j][sub][r], c1, mcneg[j]);
+          if (!PIPE_QK && sub < NSa[j]) s[j][sub][r] = __builtin_fmaf(s[j][sub][r], c1, mcneg[j]);
     }
     // causal / tail mask, classified per 16x16 sub-tile with wave-uniform tests: untouched, all masked, or mixed
 #pragma unroll
@@ -969,7 +1039,15 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     // into the stage every wave finished reading one iteration ago.  (Requesting it later, behind the score MFMAs just
     // queued - a wave spends ~350 cycles per tile issuing its four 1-KiB pieces - measured no better: 21.9-22.4 vs 21.5-21.7 us
     // on dense S=512, equal on the causal shape.)
+#if defined(OEH_PIPE_QK) && OEH_PIPE_QK == 1
+    // the request rides inside the tile (one piece behind each sub-tile's score MFMAs) where the tile is a full placed one; elsewhere here, as before
+    const bool full_tile = (TP == 0) && !SRC32 && !PAD && D == 64 && i < nkb[MQ - 1] && !(MQ == 2 && i >= nkb[0] && NSV && ((lh[1] - 64 * i) >> 4) + 1 < 4);
+    const bool ride = (i + 2 < n_kt) && full_tile && (nx_tile * 64 + 64 <= Sk);
+    if (i + 2 < n_kt && !ride) issue_next();
+#else
+    constexpr bool ride = false;
     if (i + 2 < n_kt) issue_next();
+#endif
     if (i < 8) OEH_STAMP(5 + 3 * i);
     const int soff = slot_i * STAGEB;
     slot_i = (slot_i == R - 1) ? 0 : slot_i + 1;
@@ -983,22 +1061,22 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
           if (n1 == 1) tile(J0_1{}, std::false_type{}, MODE_A{}, std::integral_constant<int, 0x14>{}, i, soff);
           else if (n1 == 2) tile(J0_1{}, std::false_type{}, MODE_A{}, std::integral_constant<int, 0x24>{}, i, soff);
           else if (n1 == 3) tile(J0_1{}, std::false_type{}, MODE_A{}, std::integral_constant<int, 0x34>{}, i, soff);
-          else tile(J0_1{}, std::false_type{}, MODE_A{}, NS_FULL{}, i, soff);
+          else tile(J0_1{}, std::false_type{}, MODE_A{}, NS_FULL{}, i, soff, ride);
         } else {
-          tile(J0_1{}, std::false_type{}, MODE_A{}, NS_FULL{}, i, soff);
+          tile(J0_1{}, std::false_type{}, MODE_A{}, NS_FULL{}, i, soff, ride);
         }
       }
     } else {
-      if constexpr (NSV && (OEH_NSUB_MASK & 2)) {
+      if constexpr (NSV && (OEH_NSUB_MASK & 28) != 0) {
         const int n0 = ((lh[0] - 64 * i) >> 4) + 1;
         const int nl = ((lh[MQ - 1] - 64 * i) >> 4) + 1;   // the last block: full, or (MQ == 1) the block itself
         if (MQ == 2 && nl < 4) tile(J0_0{}, std::false_type{}, MODE_A{}, NS_FULL{}, i, soff);   // (both blocks partial - Sq != Sk layouts: the general body)
-        else if (n0 == 1) tile(J0_0{}, std::false_type{}, MODE_A{}, std::integral_constant<int, 0x41>{}, i, soff);
-        else if (n0 == 2) tile(J0_0{}, std::false_type{}, MODE_A{}, std::integral_constant<int, 0x42>{}, i, soff);
-        else if (n0 == 3) tile(J0_0{}, std::false_type{}, MODE_A{}, std::integral_constant<int, 0x43>{}, i, soff);
-        else tile(J0_0{}, std::false_type{}, MODE_A{}, NS_FULL{}, i, soff);
+        else if (n0 == 1 && (OEH_NSUB_MASK & 4)) tile(J0_0{}, std::false_type{}, MODE_A{}, std::integral_constant<int, 0x41>{}, i, soff);
+        else if (n0 <= 2 && (OEH_NSUB_MASK & 8)) tile(J0_0{}, std::false_type{}, MODE_A{}, std::integral_constant<int, 0x42>{}, i, soff);
+        else if (n0 == 3 && (OEH_NSUB_MASK & 16)) tile(J0_0{}, std::false_type{}, MODE_A{}, std::integral_constant<int, 0x43>{}, i, soff);
+        else tile(J0_0{}, std::false_type{}, MODE_A{}, NS_FULL{}, i, soff, ride);
       } else {
-        tile(J0_0{}, std::false_type{}, MODE_A{}, NS_FULL{}, i, soff);
+        tile(J0_0{}, std::false_type{}, MODE_A{}, NS_FULL{}, i, soff, ride);
       }
     }
     if (i < 8) OEH_STAMP(6 + 3 * i);
