@@ -1081,28 +1081,28 @@ def test_frozen_int8_layers_replay_a_prebuilt_plan(oa):
             Q.INDEX_GEMM = True
 
     # ---- autograd: a plan built under no_grad must NOT be replayed once autograd is recording and the weights / the input
-    # require grad - the replay is forward-only and would hand back tensors without grad_fn.  The full path's behaviour then (a
-    # differentiable result, or its forward-only error), with the plan-run counter unchanged.
+    # require grad.  The FULL path runs then (plan-run counter unchanged) and behaves as it always did: an input that requires grad is
+    # refused loudly (the HIP ops are forward-only); with only the parameters requiring grad, an eval-mode QuantLinear works on its
+    # cached, detached quantised weights exactly as the reference's does (base_quantized_classes.py: get_params), so the output carries
+    # no grad_fn there either - and the full path, not a replay of launches built for another autograd state, is what produced it.
     with torch.no_grad():
         qm(x, attention_mask=mask)
         assert both(qm, x, attention_mask=mask)[2] == 1                     # (a live plan for this geometry)
     before = qm.__dict__.get("_i8_plan_runs", 0)
     with torch.enable_grad():                                               # parameters require grad (the default after construction)
         assert any(p_.requires_grad for p_ in qm.parameters())
+        Q.I8_PLAN = False
         try:
-            out = qm(x, attention_mask=mask)[0]
-            assert out.requires_grad and out.grad_fn is not None
-        except Q.ops._lib.OehError:
-            pass                                                            # (forward-only path refusing loudly is also the full path's behaviour)
-        assert qm.__dict__.get("_i8_plan_runs", 0) == before
+            want = qm(x, attention_mask=mask)[0]                            # the full path in this autograd state (non-pair GEMM route)
+        finally:
+            Q.I8_PLAN = True
+        out = qm(x, attention_mask=mask)[0]
+        assert torch.equal(out, want) and qm.__dict__.get("_i8_plan_runs", 0) == before
         for p_ in qm.parameters():
             p_.requires_grad_(False)
         xg = x.clone().requires_grad_(True)                                 # frozen weights, an input that requires grad
-        try:
-            out = qm(xg, attention_mask=mask)[0]
-            assert out.requires_grad
-        except Q.ops._lib.OehError:
-            pass
+        with pytest.raises(Q.ops._lib.OehError, match="forward-only"):      # (not a silent replay without grad_fn)
+            qm(xg, attention_mask=mask)
         assert qm.__dict__.get("_i8_plan_runs", 0) == before
         assert both(qm, x, attention_mask=mask)[2] == 1                     # nothing requires grad: the plan again, although grad mode is on
 
