@@ -468,6 +468,33 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   // the ones operand of the row-sum MFMAs, kept in registers across the tile loop (round 6: it was rebuilt - five v_mov - in every tile)
   u4 ones_live = ones;
   asm volatile("" : "+v"(ones_live));
+  // Issue priority of the wave's two kinds of phase (matrix-core / vector).  OEH_PRIO_MODE (round 6 experiment, not landed: profiles/r06_headline_tile_asm.txt):
+  // 0 = production (1 / 0 for every wave); 1 = the workgroups of the upper half of the causal q tiles outrank the others in both phases (3 / 2 against 1 / 0);
+  // 2 = only the heaviest q tile's; 3 = a constant level by q tile, no boost for the matrix-core phases
+#ifndef OEH_PRIO_MODE
+#define OEH_PRIO_MODE 0
+#endif
+#if OEH_PRIO_MODE == 0
+  auto prio_hi = [&]() { __builtin_amdgcn_s_setprio(1); };
+  auto prio_lo = [&]() { __builtin_amdgcn_s_setprio(0); };
+#else
+#if OEH_PRIO_MODE == 1
+  const bool prio_heavy = causal && 2 * qt >= P.nQT;
+#elif OEH_PRIO_MODE == 2
+  const bool prio_heavy = causal && qt == P.nQT - 1;
+#else
+  const int prio_lvl = causal ? min(3, (4 * qt) / max(1, P.nQT)) : 0;
+#endif
+#if OEH_PRIO_MODE == 3
+  auto prio_set = [&]() { if (prio_lvl == 3) __builtin_amdgcn_s_setprio(3); else if (prio_lvl == 2) __builtin_amdgcn_s_setprio(2); else if (prio_lvl == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); };
+  prio_set();
+  auto prio_hi = [&]() {};
+  auto prio_lo = [&]() {};
+#else
+  auto prio_hi = [&]() { if (prio_heavy) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1); };
+  auto prio_lo = [&]() { if (prio_heavy) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); };
+#endif
+#endif
   // ---- one 64-key tile for blocks J0..MQ-1 of this wave (J0 = 1: block 0's rows end before this tile)
   // MODE 0: the one-pass tile; CLIP: 1 = statistics pass (no second product), 2 = final pass (final reference, clip)
   auto tile = [&](auto j0c, auto firstc, auto modec, auto nsc, const int i, const int soff, const bool in_tile_issue = false) {
@@ -501,7 +528,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
     return;
 #endif
     // S^T = K Q^T; every K fragment is read once and used by all active blocks
-    __builtin_amdgcn_s_setprio(1);  // matrix-core phases at a higher issue priority than the other waves' softmax arithmetic (dense S=512: -2.7 %)
+    prio_hi();  // matrix-core phases at a higher issue priority than the other waves' softmax arithmetic (dense S=512: -2.7 %)
     f4 s[MQ][4];
 #ifdef OEH_PIPE_QK
     // Round 6, measured and NOT landed (profiles/r06_headline_tile_asm.txt): the FIRST half of the steady-state tile as a placed order too - the scale /
@@ -557,7 +584,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       if (in_tile_issue) issue_advance();
 #endif
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(0);
+      prio_lo();
       scale_sub(3);
     }
 #pragma unroll
@@ -586,7 +613,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
         s[j][sub] = acc;
       }
     }
-    if constexpr (!PIPE_QK) __builtin_amdgcn_s_setprio(0);
+    if constexpr (!PIPE_QK) prio_lo();
     u4 pb[MQ][2];
 #if OEH_KO == 3
 #pragma unroll
@@ -889,7 +916,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
       read_v(0, va);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_nop 1" ::: "memory");   // (the hazard rule, whatever the scheduler did with the reads above)
-      __builtin_amdgcn_s_setprio(1);
+      prio_hi();
       // first half's NB (DT + 1) MFMAs, the exponentials of keys 32-63 (8 per block with all four sub-tiles, 4 with three, none with fewer) between them
       // (about one per gap: a v_exp_f32 is the 8 issue cycles an MFMA of this shape leaves), the conversions behind
       constexpr int E2_0 = (J0 == 0) ? 4 * (NSa[0] > 2 ? NSa[0] - 2 : 0) : 0;             // block 0's exponentials of the second half (not active: none)
@@ -931,10 +958,10 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
           for (int j = J0; j < MQ; ++j)
             if (NSa[j] > 2) mfma_acc(o[j][dt], va[dt], pb[j][1]);
       }
-      __builtin_amdgcn_s_setprio(0);
+      prio_lo();
       return;
     }
-    __builtin_amdgcn_s_setprio(1);
+    prio_hi();
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       if constexpr (MODE == 0) {
@@ -960,7 +987,7 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
         }
       }
     }
-    __builtin_amdgcn_s_setprio(0);
+    prio_lo();
   };
 
   auto finish_stats = [&]() {  // two-pass forms: the row's denominator from the lanes' shares
