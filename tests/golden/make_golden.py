@@ -906,13 +906,80 @@ def gen_cfg4_calib():
     torch.set_num_threads(1)
 
 
+def gen_vit_s16():
+    """vit_attn_s16.npz: ViTSelfAttentionWithExtras at ViT-S/16 size (C = 384, 6 heads of 64, N = 197 tokens: the ragged last key tile), B = 2;
+    softmax1, clipped softmax1 and a gated case; weights from synth.state_dict_like over the module's own state_dict names."""
+    from transformers_language.models.softmax import SOFTMAX_MAPPING
+    from transformers_language.models.vit_attention import AttentionGateType, ViTSelfAttentionWithExtras
+
+    sy = _load_synth()
+    x = torch.from_numpy(sy.vit_tokens(6301))
+    arrays, meta = {}, []
+    for i, (sm, gc) in enumerate((("softmax1", "nogate"), ("clippedsoftmax1(-.025:1)", "nogate"), ("softmax1", "tok_linear"))):
+        kw = dict(GATE_CASES[gc])
+        if "attn_gate_type" in kw:
+            kw["attn_gate_type"] = AttentionGateType[kw["attn_gate_type"]]
+        mod = _load_synth_weights(ViTSelfAttentionWithExtras(sy.VIT_C, num_heads=sy.VIT_H, qkv_bias=True, softmax_fn=SOFTMAX_MAPPING[sm], **kw), sy, 6310 + i, w_std=0.05)
+        with torch.no_grad():
+            arrays[f"[{sm}|{gc}].out"] = _np(mod(x))
+        meta.append(dict(softmax=sm, gate=gc, seed=6310 + i, w_std=0.05))
+    arrays["meta_json"] = np.array(json.dumps(meta))
+    save("vit_attn_s16.npz", **arrays)
+
+
+def gen_bert_int8_calib():
+    """bert_int8_calib.npz: the reference's QuantizedBertSelfAttentionWithExtras at BERT-base size (E = 768, H = 12, S = 128, B = 32) with a key-padding mask,
+    softmax1: quantiser scalars after each of 4 calibration batches (percentile 99.999, EMA 0.9), then index histograms of the three attention quantisers
+    and sampled outputs for the evaluation batch - the BERT twin of cfg4_calib.npz (quantized_bert.py:268-440: scores quantised before the mask, context after
+    the gate)."""
+    from transformers_language.models.bert_attention import BertSelfAttentionWithExtras
+    from transformers_language.models.quantized_bert import QuantizedBertSelfAttentionWithExtras
+    from transformers_language.models.softmax import SOFTMAX_MAPPING
+
+    sy = _load_synth()
+    B, S = sy.BI8_B, sy.BI8_S
+    torch.set_num_threads(8)
+    org = _load_synth_weights(BertSelfAttentionWithExtras(_Cfg12(), softmax_fn=SOFTMAX_MAPPING["softmax1"]), sy, sy.BI8_WEIGHT_SEED, w_std=0.05)
+    qmod = QuantizedBertSelfAttentionWithExtras(org, **_qparams())
+    qmod.set_quant_state(weight_quant=True, act_quant=True)
+    qmod.eval()
+    lens = sy.bi8_lengths()
+    mask = torch.from_numpy(sy.key_padding(B, S, [0] * B, [S - n for n in lens])).view(B, 1, 1, S)
+    arrays = {}
+    with torch.no_grad():
+        for i, seed in enumerate(sy.BI8_CALIB_SEEDS):
+            qmod(torch.from_numpy(sy.bi8_hidden(seed)), attention_mask=mask)
+            _dump_quantizers(f"after{i + 1}", qmod, arrays)
+        qmod.fix_ranges()
+        _dump_quantizers("final", qmod, arrays)
+        hist = {}
+
+        def mk(tag, m):
+            def hook(mod, inp, out):
+                idx = mod.activation_quantizer.quantizer.to_integer_forward(inp[0].detach())
+                hist[tag] = np.bincount(idx.to(torch.int64).flatten().numpy(), minlength=256).astype(np.int64)
+
+            return m.register_forward_hook(hook)
+
+        hs = [mk("scores", qmod.attn_scores_act_quantizer), mk("probs", qmod.attn_probs_act_quantizer), mk("ctx", qmod.context_act_quantizer)]
+        out = qmod(torch.from_numpy(sy.bi8_hidden(sy.BI8_EVAL_SEED)), attention_mask=mask)[0]
+        for h in hs:
+            h.remove()
+    for k_, v_ in hist.items():
+        arrays[f"eval.hist.{k_}"] = v_
+    arrays["eval.out_absmax"] = np.float64(float(out.abs().max()))
+    arrays["eval.out_sample"] = _np(out[::2, ::5, ::13])     # 16 x 26 x 60 sampled outputs
+    save("bert_int8_calib.npz", **arrays)
+    torch.set_num_threads(1)
+
+
 def main():
     only = set(sys.argv[1:])
     assert os.path.isdir(REF), "reference not mounted: golden fixtures can only be generated in the build container"
     torch.set_num_threads(1)  # deterministic reduction order for the captured outputs
     _shim()
     gens = [gen_softmax_rows, gen_fakequant, gen_range_estimators, gen_bert_fp, gen_opt_fp, gen_int8, gen_vit, gen_core_cases,
-            gen_stanhop, gen_theory_cfg1, gen_sparse_acts, gen_train_grads, gen_core_long, gen_h12, gen_cfg4_calib]
+            gen_stanhop, gen_theory_cfg1, gen_sparse_acts, gen_train_grads, gen_core_long, gen_h12, gen_cfg4_calib, gen_vit_s16, gen_bert_int8_calib]
     sys.path.insert(0, os.path.join(REF, "OutEffHop"))
     for fn in gens:  # `make_golden.py gen_vit` regenerates one file
         if not only or fn.__name__ in only:

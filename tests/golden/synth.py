@@ -85,3 +85,26 @@ def cfg4_hidden(seed: int) -> np.ndarray:
     x = normal(seed, (CFG4_B, CFG4_S, CFG4_E))
     x[..., [77, 380, 588]] *= 12.0
     return x
+
+
+# ---- ViT-S/16 attention at its own size (vit_attn_s16.npz): 197 tokens (196 patches + cls: not a multiple of 16), 6 heads of 64
+VIT_B, VIT_N, VIT_C, VIT_H = 2, 197, 384, 6
+
+
+def vit_tokens(seed: int) -> np.ndarray:
+    return normal(seed, (VIT_B, VIT_N, VIT_C))
+
+
+# ---- BERT-base INT8 validate flow at full size (bert_int8_calib.npz): B = 32, S = 128, E = 768, key padding, 4 calibration batches + 1 evaluation batch
+BI8_B, BI8_S, BI8_E, BI8_H = 32, 128, 768, 12
+BI8_CALIB_SEEDS, BI8_EVAL_SEED, BI8_WEIGHT_SEED = (2100, 2101, 2102, 2103), 2104, 2110
+
+
+def bi8_hidden(seed: int) -> np.ndarray:
+    x = normal(seed, (BI8_B, BI8_S, BI8_E))
+    x[..., [12, 300, 701]] *= 10.0
+    return x
+
+
+def bi8_lengths() -> list:
+    return [int(v) for v in np.random.RandomState(2120).randint(64, BI8_S + 1, size=BI8_B)]

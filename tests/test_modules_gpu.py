@@ -224,6 +224,92 @@ def test_modules_at_twelve_heads_against_the_reference(oa):
 # input is the quantised context, where one index flip in 1e5 among the ~60 largest outputs moves the 99.999th percentile)
 # eval on the reference's grids: 2.0e-3 of 41 440 sampled outputs one output-grid step off (never more) - every output sums 768 context indices
 # x weights, and the share of context indices that differ from the reference's by one step is 1.5e-5 (test_attn_gpu.py: cfg4 full size)
+def test_vit_small_size_against_the_reference(oa):
+    """ViT-S/16's attention at its own size (C = 384, 6 heads of 64, N = 197 tokens: three full key tiles + a ragged one of 5 keys - the tile the
+    one-pass kernel now specialises) against module outputs captured from the reference (vit_attn_s16.npz); fp32 and fp16 modules."""
+    from tests.golden import synth as sy
+
+    g = load_golden("vit_attn_s16.npz")
+    x = torch.from_numpy(sy.vit_tokens(6301)).cuda()
+    for c in json.loads(str(g["meta_json"])):
+        want = g[f"[{c['softmax']}|{c['gate']}].out"]
+        m = _load_synth(oa.ViTSelfAttentionWithExtras(sy.VIT_C, num_heads=sy.VIT_H, qkv_bias=True, softmax_fn=oa.SOFTMAX_MAPPING[c["softmax"]], **gate_kwargs(c["gate"])),
+                        c["seed"], c["w_std"]).cuda().eval()
+        with torch.no_grad():
+            got = m(x)
+            _close(got, want, f"vit-s {c} fp32", dict(atol=5e-4, rtol=5e-4))   # (measured 7e-5 ... 1.1e-4)
+            got16 = m.half()(x.half())
+        _close(got16, want, f"vit-s {c} fp16", dict(atol=2e-3, rtol=2e-3))   # (measured 3e-4 ... 6e-4)
+        print(f"vit-s {c['softmax']}|{c['gate']}: fp32 module max err {float(np.abs(got.cpu().numpy() - want).max()):.2e}, fp16 module {float(np.abs(got16.float().cpu().numpy() - want).max()):.2e}")
+
+
+def test_bert_int8_calibration_and_eval_at_full_size_against_the_reference(oa):
+    """The BERT twin of the cfg4 test: the reference's QuantizedBertSelfAttentionWithExtras at BERT-base size (E = 768, H = 12, S = 128, B = 32, key padding,
+    softmax1; quantized_bert.py:268-440) - quantiser scalars after every one of 4 calibration batches, then (on the reference's grids) sampled outputs and the
+    index histograms of the three attention quantisers for the evaluation batch (tests/golden/bert_int8_calib.npz)."""
+    from outeffhop_amd import ops
+    from tests.golden import synth as sy
+
+    class Cfg12(Cfg):
+        hidden_size = 768
+        num_attention_heads = 12
+        max_position_embeddings = 512
+
+    g = load_golden("bert_int8_calib.npz")
+    B, S, E, H = sy.BI8_B, sy.BI8_S, sy.BI8_E, sy.BI8_H
+    dev = torch.device("cuda:0")
+    org = _load_synth(oa.BertSelfAttentionWithExtras(Cfg12(), softmax_fn=oa.SOFTMAX_MAPPING["softmax1"]), sy.BI8_WEIGHT_SEED, 0.05)
+    qm = oa.QuantizedBertSelfAttentionWithExtras(org.to(dev), **_qparams(oa)).to(dev).eval()
+    qm.set_quant_state(weight_quant=True, act_quant=True)
+    lens = sy.bi8_lengths()
+    padv = torch.from_numpy(sy.key_padding(B, S, [0] * B, [S - n for n in lens])).to(dev)
+    mask = padv.view(B, 1, 1, S)
+    names = [n for n, m_ in qm.named_modules() if hasattr(m_, "quantizer") and not n.endswith("range_estimator")]
+    with torch.no_grad():
+        for i, seed in enumerate(sy.BI8_CALIB_SEEDS):
+            qm(torch.from_numpy(sy.bi8_hidden(seed)).to(dev), attention_mask=mask)
+            wd = wz = 0.0
+            for n in names:
+                qz = qm.get_submodule(n).quantizer
+                key = f"after{i + 1}.q.{n}.delta"
+                if key in g.files and getattr(qz, "_delta", None) is not None:
+                    wd = max(wd, abs(float(qz._delta) - float(g[key])) / float(g[key]))
+                    zk = f"after{i + 1}.q.{n}.zero_float"
+                    if zk in g.files:
+                        wz = max(wz, abs(float(qz._zero_float) - float(g[zk])))
+            print(f"bert int8 calibration batch {i + 1}: worst delta rel err {wd:.2e}, worst zero_float abs err {wz:.2e}")
+            assert wd <= CFG4_LIMITS["delta"] and wz <= CFG4_LIMITS["zero"], (i, wd, wz)
+        qm.fix_ranges()
+        for n in names:   # evaluation on the reference's grids (see the cfg4 test)
+            qz = qm.get_submodule(n).quantizer
+            if f"final.q.{n}.delta" in g.files and getattr(qz, "_delta", None) is not None:
+                qz._delta.copy_(torch.as_tensor(float(g[f"final.q.{n}.delta"]), dtype=qz._delta.dtype))
+                if f"final.q.{n}.zero_float" in g.files:
+                    qz._zero_float.copy_(torch.as_tensor(float(g[f"final.q.{n}.zero_float"]), dtype=qz._zero_float.dtype))
+        x = torch.from_numpy(sy.bi8_hidden(sy.BI8_EVAL_SEED)).to(dev)
+        out = qm(x, attention_mask=mask)[0]
+        step = float(g["final.q.context_act_quantizer.activation_quantizer.delta"])
+        err = np.abs(out[::2, ::5, ::13].float().cpu().numpy() - g["eval.out_sample"])
+        off, steps = float((err > 0.5 * step).mean()), float(err.max() / step)
+        print(f"bert int8 eval: sampled outputs > half a step off {off:.2e}, max error {steps:.2f} steps; |out| max {float(out.abs().max()):.4f} (reference {float(g['eval.out_absmax']):.4f})")
+        assert steps <= CFG4_LIMITS["steps"] and off <= CFG4_LIMITS["off"]
+        d = E // H
+        heads = lambda t: t.view(B, S, H, d).permute(0, 2, 1, 3)  # noqa: E731
+        q, k, v = heads(qm.query(x)), heads(qm.key(x)), heads(qm.value(x))
+        dumps = [torch.zeros((B, H, S, S), dtype=torch.uint8, device=dev), torch.zeros((B, H, S, S), dtype=torch.uint8, device=dev),
+                 torch.zeros((B, H, S, d), dtype=torch.uint8, device=dev)]
+        FQ = ops.FakeQuantSpec.from_delta
+        trio = [getattr(qm, n).activation_quantizer.quantizer for n in ("attn_scores_act_quantizer", "attn_probs_act_quantizer", "context_act_quantizer")]
+        fq = ops.AttnFakeQuant(*(FQ(float(z._delta), float(z._zero_float), dump=t_) for z, t_ in zip(trio, dumps)), ctx_before_gate=False)
+        ops.attn_fwd(q, k, v, fq=fq, scale_div=8.0, key_pad_mask=padv, mask_min=float(np.finfo(np.float32).min))
+        for name, t_ in zip(("scores", "probs", "ctx"), dumps):
+            h = torch.bincount(t_.flatten().to(torch.int64), minlength=256).cpu().numpy()
+            ref = g[f"eval.hist.{name}"]
+            moved = float(np.abs(h - ref).sum()) / 2.0 / float(ref.sum())
+            print(f"bert int8 eval {name} index histogram: share of indices in another bin than the reference's {moved:.2e}")
+            assert h.sum() == ref.sum() and moved <= CFG4_LIMITS["hist"], (name, moved)
+
+
 CFG4_LIMITS = dict(delta=2e-6, zero=2e-4, delta_out=1e-4, zero_out=1e-2, hist=1e-4, steps=1.05, off=4e-3)   # hist: measured 7e-6 / 2e-6 / 3.6e-5 (scores / probs / ctx); the suite's FLIP_RATE
 
 

@@ -312,3 +312,24 @@ def test_modules_at_twelve_heads_against_reference():
         b, ga, et = tbl[c["softmax"]]
         out = O.opt_attention(sd, hidden, H, mask=mask, base=b, gamma=ga, eta=et, clip=not (ga == 0.0 and et == 1.0))
         np.testing.assert_allclose(out, g[f"[{c['softmax']}|{c['gate']}].out"], err_msg=str(c), rtol=2e-5, atol=2e-5)
+
+
+def test_vit_small_size_against_reference():
+    """vit_attn_s16.npz: ViT-S/16's attention (C = 384, 6 heads, 197 tokens) - the un-gated cases through the oracle's core
+    (vit_attention.py:54-75,202-269: fused qkv Linear, q @ k^T * scale, softmax_fn, @ v, proj)."""
+    from tests.golden import synth as sy
+
+    g = load_golden("vit_attn_s16.npz")
+    tbl = O.softmax_table()
+    B, N, C, H = sy.VIT_B, sy.VIT_N, sy.VIT_C, sy.VIT_H
+    d = C // H
+    x = sy.vit_tokens(6301)
+    for c in json.loads(str(g["meta_json"])):
+        if c["gate"] != "nogate":
+            continue
+        sd = _synth_state({"qkv.weight": (3 * C, C), "qkv.bias": (3 * C,), "proj.weight": (C, C), "proj.bias": (C,)}, c["seed"], c["w_std"])
+        qkv = O.linear(x, sd["qkv.weight"], sd["qkv.bias"]).reshape(B, N, 3, H, d).transpose(2, 0, 3, 1, 4)
+        b, ga, et = tbl[c["softmax"]]
+        ctx = O.attn_core(qkv[0], qkv[1], qkv[2], scale=d ** -0.5, base=b, gamma=ga, eta=et, clip=not (ga == 0.0 and et == 1.0))
+        out = O.linear(O.merge_heads(ctx), sd["proj.weight"], sd["proj.bias"])
+        np.testing.assert_allclose(out, g[f"[{c['softmax']}|{c['gate']}].out"], err_msg=str(c), rtol=2e-5, atol=2e-5)
