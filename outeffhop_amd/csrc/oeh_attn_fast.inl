@@ -193,6 +193,9 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
 #define OEH_STAMP(slot) do { } while (0)
 #endif
   OEH_STAMP(0);
+#ifdef OEH_TIMELINE
+  if (stamp != nullptr && lane == 0) stamp[30] = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- Q rides the LDS-DMA stream, first, as a K-shaped tile in the V ring's last slot (first used by V tile R-1, long
   // after the operands below are in registers): the bytes in front of the first MFMA are Q + K tile 0, requested together,
   // instead of a register load of Q that had to land before the first transfer could even be issued.
@@ -875,6 +878,9 @@ __global__ __launch_bounds__(256, (fast_occupancy<NT, D, SRC32, GATE>())) void o
     }
   }
   OEH_STAMP(22);
+#ifdef OEH_TIMELINE
+  if (stamp != nullptr && lane == 0) stamp[31] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 #undef OEH_STAMP
 
