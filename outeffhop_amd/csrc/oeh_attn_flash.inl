@@ -209,12 +209,12 @@ __global__ __launch_bounds__(256, (flash_occupancy<D, MQ, SRC32>())) void oeh_at
   };
   // (round 6, OEH_PIPE_QK == 1: the same stage request in its 2 G pieces, so that the placed tile can put one behind each sub-tile's score MFMAs;
   // full stages only - the ragged last stage is never requested from inside a tile: the caller tests `nx_tile * 64 + 64 <= Sk`)
-  auto issue_piece = [&](const int p) {
+  [[maybe_unused]] auto issue_piece = [&](const int p) {
     const unsigned slot = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(nx_slot * STAGEB + wave * G * 1024));
     if (p < G) glds16_s(kcur, koff[p], slot + p * 1024);
     else glds16_s(vcur, voff[p - G], slot + TILEB + (p - G) * 1024);
   };
-  auto issue_advance = [&]() {
+  [[maybe_unused]] auto issue_advance = [&]() {
     kcur += kstep;
     vcur += vstep;
     ++nx_tile;
