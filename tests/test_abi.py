@@ -205,3 +205,35 @@ def test_built_library_disassembly_keeps_the_hand_kept_hazard_rules():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_disasm.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "findings: 0" in r.stdout
+
+
+def test_disassembly_rules_fire_on_synthetic_listings():
+    """Each rule of tools/check_disasm.py on a listing that breaks it (and not on the patterns the kernels really contain)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("check_disasm", os.path.join(ROOT, "tools", "check_disasm.py"))
+    cd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cd)
+
+    def run(body):
+        f, st = [], {}
+        cd.check_text("0000000000001000 <kernel_a>:\n" + body, f, st)
+        return f
+
+    ok = """\ts_mov_b32 m0, s56
+\ts_nop 0
+\tglobal_load_lds_dwordx4 v106, s[16:17]
+\tv_exp_f32_e32 v78, v78
+\ts_nop 0
+\tv_cvt_pk_f16_f32 v78, v78, v79
+\tv_exp_f32_e32 v80, v80
+\tv_exp_f32_e32 v81, v81
+\tv_mfma_f32_16x16x32_f16 v[86:89], v[132:135], v[74:77], v[86:89]
+"""
+    assert run(ok) == []
+    assert any("trans -> VALU" in x for x in run("\tv_exp_f32_e32 v78, v78\n\tv_cvt_pk_f16_f32 v1, v78, v79\n"))
+    assert any("trans -> VALU" in x for x in run("\\tv_rcp_f32_e32 v5, v6\\n\\tv_pk_mul_f32 v[8:9], v[4:5], v[10:11]\\n"))   # (register ranges are parsed too)
+    assert run("\tv_exp_f32_e32 v78, v78\n\tv_cvt_pk_f16_f32 v78, v79, v80\n") == []      # overwrites, does not read
+    assert any("M0 user" in x for x in run("\ts_set_gpr_idx_on s4, gpr_idx(SRC0)\n"))
+    assert any("M0 operand" in x for x in run("\tv_readlane_b32 s5, v3, m0\n"))
+    assert run("\ts_mov_b32 s7, m0\n\ts_mov_b32 m0, s7\n") == []                           # the save / restore forms of -DOEH_KEEP_M0 builds

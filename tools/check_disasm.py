@@ -44,13 +44,17 @@ def regs_of(tok: str):
 
 def check_code_object(co: str, findings: list, stats: dict):
     dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", "--no-leading-addr", co], capture_output=True, text=True).stdout
+    check_text(dis, findings, stats)
+
+
+def check_text(dis: str, findings: list, stats: dict):
+    """The rules on one disassembly listing (llvm-objdump -d text); tests/test_abi.py feeds it synthetic listings to show each rule fires."""
     kernel = "?"
     prev = None  # (mnemonic, operands)
-    window = []  # the last instructions, for the M0 request pattern
     for line in dis.splitlines():
         m = re.match(r"^[0-9a-f]* ?<(\S+)>:", line)
         if m:
-            kernel, prev, window = m.group(1), None, []
+            kernel, prev = m.group(1), None
             continue
         t = line.split("//")[0].strip()
         if not t or t.startswith(".") or t.endswith(":"):
@@ -69,7 +73,7 @@ def check_code_object(co: str, findings: list, stats: dict):
             else:
                 stats["m0_writes"] = stats.get("m0_writes", 0) + 1
         # ---- 2. trans -> reader
-        if prev is not None and prev[0].split("_e")[0] in TRANS or (prev is not None and any(prev[0].startswith(x) for x in TRANS)):
+        if prev is not None and any(prev[0].startswith(x) for x in TRANS):
             dst = regs_of(prev[1].split(",")[0])
             srcs = ops.split(",", 1)[1] if "," in ops else ""
             is_trans = any(mn.startswith(x) for x in TRANS)
