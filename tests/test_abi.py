@@ -232,7 +232,7 @@ def test_disassembly_rules_fire_on_synthetic_listings():
 """
     assert run(ok) == []
     assert any("trans -> VALU" in x for x in run("\tv_exp_f32_e32 v78, v78\n\tv_cvt_pk_f16_f32 v1, v78, v79\n"))
-    assert any("trans -> VALU" in x for x in run("\\tv_rcp_f32_e32 v5, v6\\n\\tv_pk_mul_f32 v[8:9], v[4:5], v[10:11]\\n"))   # (register ranges are parsed too)
+    assert any("trans -> VALU" in x for x in run("\tv_rcp_f32_e32 v5, v6\n\tv_pk_mul_f32 v[8:9], v[4:5], v[10:11]\n"))   # (register ranges are parsed too)
     assert run("\tv_exp_f32_e32 v78, v78\n\tv_cvt_pk_f16_f32 v78, v79, v80\n") == []      # overwrites, does not read
     assert any("M0 user" in x for x in run("\ts_set_gpr_idx_on s4, gpr_idx(SRC0)\n"))
     assert any("M0 operand" in x for x in run("\tv_readlane_b32 s5, v3, m0\n"))
